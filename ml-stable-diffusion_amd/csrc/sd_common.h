@@ -1,0 +1,85 @@
+// Common host/device definitions for libsdmi355 (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace sd {
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+// ---- errors: C++ exceptions inside, int status + thread-local string at the C ABI ------------
+enum Status : int {
+  kOk = 0,
+  kInvalidArgument = -1,   // Python wrapper raises ValueError / TypeError
+  kNotFound = -2,          // FileNotFoundError / KeyError (missing weight)
+  kHipError = -3,          // RuntimeError
+  kUnsupported = -4,       // NotImplementedError
+  kInternal = -5,
+};
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+[[noreturn]] void fail(int code, const char* fmt, ...);
+
+#define SD_HIP(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess)                                                                    \
+      ::sd::fail(::sd::kHipError, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),     \
+                 __FILE__, __LINE__);                                                        \
+  } while (0)
+
+#define SD_REQUIRE(cond, code, ...)            \
+  do {                                         \
+    if (!(cond)) ::sd::fail((code), __VA_ARGS__); \
+  } while (0)
+
+// ---- device memory ---------------------------------------------------------------------------
+// One arena per model handle: a single hipMalloc carved by a bump pointer (256-B aligned).
+// 288 GB of HBM per GPU means we never recycle activation buffers inside a forward: every
+// tensor of the static graph owns its bytes, which is what makes HIP-graph replay trivially safe.
+class Arena {
+ public:
+  Arena() = default;
+  ~Arena();
+  Arena(const Arena&) = delete;
+  Arena& operator=(const Arena&) = delete;
+  // two-phase: plan (count bytes) then commit (allocate) then hand out pointers in the same order
+  void* alloc(size_t bytes);
+  void commit();             // allocate everything planned so far; later alloc() calls carve it
+  size_t planned() const { return planned_; }
+  size_t capacity() const { return capacity_; }
+  bool committed() const { return base_ != nullptr; }
+
+ private:
+  char* base_ = nullptr;
+  size_t planned_ = 0, capacity_ = 0, cursor_ = 0;
+  std::vector<size_t> plan_;   // sizes requested before commit (re-issued in order after commit)
+  size_t replay_ = 0;
+};
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+};
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace sd

@@ -1,0 +1,131 @@
+"""Oracle (test infrastructure): scheduler step math either side of the UNet.
+
+DDIM is third-party in the reference (diffusers==0.30.2, setup.py:18; call sites
+python_coreml_stable_diffusion/pipeline.py:475-476, 504-505, 565-569) and none of the
+reference's tests pin its numerics -> **PARITY UNPINNED** for DDIM: restated from the public
+algorithm (DDIM paper eq. 12, eta = 0) with SD2.1-base's scheduler config
+(scaled-linear betas 0.00085..0.012 over 1000 steps, steps_offset=1, set_alpha_to_one=False,
+clip_sample=False, epsilon prediction, "leading" spacing).
+
+PNDM/PLMS is restated from the reference's own Swift implementation
+swift/StableDiffusion/pipeline/Scheduler.swift:137-344 (float32 tables like the Swift code).
+No golden vectors exist for either in the reference.
+"""
+import numpy as np
+
+
+def scaled_linear_betas(n_train=1000, beta_start=0.00085, beta_end=0.012):
+    """Scheduler.swift:168-173 (.scaledLinear)."""
+    return np.linspace(beta_start ** 0.5, beta_end ** 0.5, n_train, dtype=np.float32) ** 2
+
+
+def alphas_cumprod(betas):
+    return np.cumprod(1.0 - betas.astype(np.float32), dtype=np.float32)
+
+
+class DDIM:
+    """eta = 0, leading spacing, steps_offset = 1."""
+
+    init_noise_sigma = 1.0
+
+    def __init__(self, n_train=1000, beta_start=0.00085, beta_end=0.012):
+        self.n_train = n_train
+        self.acp = alphas_cumprod(scaled_linear_betas(n_train, beta_start, beta_end))
+        self.final_alpha_cumprod = self.acp[0]          # set_alpha_to_one=False
+
+    def set_timesteps(self, n):
+        self.n = n
+        ratio = self.n_train // n
+        self.timesteps = (np.arange(n) * ratio).round()[::-1].astype(np.int64) + 1
+        return self.timesteps
+
+    def scale_model_input(self, x, t):
+        return x
+
+    def coefficients(self, t):
+        """x_prev = cx*x + ce*eps  (both float64 scalars)."""
+        t_prev = t - self.n_train // self.n
+        a_t = float(self.acp[t])
+        a_p = float(self.acp[t_prev]) if t_prev >= 0 else float(self.final_alpha_cumprod)
+        cx = (a_p / a_t) ** 0.5
+        ce = (1.0 - a_p) ** 0.5 - (a_p * (1.0 - a_t) / a_t) ** 0.5
+        return cx, ce
+
+    def step(self, eps, t, x):
+        t_prev = t - self.n_train // self.n
+        a_t = self.acp[t]
+        a_p = self.acp[t_prev] if t_prev >= 0 else self.final_alpha_cumprod
+        x0 = (x - (1 - a_t) ** 0.5 * eps) / a_t ** 0.5
+        return a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * eps
+
+
+class PNDM:
+    """Scheduler.swift:137-344 (PLMS, skip_prk_steps)."""
+
+    init_noise_sigma = 1.0
+
+    def __init__(self, n_train=1000, beta_start=0.00085, beta_end=0.012):
+        self.n_train = n_train
+        self.acp = alphas_cumprod(scaled_linear_betas(n_train, beta_start, beta_end))
+
+    def set_timesteps(self, n):
+        self.n = n
+        ratio = float(self.n_train // n)
+        fwd = [int(round(i * ratio)) + 1 for i in range(n)]       # Scheduler.swift:188-192
+        ts = fwd[:-1] + [fwd[-2]] + [fwd[-1]]                      # :198-202
+        self.timesteps = np.array(ts[::-1], dtype=np.int64)
+        self.counter, self.ets, self.cur = 0, [], None
+        return self.timesteps
+
+    def scale_model_input(self, x, t):
+        return x
+
+    def step(self, eps, t, x):
+        inc = self.n_train // self.n
+        prev = t - inc
+        if self.counter != 1:                                      # :228-236
+            self.ets = self.ets[-3:]
+            self.ets.append(eps)
+        else:
+            prev, t = t, t + inc
+        e = self.ets
+        if len(e) == 1 and self.counter == 0:
+            out, self.cur = eps, x
+        elif len(e) == 1 and self.counter == 1:
+            out, x, self.cur = 0.5 * eps + 0.5 * e[-1], self.cur, None
+        elif len(e) == 2:
+            out = 1.5 * e[-1] - 0.5 * e[-2]
+        elif len(e) == 3:
+            out = (23 * e[-1] - 16 * e[-2] + 5 * e[-3]) / 12.0
+        else:
+            out = (55 * e[-1] - 59 * e[-2] + 37 * e[-3] - 9 * e[-4]) / 24.0
+        self.counter += 1
+        a_t, a_p = self.acp[t], self.acp[max(0, prev)]             # :315-343
+        sample_coeff = (a_p / a_t) ** 0.5
+        denom = a_t * (1 - a_p) ** 0.5 + (a_t * (1 - a_t) * a_p) ** 0.5
+        return sample_coeff * x - (a_p - a_t) / denom * out
+
+
+def cfg_combine(noise_uncond, noise_text, guidance_scale):
+    """pipeline.py:561-562."""
+    return noise_uncond + guidance_scale * (noise_text - noise_uncond)
+
+
+def denoise_loop(unet_fn, scheduler, latents, text_embeddings, n_steps, guidance_scale, callback=None):
+    """pipeline.py:500-573 restated: duplicate latents, fp16 cast at the UNet boundary,
+    timestep [t,t] as fp16, CFG combine, scheduler step in fp32 on the host."""
+    timesteps = scheduler.set_timesteps(n_steps)
+    latents = latents.astype(np.float32) * scheduler.init_noise_sigma
+    do_cfg = guidance_scale > 1.0                                  # pipeline.py:443
+    for i, t in enumerate(timesteps):
+        x = np.concatenate([latents] * 2) if do_cfg else latents
+        x = scheduler.scale_model_input(x, t)
+        ts = np.array([t, t] if do_cfg else [t], np.float16)
+        eps = unet_fn(x.astype(np.float16), ts, text_embeddings.astype(np.float16))
+        if do_cfg:
+            u, c = np.split(eps, 2)
+            eps = cfg_combine(u, c, guidance_scale)
+        latents = scheduler.step(eps.astype(np.float32), int(t), latents.astype(np.float32))
+        if callback is not None:
+            callback(i, t, latents)
+    return latents
