@@ -1,0 +1,185 @@
+#!/usr/bin/env python
+"""Headline benchmark: diffusion iter/s (UNet steps/s) of SD2.1-base 512x512 fp16 on MI355X.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one iteration of the reference's denoising loop (pipeline.py:500-573; iter/s as
+defined by swift/StableDiffusionCLI/main.swift:225-257): duplicate latents for classifier-free
+guidance, one UNet forward at CFG batch 2 per prompt, guidance combine, scheduler (DDIM) update -
+all device-resident, inputs already in HBM when the timed region starts.  Weights are random-init
+tensors of the SD2.1-base architecture (865.9 M parameters; no checkpoints exist offline) and the
+latents / text embeddings are synthetic N(0,1) of the real shapes.
+
+Multi-GPU: independent prompts shard over ranks (one process per GPU, no data-path collective;
+RCCL only broadcasts the text embeddings at start and gathers the final latents at the end, both
+outside the timed region) -> weak scaling; value = all prompts' steps / max-over-ranks time.
+
+Extra objects on the JSON line:
+  roofline     MFMA roofline of the step graph: algorithmic FLOP per step (SURVEY.md section 8d:
+               1.6085e12 per CFG-batch-2 step) / HIP-event time per step on the handle's stream
+  cpu_baseline the oracle (CPU restatement of the reference UNet + loop) timed on this box's host
+               cores on a bounded sample (rank 0, N=1 only); kind "port"
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "ml-stable-diffusion_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+FLOP_PER_SAMPLE_STEP = 1.6085e12 / 2     # 804.3 GFLOP per latent sample
+MFMA_PEAK_TFLOPS = 2500.0                # MI355X dense fp16/bf16 (MI355X_MICROARCH.md)
+PUBLISHED_BEST_ITS = 3.07                # best published SD2.1-base it/s (iPad Pro M2, Core ML)
+MODEL = "stabilityai/stable-diffusion-2-1-base"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--prompts-per-gpu", type=int, default=1)
+    ap.add_argument("--attention", default="ORIGINAL", choices=["ORIGINAL", "SPLIT_EINSUM", "SPLIT_EINSUM_V2"])
+    ap.add_argument("--guidance-scale", type=float, default=7.5)
+    ap.add_argument("--cpu-steps", type=int, default=2, help="oracle steps timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from python_hip_stable_diffusion import HipModel, checkpoint, schedulers
+    from python_hip_stable_diffusion.parallel import broadcast_array, gather_arrays, shard_prompts
+
+    ppg = args.prompts_per_gpu
+    t_build = time.time()
+    shapes = checkpoint.unet_param_shapes(MODEL)
+    ckpt = checkpoint.random_checkpoint(shapes, seed=0)
+    model = HipModel(MODEL, ckpt, batch=2 * ppg, attention_implementation=args.attention, device=local_rank,
+                     use_graph=not args.no_graph)
+    build_s = time.time() - t_build
+
+    # prompts are independent units: rank r owns global prompts shard_prompts(...)[r]
+    mine = shard_prompts(world * ppg, world)[rank]
+    ehs = None
+    if rank == 0:   # "text embeddings" for all prompts, [uncond | cond] halves per prompt
+        ehs = np.random.RandomState(94).randn(world * ppg, 2, 1024, 1, 77).astype(np.float16)
+    ehs = broadcast_array(ehs, (world * ppg, 2, 1024, 1, 77), np.float16, dist, local_rank)
+    my_ehs = np.concatenate([ehs[mine, 0], ehs[mine, 1]])          # batch order [uncond..., cond...] (pipeline.py:245)
+    latents = np.stack([np.random.RandomState(93 + g).randn(4, 64, 64) for g in mine]).astype(np.float32)
+
+    sch = schedulers.DDIMScheduler()
+
+    def run(n_steps):
+        sch.set_timesteps(max(n_steps, 1))
+        ts, coef, hist = sch.device_tables()
+        return model.denoise_loop(latents * sch.init_noise_sigma, ts, coef, args.guidance_scale, history=hist,
+                                  encoder_hidden_states=my_ehs)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        run(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    final, ev_ms = run(args.steps)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+    assert np.isfinite(final).all()
+    all_final = gather_arrays(final, dist, local_rank)               # outside the timed region
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    total_prompt_steps = world * ppg * args.steps
+    value = total_prompt_steps / elapsed
+    ev_ms_step = float(np.median(ev_ms))
+    flop_per_launch = FLOP_PER_SAMPLE_STEP * 2 * ppg
+    achieved = flop_per_launch / (ev_ms_step * 1e-3) / 1e12
+    out = {
+        "metric": "diffusion iter/s (UNet steps/s), SD2.1-base 512x512 fp16",
+        "value": round(value, 3), "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": round(value / PUBLISHED_BEST_ITS, 2),
+        "vs_baseline_note": "BASELINE.md best published SD2.1-base number: 3.07 it/s, iPad Pro (M2), Core ML "
+                            "6-bit palettized (README.md:74); no published CPU/GPU-server number exists",
+        "dtype": "fp16", "data": "synthetic",
+        "config": {"workload": "SD2.1-base UNet denoising iteration, 512x512 (64x64 latents), CFG batch 2 per prompt, "
+                               "DDIM, device-resident loop", "model": MODEL, "attention": args.attention,
+                   "prompts_per_gpu": ppg, "global_batch": 2 * ppg * world, "seq_len": 4096,
+                   "guidance_scale": args.guidance_scale, "hip_graph": not args.no_graph,
+                   "parallelism": f"dp{world} (independent prompts per rank, no data-path collective)"},
+        "roofline": {"bound": "mfma", "kernel": "unet_step_graph (all MFMA conv/GEMM/attention launches of one step)",
+                     "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                     "flop_per_launch": flop_per_launch, "launch_ms": round(ev_ms_step, 4),
+                     "timing": "hipEvent on the handle's stream, median over timed steps"},
+        "e2e": {"model_build_s": round(build_s, 1), "final_latents_finite": True,
+                "gathered_latents": list(all_final.shape), "hbm_bytes": int(model.device_bytes)},
+    }
+    if world == 1 and args.cpu_steps > 0:
+        out["cpu_baseline"] = cpu_baseline(ckpt, my_ehs[[0, ppg]], latents[:1], args.cpu_steps, args.guidance_scale)
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(ckpt, ehs, latents, n_steps, guidance):
+    """The oracle (CPU port of the reference UNet, oracle/unet_ref.py, driven by the restated
+    pipeline loop, oracle/scheduler_ref.py) on this box's host cores: 1 untimed + n timed steps
+    of the same workload (same weights, same shapes).  Checker code used as a reported baseline,
+    never as the product path."""
+    import torch
+
+    from oracle import scheduler_ref, unet_ref, weights
+    cfg = unet_ref.CONFIGS["sd21-base"]
+    sd = weights.to_torch({k: v.astype(np.float32) for k, v in ckpt.items()})
+    times = []
+
+    def unet(x, t, e):
+        t0 = time.perf_counter()
+        y = unet_ref.unet_forward(sd, cfg, torch.from_numpy(x.astype(np.float32)), torch.from_numpy(t.astype(np.float32)),
+                                  torch.from_numpy(e.astype(np.float32))).numpy()
+        times.append(time.perf_counter() - t0)
+        return y
+
+    t0 = time.perf_counter()
+    scheduler_ref.denoise_loop(unet, scheduler_ref.DDIM(), latents, ehs, n_steps + 1, guidance)
+    total = time.perf_counter() - t0
+    per = float(np.median(times[1:]))
+    return {"value": round(1.0 / per, 4), "unit": "it/s", "cores": int(torch.get_num_threads()),
+            "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": f"{n_steps} timed + 1 warm-up CFG-batch-2 steps of the same SD2.1-base loop, torch-CPU fp32 "
+                      f"({total:.1f} s total)", "s_per_step": round(per, 3)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,178 @@
+/* libsdmi355 - C ABI of the MI355X-native Stable Diffusion hot path.
+ *
+ * This is the drop-in boundary for the model-runner seam of apple/ml-stable-diffusion:
+ *   python_coreml_stable_diffusion/coreml_model.py:36-120   CoreMLModel(**np.ndarray) -> dict
+ *   swift/StableDiffusion/pipeline/Unet.swift:90-144        Unet.predictNoise
+ *   swift/StableDiffusion/pipeline/ManagedMLModel.swift:11-127 (load / perform / unload)
+ * Each entry point below names the reference interface it replaces.  Plain pointers and sizes
+ * only; no torch / numpy types.  All functions return 0 on success or a negative sd_status and
+ * leave a message retrievable with sd_last_error() (thread-local).  A handle is NOT thread-safe
+ * (one HIP stream per handle, like the one serial DispatchQueue per model of
+ * ManagedMLModel.swift:24-69); different handles may be driven from different threads.
+ *
+ * Tensor conventions at the boundary are the reference's: NCHW images, BC1S sequences, fp16
+ * inputs, fp32 outputs (python_coreml_stable_diffusion/torch2coreml.py:135, :857-863).
+ */
+#ifndef SD_MI355X_H
+#define SD_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum sd_status {
+  SD_OK = 0,
+  SD_ERR_INVALID_ARGUMENT = -1, /* wrong shape/dtype/flag      -> TypeError / ValueError (coreml_model.py:97-116) */
+  SD_ERR_NOT_FOUND = -2,        /* missing file / weight key   -> FileNotFoundError (coreml_model.py:176-178)     */
+  SD_ERR_HIP = -3,              /* HIP runtime failure         -> RuntimeError                                     */
+  SD_ERR_UNSUPPORTED = -4,      /* config outside the path     -> NotImplementedError (unet.py:835-880)            */
+  SD_ERR_INTERNAL = -5
+} sd_status;
+
+typedef enum sd_dtype { SD_F16 = 0, SD_F32 = 1 } sd_dtype;
+
+/* unet.py:33-36 AttentionImplementations; a per-handle field here instead of the reference's
+ * module global unet.py:39 (conversion-time flag torch2coreml.py:1678-1685). */
+typedef enum sd_attention_impl {
+  SD_ATTN_ORIGINAL = 0,
+  SD_ATTN_SPLIT_EINSUM = 1,
+  SD_ATTN_SPLIT_EINSUM_V2 = 2
+} sd_attention_impl;
+
+const char* sd_last_error(void);
+const char* sd_version(void);
+/* number of visible HIP devices (<0: error).  The library never falls back to the CPU. */
+int sd_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Checkpoints.  Replaces `load_state_dict` of torch2coreml.py:917-918 + the two load hooks of
+ * unet.py:121-146: tensors are handed over with their diffusers key names AS-IS (Linear weights
+ * may be 2-D or 4-D; LayerNorm bias is the checkpoint's, not the reference's rewritten b/w).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct sd_weights sd_weights;
+int sd_weights_create(sd_weights** out);
+/* copies `data` (host memory); shape has ndim entries */
+int sd_weights_add(sd_weights* w, const char* name, const void* data, sd_dtype dtype, const int64_t* shape,
+                   int ndim);
+/* parse a .safetensors file (F16 / F32 / BF16 tensors); `prefix` (may be NULL) is stripped */
+int sd_weights_load_safetensors(sd_weights* w, const char* path, const char* prefix);
+int sd_weights_count(const sd_weights* w);
+void sd_weights_destroy(sd_weights* w);
+
+/* ------------------------------------------------------------------------------------------
+ * UNet / ControlNet.  Config mirrors UNet2DConditionModel.__init__ (unet.py:801-833) with the
+ * static shapes Core ML bakes in at conversion time (torch2coreml.py:827-863).
+ * ------------------------------------------------------------------------------------------ */
+#define SD_MAX_LEVELS 6
+
+typedef struct sd_unet_config {
+  int32_t batch;                 /* UNet batch (2 = classifier-free guidance for one image)          */
+  int32_t in_channels, out_channels;
+  int32_t height, width;         /* latent size (image / 8)                                          */
+  int32_t n_levels;
+  int32_t block_out_channels[SD_MAX_LEVELS];
+  int32_t down_cross_attn[SD_MAX_LEVELS];   /* 1: CrossAttnDownBlock2D, 0: DownBlock2D               */
+  int32_t up_cross_attn[SD_MAX_LEVELS];     /* 1: CrossAttnUpBlock2D,  0: UpBlock2D (up order)       */
+  int32_t layers_per_block;
+  int32_t attention_head_dim[SD_MAX_LEVELS];           /* = NUMBER of heads (unet.py:194-198, :912)  */
+  int32_t transformer_layers_per_block[SD_MAX_LEVELS];
+  int32_t cross_attention_dim;
+  int32_t context_len;           /* 77                                                               */
+  int32_t norm_num_groups;       /* 32                                                               */
+  float norm_eps;                /* 1e-5                                                             */
+  int32_t flip_sin_to_cos;       /* 1                                                                */
+  float freq_shift;              /* 0                                                                */
+  int32_t addition_time_embed_dim;                 /* 0: none; SDXL 256 (text_time)                  */
+  int32_t projection_class_embeddings_input_dim;   /* SDXL 2816 / refiner 2560                       */
+  int32_t num_time_ids;          /* SDXL base 6, refiner 5                                           */
+  int32_t support_controlnet;    /* UNet: consume additional_residual_0..N (unet.py:1009-1022)       */
+  int32_t is_controlnet;         /* build controlnet.py:49-250 instead of the UNet                   */
+  int32_t attention_impl;        /* sd_attention_impl                                                */
+  int32_t use_graph;             /* 1: capture the forward into a HIP graph and replay it            */
+} sd_unet_config;
+
+typedef struct sd_unet sd_unet;
+
+/* replaces CoreMLModel.__init__ / _load_mlpackage (coreml_model.py:40-95, :155-203) and
+ * ManagedMLModel.loadResources (ManagedMLModel.swift:40-47) */
+int sd_unet_create(const sd_unet_config* cfg, const sd_weights* w, int device, sd_unet** out);
+/* ManagedMLModel.unloadResources (ManagedMLModel.swift:49-52) */
+void sd_unet_destroy(sd_unet* u);
+int sd_unet_set_attention(sd_unet* u, int impl);
+int sd_unet_num_residuals(const sd_unet* u); /* controlnet.py:191-197 */
+/* bytes of HBM held by the handle (weights + activations) */
+size_t sd_unet_device_bytes(const sd_unet* u);
+
+#define SD_FLAG_DEVICE_PTRS 1 /* all data pointers are device pointers on the handle's GPU */
+
+typedef struct sd_unet_io {
+  const void* sample;                /* (B, in_channels, H, W) f16                                   */
+  const void* timestep;              /* (B,) f16                                                     */
+  const void* encoder_hidden_states; /* (B, cross_attention_dim, 1, context_len) f16 BC1S            */
+  const void* time_ids;              /* SDXL: (B, num_time_ids) f16, else NULL                       */
+  const void* text_embeds;           /* SDXL: (B, proj_dim - num_time_ids*addition_time_embed_dim) f16 */
+  const void* controlnet_cond;       /* ControlNet: (B, 3, 8H, 8W) f16                               */
+  const void* const* additional_residuals; /* UNet w/ support_controlnet: N pointers, f16 NCHW        */
+  int32_t num_additional_residuals;
+  void* noise_pred;                  /* UNet out: (B, out_channels, H, W) f32                        */
+  void* const* residual_outputs;     /* ControlNet out: N pointers, f32 NCHW                         */
+  int32_t flags;
+} sd_unet_io;
+
+/* replaces CoreMLModel.__call__ -> MLModel.predict (coreml_model.py:118-120; call site
+ * pipeline.py:531-536) and Unet.predictNoise (Unet.swift:90-144).  Synchronous. */
+int sd_unet_forward(sd_unet* u, const sd_unet_io* io);
+
+/* Timing on the handle's own stream with HIP events: runs `iters` forwards on the inputs of
+ * the last sd_unet_forward call and returns the mean milliseconds per forward. */
+int sd_unet_time_forward(sd_unet* u, int warmup, int iters, float* ms_per_iter);
+
+/* Device-resident denoising loop (pipeline.py:500-573 with latents, CFG combine and scheduler
+ * update never leaving HBM).  latents: (n_images, C, H, W) f32 host in/out; the UNet batch must
+ * be cfg * n_images with cfg = (guidance_scale > 1 ? 2 : 1) (pipeline.py:443).  `timesteps`
+ * (n_steps) and `coef` (n_steps x 8: x_prev = coef[0]*x + coef[1]*eps + sum_j coef[2+j]*eps_hist[j])
+ * come from the host-side scheduler tables.  The encoder_hidden_states / SDXL extras are taken
+ * from `io`.  ms_per_step (may be NULL) receives HIP-event time per loop iteration. */
+int sd_unet_denoise_loop(sd_unet* u, const sd_unet_io* io, float* latents, int n_images, int n_steps,
+                         const float* timesteps, const float* coef, int history, float guidance_scale,
+                         float* ms_per_step);
+
+/* ------------------------------------------------------------------------------------------
+ * Operator-level entry points (what the parity tests and micro-benchmarks bind).  Host
+ * pointers unless SD_FLAG_DEVICE_PTRS; each call is synchronous on an internal stream.
+ * `ms` (may be NULL) returns HIP-event kernel time averaged over `iters` (>=1) launches.
+ * ------------------------------------------------------------------------------------------ */
+/* attention.py:24-168.  q (B, h*d, 1, Sq), k/v (B, h*d, 1, Sk) f16 BC1S -> out (B, h*d, 1, Sq) f16 */
+int sd_op_attention(int impl, const void* q, const void* k, const void* v, void* out, int B, int heads, int d,
+                    int Sq, int Sk, int variant, int iters, float* ms);
+/* layer_norm.py:51-80.  x (B, C, 1, S) f16, weight/bias (C) f32 -> out (B, C, 1, S) f16 */
+int sd_op_layernorm(const void* x, const float* weight, const float* bias, void* out, int B, int C, int S, float eps,
+                    int iters, float* ms);
+/* torch.nn.GroupNorm (+ optional SiLU) as used by unet.py:430-451,:472-481,:528-531.  NCHW f16 */
+int sd_op_groupnorm(const void* x, const float* weight, const float* bias, void* out, int B, int C, int H, int W,
+                    int groups, float eps, int silu, int iters, float* ms);
+/* nn.Conv2d as used by unet.py (k in {1,3}, stride in {1,2}, padding k/2), optional nearest x2
+ * upsample before the conv (unet.py:498-500), optional residual add.  x (B,Cin,H,W) f16 NCHW,
+ * w (Cout,Cin,k,k) f16, bias (Cout) f32 or NULL, res (B,Cout,Ho,Wo) f16 or NULL -> out f16 NCHW.
+ * tile/splitk: 0 = heuristic (tuning hooks). force_generic: 1 = direct non-MFMA kernel. */
+int sd_op_conv2d(const void* x, const void* w, const float* bias, const void* res, void* out, int B, int Cin, int H,
+                 int W, int Cout, int ksize, int stride, int upsample, int tile, int splitk, int force_generic,
+                 int iters, float* ms);
+/* GEGLU feed-forward first half (unet.py:609-617): x (M, C) f16, w (8C', C) f16, bias (8C'/.. ) */
+int sd_op_geglu(const void* x, const void* w, const float* bias, void* out, int M, int C, int N2, int iters, float* ms);
+/* unet.py:703-728 */
+int sd_op_timestep_embedding(const float* t, float* out, int n, int dim, int flip_sin_to_cos, float freq_shift);
+/* numpy legacy stream: np.random.seed(seed); np.random.randn(n) (pipeline.py:331,:726;
+ * NumPyRandomSource.swift:28-102).  Host-side, bit-exact. */
+int sd_numpy_randn(uint32_t seed, double* out, size_t n);
+/* MFMA fragment layout self-check used by the build/smoke tests (returns 0 when the hardware
+ * layout matches what the kernels assume). */
+int sd_selftest_mfma(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SD_MI355X_H */

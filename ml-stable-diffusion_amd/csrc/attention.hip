@@ -1,0 +1,426 @@
+// K1-K3 - streaming-softmax multi-head attention on gfx950 MFMA, three schedules mirroring
+// python_coreml_stable_diffusion/attention.py (selected at run time like unet.py:51-59):
+//
+//   ORIGINAL         attention.py:147-168  heads batched in the grid, score tile oriented [q][k]
+//                    (the reference's "bhqk"), softmax over k = ACROSS LANES: row max by DPP
+//                    wavefront shuffles, P re-laid-out through a wave-private LDS tile for P.V.
+//   SPLIT_EINSUM     attention.py:24-72    per-head key-major score tile [k][q] (the reference's
+//                    "bkhq", softmax over dim=1): computed as K.Q^T so every lane owns one query
+//                    column and reduces over keys IN REGISTERS - no cross-lane traffic except one
+//                    half-wave exchange; P feeds the P.V MFMA straight from registers.
+//   SPLIT_EINSUM_V2  attention.py:77-144   SPLIT_EINSUM with the query axis cut into 512-query
+//                    workgroup chunks (CHUNK_SIZE attention.py:75): 8 waves x 64 queries.  Falls
+//                    back to SPLIT_EINSUM when S_q < 512 (attention.py:88-92) and rejects
+//                    S_q % 512 != 0 instead of silently dropping the tail (attention.py:86).
+//
+// All three: scores never touch HBM (the reference materialises attn_weights, 335 MB at
+// S=4096), scale d^-0.5 applied to the scores (attention.py:49,123,159) folded with log2(e) so
+// the exponent is the native v_exp_f32 (base 2; cf. the reference's own exp2 softmax,
+// attention.py:11-22), fp32 running max / sum / accumulators, fp16 operands.
+// Data: q [B][Sq][ldq], k [B][Sk][ldk] token-major (head h = columns h*d..), vt [B][C][ldv]
+// channel-major (written by the V projection GEMM's transposed epilogue) so that both MFMA
+// operands of P.V are key-contiguous.  K / V^T tiles of 64 keys are staged HBM -> VGPR -> LDS
+// (padded, bank-conflict-free rows) with a register double buffer, one barrier per tile.
+#include "kernels.h"
+
+namespace sd {
+namespace {
+
+constexpr int KT = 64;   // keys per tile
+
+struct AttnArgs {
+  const half_t* q;
+  const half_t* k;
+  const half_t* vt;
+  half_t* out;
+  int heads, d, Sq, Sk;
+  int ldq, ldk, ldv, ldo;
+  float scale_log2;   // d^-0.5 * log2(e)
+  int use_bpermute;
+};
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+// reductions across the 32 lanes that share (lane >> 5): 4 DPP steps inside each 16-lane row
+// (quad_perm xor1, xor2, row_half_mirror, row_mirror) + one ds_bpermute across the two rows
+__device__ __forceinline__ float half_wave_max(float v, bool bperm) {
+  if (bperm) {
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+  }
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, dpp_mov<0x140>(v));
+  return fmaxf(v, __shfl_xor(v, 16));
+}
+__device__ __forceinline__ float half_wave_sum(float v, bool bperm) {
+  if (bperm) {
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) v += __shfl_xor(v, o);
+    return v;
+  }
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
+  return v + __shfl_xor(v, 16);
+}
+
+// MODE 0: ORIGINAL ([q][k] tiles), MODE 1: SPLIT_EINSUM ([k][q] tiles).  QT = 32-query tiles per wave.
+template <int DK16, int DC32, int MODE, int WAVES, int QT>
+__global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs a) {
+  constexpr int NT = WAVES * 64;
+  constexpr int DKP = DK16 * 16;                  // head dim padded for the QK^T k-loop
+  constexpr int DCP = DC32 * 32;                  // head dim padded for the PV output tiles
+  constexpr int KROW = DKP + 8;                   // halves; (DKP*2+16) B = odd multiple of 16 B
+  constexpr int VROW = (MODE == 0) ? KT + 8 : KT + 4;   // 144 B (b128 reads) / 136 B (b64 reads)
+  constexpr int PROW = KT + 8;
+  constexpr int KCH = DKP / 8;                    // 16-B chunks per K row
+  constexpr int K_ITEMS = (KT * KCH + NT - 1) / NT;
+  constexpr int V_ITEMS = (DCP * (KT / 8) + NT - 1) / NT;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* Ks = reinterpret_cast<half_t*>(smem);                    // [2][KT][KROW]
+  half_t* Vs = Ks + 2 * KT * KROW;                                 // [2][DCP][VROW]
+  half_t* Ps = Vs + 2 * DCP * VROW;                                // MODE 0: [WAVES][QT*32][PROW]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q_wave0 = (blockIdx.x * WAVES + wave) * QT * 32;
+
+  const half_t* qbase = a.q + (size_t)b * a.Sq * a.ldq + (size_t)h * a.d;
+  const half_t* kbase = a.k + (size_t)b * a.Sk * a.ldk + (size_t)h * a.d;
+  const half_t* vbase = a.vt + ((size_t)b * a.heads * a.d + (size_t)h * a.d) * a.ldv;
+  const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  // ---- Q fragments stay in registers for the whole kernel ----
+  half8 qf[QT][DK16];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const int q = q_wave0 + t * 32 + l31;
+#pragma unroll
+    for (int kk = 0; kk < DK16; ++kk) {
+      const int c = kk * 16 + hi * 8;
+      qf[t][kk] = (q < a.Sq && c < a.d) ? *reinterpret_cast<const half8*>(qbase + (size_t)q * a.ldq + c) : zero8;
+    }
+  }
+
+  half8 kreg[K_ITEMS], vreg[V_ITEMS];
+  auto load_tiles = [&](int kt) {
+    const int key0 = kt * KT;
+#pragma unroll
+    for (int i = 0; i < K_ITEMS; ++i) {
+      const int idx = tid + i * NT;
+      const int row = idx / KCH, ch = idx - row * KCH;
+      const int key = key0 + row, c = ch * 8;
+      kreg[i] = (idx < KT * KCH && key < a.Sk && c < a.d)
+                    ? *reinterpret_cast<const half8*>(kbase + (size_t)key * a.ldk + c)
+                    : zero8;
+    }
+#pragma unroll
+    for (int i = 0; i < V_ITEMS; ++i) {
+      const int idx = tid + i * NT;
+      const int row = idx >> 3, ch = idx & 7;
+      const int key = key0 + ch * 8;
+      // contract: columns [Sk, ldv) of vt are zero (the UNet zero-fills them once at create time)
+      vreg[i] = (idx < DCP * 8 && row < a.d && key < a.ldv)
+                    ? *reinterpret_cast<const half8*>(vbase + (size_t)row * a.ldv + key)
+                    : zero8;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    half_t* ks = Ks + buf * KT * KROW;
+    half_t* vs = Vs + buf * DCP * VROW;
+#pragma unroll
+    for (int i = 0; i < K_ITEMS; ++i) {
+      const int idx = tid + i * NT;
+      const int row = idx / KCH, ch = idx - row * KCH;
+      if (idx < KT * KCH) *reinterpret_cast<half8*>(ks + row * KROW + ch * 8) = kreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < V_ITEMS; ++i) {
+      const int idx = tid + i * NT;
+      const int row = idx >> 3, ch = idx & 7;
+      if (idx < DCP * 8) {
+        if constexpr (MODE == 0) {
+          *reinterpret_cast<half8*>(vs + row * VROW + ch * 8) = vreg[i];
+        } else {   // 136-B rows are only 8-B aligned
+          half4 lo = {vreg[i][0], vreg[i][1], vreg[i][2], vreg[i][3]};
+          half4 hi4 = {vreg[i][4], vreg[i][5], vreg[i][6], vreg[i][7]};
+          *reinterpret_cast<half4*>(vs + row * VROW + ch * 8) = lo;
+          *reinterpret_cast<half4*>(vs + row * VROW + ch * 8 + 4) = hi4;
+        }
+      }
+    }
+  };
+
+  floatx16 oacc[QT][DC32];
+#pragma unroll
+  for (int t = 0; t < QT; ++t)
+#pragma unroll
+    for (int ct = 0; ct < DC32; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[t][ct][r] = 0.f;
+
+  // running softmax state.  MODE 1: one query per lane.  MODE 0: 16 query rows per lane.
+  constexpr int NS = (MODE == 0) ? 16 : 1;
+  float mrun[QT][NS], lrun[QT][NS];
+#pragma unroll
+  for (int t = 0; t < QT; ++t)
+#pragma unroll
+    for (int r = 0; r < NS; ++r) {
+      mrun[t][r] = -1e30f;
+      lrun[t][r] = 0.f;
+    }
+
+  const int ntiles = (a.Sk + KT - 1) / KT;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int buf = kt & 1;
+    const bool more = kt + 1 < ntiles;
+    if (more) load_tiles(kt + 1);
+    const half_t* ks = Ks + buf * KT * KROW;
+    const half_t* vs = Vs + buf * DCP * VROW;
+    const bool tail = (kt + 1) * KT > a.Sk;   // wave-uniform: only the last tile masks
+
+    // ---------------- scores: two 32-key sub-tiles ----------------
+    floatx16 sacc[QT][2];
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[t][sub][r] = 0.f;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int kk = 0; kk < DK16; ++kk) {
+        const half8 kf = *reinterpret_cast<const half8*>(ks + (sub * 32 + l31) * KROW + kk * 16 + hi * 8);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+          if constexpr (MODE == 0)   // rows = q, cols = key
+            sacc[t][sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qf[t][kk], kf, sacc[t][sub], 0, 0, 0);
+          else                       // rows = key, cols = q
+            sacc[t][sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[t][kk], sacc[t][sub], 0, 0, 0);
+        }
+      }
+
+    if constexpr (MODE == 1) {
+      // ======== SPLIT_EINSUM: lane = query column, registers = keys ========
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+        float mx = -1e30f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float s = sacc[t][sub][r] * a.scale_log2;
+            if (tail) {
+              const int key = kt * KT + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+              if (key >= a.Sk) s = -1e30f;
+            }
+            sacc[t][sub][r] = s;
+            mx = fmaxf(mx, s);
+          }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));            // the other half-wave holds the other 32 keys
+        const float mnew = fmaxf(mrun[t][0], mx);
+        const float alpha = __builtin_amdgcn_exp2f(mrun[t][0] - mnew);
+        mrun[t][0] = mnew;
+        float psum = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(sacc[t][sub][r] - mnew);
+            sacc[t][sub][r] = p;
+            psum += p;
+          }
+        lrun[t][0] = lrun[t][0] * alpha + psum;        // per-lane partial (own keys); merged at the end
+#pragma unroll
+        for (int ct = 0; ct < DC32; ++ct)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[t][ct][r] *= alpha;
+      }
+      // P (registers) is already the B operand of O^T += V^T . P^T: k-slot (hi, e) of MFMA step s2
+      // holds key  sub*32 + s2*16 + (e&3) + 8*(e>>2) + 4*hi ; V^T is gathered with the same map.
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          half8 pf[QT];
+#pragma unroll
+          for (int t = 0; t < QT; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[t][e] = (half_t)sacc[t][sub][s2 * 8 + e];
+#pragma unroll
+          for (int ct = 0; ct < DC32; ++ct) {
+            const half_t* vp = vs + (ct * 32 + l31) * VROW + sub * 32 + s2 * 16 + 4 * hi;
+            const half4 v0 = *reinterpret_cast<const half4*>(vp);
+            const half4 v1 = *reinterpret_cast<const half4*>(vp + 8);
+            const half8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+            for (int t = 0; t < QT; ++t)
+              oacc[t][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[t], oacc[t][ct], 0, 0, 0);
+          }
+        }
+    } else {
+      // ======== ORIGINAL: lane = key column, registers = 16 query rows; softmax across lanes ========
+      half_t* ps = Ps + wave * (QT * 32) * PROW;
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float s0 = sacc[t][0][r] * a.scale_log2, s1 = sacc[t][1][r] * a.scale_log2;
+          if (tail) {
+            if (kt * KT + l31 >= a.Sk) s0 = -1e30f;
+            if (kt * KT + 32 + l31 >= a.Sk) s1 = -1e30f;
+          }
+          const float mx = half_wave_max(fmaxf(s0, s1), a.use_bpermute);
+          const float mnew = fmaxf(mrun[t][r], mx);
+          const float alpha = __builtin_amdgcn_exp2f(mrun[t][r] - mnew);
+          mrun[t][r] = mnew;
+          const float p0 = __builtin_amdgcn_exp2f(s0 - mnew), p1 = __builtin_amdgcn_exp2f(s1 - mnew);
+          lrun[t][r] = lrun[t][r] * alpha + p0 + p1;   // per-lane partial, reduced at the end
+#pragma unroll
+          for (int ct = 0; ct < DC32; ++ct) oacc[t][ct][r] *= alpha;
+          const int qrow = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          ps[qrow * PROW + l31] = (half_t)p0;
+          ps[qrow * PROW + 32 + l31] = (half_t)p1;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();   // P tile is wave-private; LDS ops of one wave complete in order
+#pragma unroll
+      for (int s4 = 0; s4 < KT / 16; ++s4) {
+        half8 pf[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+          pf[t] = *reinterpret_cast<const half8*>(ps + (t * 32 + l31) * PROW + s4 * 16 + hi * 8);
+#pragma unroll
+        for (int ct = 0; ct < DC32; ++ct) {
+          const half8 vf = *reinterpret_cast<const half8*>(vs + (ct * 32 + l31) * VROW + s4 * 16 + hi * 8);
+#pragma unroll
+          for (int t = 0; t < QT; ++t)
+            oacc[t][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf[t], vf, oacc[t][ct], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+
+    if (more) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---------------- normalise + store ----------------
+  half_t* obase = a.out + (size_t)b * a.Sq * a.ldo + (size_t)h * a.d;
+  if constexpr (MODE == 1) {
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      const float ltot = lrun[t][0] + __shfl_xor(lrun[t][0], 32);
+      const float inv = 1.0f / ltot;
+      const int q = q_wave0 + t * 32 + l31;
+      if (q < a.Sq) {
+#pragma unroll
+        for (int ct = 0; ct < DC32; ++ct)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int c = ct * 32 + 8 * g + 4 * hi;
+            if (c < a.d) {
+              half4 o = {(half_t)(oacc[t][ct][4 * g] * inv), (half_t)(oacc[t][ct][4 * g + 1] * inv),
+                         (half_t)(oacc[t][ct][4 * g + 2] * inv), (half_t)(oacc[t][ct][4 * g + 3] * inv)};
+              *reinterpret_cast<half4*>(obase + (size_t)q * a.ldo + c) = o;
+            }
+          }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float inv = 1.0f / half_wave_sum(lrun[t][r], a.use_bpermute);
+        const int q = q_wave0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (q < a.Sq) {
+#pragma unroll
+          for (int ct = 0; ct < DC32; ++ct) {
+            const int c = ct * 32 + l31;
+            if (c < a.d) obase[(size_t)q * a.ldo + c] = (half_t)(oacc[t][ct][r] * inv);
+          }
+        }
+      }
+  }
+}
+
+template <int DK16, int DC32, int MODE, int WAVES, int QT>
+void launch_one(const AttnArgs& a, int B, hipStream_t s) {
+  constexpr int DKP = DK16 * 16, DCP = DC32 * 32;
+  constexpr int VROW = (MODE == 0) ? KT + 8 : KT + 4;
+  size_t lds = (size_t)2 * KT * (DKP + 8) * 2 + (size_t)2 * DCP * VROW * 2;
+  if (MODE == 0) lds += (size_t)WAVES * QT * 32 * (KT + 8) * 2;
+  auto k = attn_kernel<DK16, DC32, MODE, WAVES, QT>;
+  static bool attr = false;
+  if (!attr) {
+    SD_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  dim3 grid(cdiv(a.Sq, WAVES * QT * 32), a.heads, B);
+  hipLaunchKernelGGL(k, grid, dim3(WAVES * 64), lds, s, a);
+}
+
+template <int DK16, int DC32>
+void launch_d(const AttnArgs& a, int B, int impl, hipStream_t s) {
+  if (impl == kAttnOriginal)
+    launch_one<DK16, DC32, 0, 4, 1>(a, B, s);
+  else if (impl == kAttnSplitEinsum)
+    launch_one<DK16, DC32, 1, 4, 1>(a, B, s);
+  else if constexpr (DC32 <= 2)
+    launch_one<DK16, DC32, 1, 8, 2>(a, B, s);   // one 512-query chunk per workgroup (8 waves x 64 queries)
+  else
+    launch_one<DK16, DC32, 1, 8, 1>(a, B, s);   // d > 64: register budget -> two 256-query workgroups per chunk
+}
+
+}  // namespace
+
+bool attention_supported(int d) { return d > 0 && d % 8 == 0 && d <= 160; }
+
+void launch_attention(const AttnDesc& d, hipStream_t s) {
+  SD_REQUIRE(attention_supported(d.d), kUnsupported, "attention: head dim %d unsupported (need d %% 8 == 0, d <= 160)",
+             d.d);
+  SD_REQUIRE(d.ldq % 8 == 0 && d.ldk % 8 == 0 && d.ldv % 8 == 0 && d.ldo % 4 == 0, kInvalidArgument,
+             "attention: leading dims must be multiples of 8 (ldq %d ldk %d ldv %d ldo %d)", d.ldq, d.ldk, d.ldv,
+             d.ldo);
+  SD_REQUIRE(d.ldv >= d.Sk, kInvalidArgument, "attention: ldv %d < Sk %d", d.ldv, d.Sk);
+  int impl = d.impl;
+  if (impl == kAttnSplitEinsumV2) {
+    if (d.Sq < 512)
+      impl = kAttnSplitEinsum;                        // attention.py:88-92
+    else
+      SD_REQUIRE(d.Sq % 512 == 0, kInvalidArgument,
+                 "SPLIT_EINSUM_V2 needs S_q %% 512 == 0 (got %d); the reference would silently drop the tail "
+                 "(attention.py:86)", d.Sq);
+  }
+  AttnArgs a{d.q, d.k, d.vt, d.out, d.heads, d.d, d.Sq, d.Sk, d.ldq, d.ldk, d.ldv, d.ldo,
+             1.4426950408889634f / sqrtf((float)d.d), d.variant & 1};
+  const int dk16 = cdiv(d.d, 16), dc32 = cdiv(d.d, 32);
+  if (dk16 == 1 && dc32 == 1) launch_d<1, 1>(a, d.B, impl, s);
+  else if (dk16 == 2 && dc32 == 1) launch_d<2, 1>(a, d.B, impl, s);
+  else if (dk16 == 3 && dc32 == 2) launch_d<3, 2>(a, d.B, impl, s);
+  else if (dk16 == 4 && dc32 == 2) launch_d<4, 2>(a, d.B, impl, s);
+  else if (dk16 == 5 && dc32 == 3) launch_d<5, 3>(a, d.B, impl, s);
+  else if (dk16 == 6 && dc32 == 3) launch_d<6, 3>(a, d.B, impl, s);
+  else if (dk16 == 7 && dc32 == 4) launch_d<7, 4>(a, d.B, impl, s);
+  else if (dk16 == 8 && dc32 == 4) launch_d<8, 4>(a, d.B, impl, s);
+  else if (dk16 == 9 && dc32 == 5) launch_d<9, 5>(a, d.B, impl, s);
+  else if (dk16 == 10 && dc32 == 5) launch_d<10, 5>(a, d.B, impl, s);
+  else fail(kUnsupported, "attention: no kernel for head dim %d", d.d);
+  SD_HIP(hipGetLastError());
+}
+
+}  // namespace sd

@@ -1,0 +1,424 @@
+// extern "C" surface of libsdmi355 (include/sd_mi355x.h).  Exceptions never cross the ABI:
+// every entry point converts sd::Error into a status code + thread-local message.
+#include <cmath>
+#include <cstring>
+
+#include "unet.h"
+
+namespace sd {
+extern thread_local std::string g_last_error;
+int selftest_mfma();   // selftest.hip
+
+namespace {
+
+template <typename F>
+int guarded(F&& f) {
+  try {
+    f();
+    g_last_error.clear();
+    return kOk;
+  } catch (const Error& e) {
+    g_last_error = e.what();
+    return e.code;
+  } catch (const std::bad_alloc&) {
+    g_last_error = "out of host memory";
+    return kInternal;
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    return kInternal;
+  }
+}
+
+void require_device() {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    fail(kHipError, "no HIP device visible (%s): libsdmi355 has no CPU fallback", hipGetErrorString(e));
+}
+
+// scoped device scratch for the operator-level entry points
+struct Scratch {
+  std::vector<void*> ptrs;
+  hipStream_t stream = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  Scratch() {
+    require_device();
+    SD_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    SD_HIP(hipEventCreate(&e0));
+    SD_HIP(hipEventCreate(&e1));
+  }
+  ~Scratch() {
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (void* p : ptrs) (void)hipFree(p);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+  template <typename T>
+  T* dev(size_t n, const T* host = nullptr) {
+    void* p = nullptr;
+    SD_HIP(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)));
+    ptrs.push_back(p);
+    if (host)
+      SD_HIP(hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice));
+    else
+      SD_HIP(hipMemset(p, 0, std::max<size_t>(n, 1) * sizeof(T)));
+    return reinterpret_cast<T*>(p);
+  }
+  template <typename F>
+  void timed(int iters, float* ms, F&& launch) {
+    if (iters < 1) iters = 1;
+    launch();   // warm (also sets kernel attributes)
+    SD_HIP(hipStreamSynchronize(stream));
+    SD_HIP(hipEventRecord(e0, stream));
+    for (int i = 0; i < iters; ++i) launch();
+    SD_HIP(hipEventRecord(e1, stream));
+    SD_HIP(hipEventSynchronize(e1));
+    float t = 0.f;
+    SD_HIP(hipEventElapsedTime(&t, e0, e1));
+    if (ms) *ms = t / (float)iters;
+  }
+};
+
+// (B, C, H, W) -> (B, H, W, C) on the host
+std::vector<half_t> nchw_to_nhwc(const half_t* src, int B, int C, int H, int W) {
+  std::vector<half_t> out((size_t)B * C * H * W);
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < C; ++c)
+      for (int p = 0; p < H * W; ++p) out[((size_t)b * H * W + p) * C + c] = src[((size_t)b * C + c) * H * W + p];
+  return out;
+}
+void nhwc_to_nchw(const half_t* src, half_t* dst, int B, int C, int H, int W) {
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < C; ++c)
+      for (int p = 0; p < H * W; ++p) dst[((size_t)b * C + c) * H * W + p] = src[((size_t)b * H * W + p) * C + c];
+}
+
+}  // namespace
+}  // namespace sd
+
+using namespace sd;
+
+extern "C" {
+
+const char* sd_last_error(void) { return g_last_error.c_str(); }
+const char* sd_version(void) { return "libsdmi355 0.1 (gfx950)"; }
+
+int sd_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    g_last_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e);
+    return kHipError;
+  }
+  return n;
+}
+
+int sd_weights_create(sd_weights** out) {
+  return guarded([&] {
+    SD_REQUIRE(out != nullptr, kInvalidArgument, "out is NULL");
+    *out = new sd_weights();
+  });
+}
+int sd_weights_add(sd_weights* w, const char* name, const void* data, sd_dtype dtype, const int64_t* shape, int ndim) {
+  return guarded([&] {
+    SD_REQUIRE(w && name && data && shape, kInvalidArgument, "NULL argument");
+    w->store.add(name, data, (int)dtype, shape, ndim);
+  });
+}
+int sd_weights_load_safetensors(sd_weights* w, const char* path, const char* prefix) {
+  return guarded([&] {
+    SD_REQUIRE(w && path, kInvalidArgument, "NULL argument");
+    w->store.load_safetensors(path, prefix ? prefix : "");
+  });
+}
+int sd_weights_count(const sd_weights* w) { return w ? (int)w->store.size() : 0; }
+void sd_weights_destroy(sd_weights* w) { delete w; }
+
+int sd_unet_create(const sd_unet_config* cfg, const sd_weights* w, int device, sd_unet** out) {
+  return guarded([&] {
+    SD_REQUIRE(cfg && w && out, kInvalidArgument, "NULL argument");
+    require_device();
+    auto h = std::make_unique<sd_unet>();
+    h->impl = std::make_unique<UNet>(*cfg, w->store, device);
+    *out = h.release();
+  });
+}
+void sd_unet_destroy(sd_unet* u) { delete u; }
+int sd_unet_set_attention(sd_unet* u, int impl) {
+  return guarded([&] {
+    SD_REQUIRE(u, kInvalidArgument, "NULL handle");
+    u->impl->set_attention(impl);
+  });
+}
+int sd_unet_num_residuals(const sd_unet* u) { return u ? u->impl->num_residuals() : 0; }
+size_t sd_unet_device_bytes(const sd_unet* u) { return u ? u->impl->device_bytes() : 0; }
+
+int sd_unet_forward(sd_unet* u, const sd_unet_io* io) {
+  return guarded([&] {
+    SD_REQUIRE(u && io, kInvalidArgument, "NULL argument");
+    u->impl->forward(*io);
+  });
+}
+int sd_unet_time_forward(sd_unet* u, int warmup, int iters, float* ms_per_iter) {
+  return guarded([&] {
+    SD_REQUIRE(u && ms_per_iter, kInvalidArgument, "NULL argument");
+    *ms_per_iter = u->impl->time_forward(warmup, iters);
+  });
+}
+int sd_unet_denoise_loop(sd_unet* u, const sd_unet_io* io, float* latents, int n_images, int n_steps,
+                         const float* timesteps, const float* coef, int history, float guidance_scale,
+                         float* ms_per_step) {
+  return guarded([&] {
+    SD_REQUIRE(u && io && latents && timesteps && coef, kInvalidArgument, "NULL argument");
+    u->impl->denoise_loop(*io, latents, n_images, n_steps, timesteps, coef, history, guidance_scale, ms_per_step);
+  });
+}
+
+// ------------------------------- operator-level entry points -------------------------------
+
+int sd_op_attention(int impl, const void* q, const void* k, const void* v, void* out, int B, int heads, int d,
+                    int Sq, int Sk, int variant, int iters, float* ms) {
+  return guarded([&] {
+    SD_REQUIRE(q && k && v && out, kInvalidArgument, "NULL argument");
+    SD_REQUIRE(impl >= 0 && impl <= 2, kInvalidArgument, "unknown attention implementation %d", impl);
+    SD_REQUIRE(B > 0 && heads > 0 && d > 0 && Sq > 0 && Sk > 0, kInvalidArgument, "empty attention problem");
+    Scratch sc;
+    const int C = heads * d;
+    const int ldv = (Sk + 7) / 8 * 8;
+    const half_t* qh = reinterpret_cast<const half_t*>(q);
+    const half_t* kh = reinterpret_cast<const half_t*>(k);
+    const half_t* vh = reinterpret_cast<const half_t*>(v);
+    // BC1S (B, C, 1, S) -> token-major [B][S][C]; V stays channel-major, rows zero-padded to ldv
+    std::vector<half_t> qt((size_t)B * Sq * C), kt((size_t)B * Sk * C), vt((size_t)B * C * ldv, (half_t)0);
+    for (int b = 0; b < B; ++b)
+      for (int c = 0; c < C; ++c) {
+        for (int s = 0; s < Sq; ++s) qt[((size_t)b * Sq + s) * C + c] = qh[((size_t)b * C + c) * Sq + s];
+        for (int s = 0; s < Sk; ++s) {
+          kt[((size_t)b * Sk + s) * C + c] = kh[((size_t)b * C + c) * Sk + s];
+          vt[((size_t)b * C + c) * ldv + s] = vh[((size_t)b * C + c) * Sk + s];
+        }
+      }
+    AttnDesc a;
+    a.q = sc.dev<half_t>(qt.size(), qt.data());
+    a.k = sc.dev<half_t>(kt.size(), kt.data());
+    a.vt = sc.dev<half_t>(vt.size(), vt.data());
+    half_t* o = sc.dev<half_t>((size_t)B * Sq * C);
+    a.out = o;
+    a.B = B; a.heads = heads; a.d = d; a.Sq = Sq; a.Sk = Sk;
+    a.ldq = C; a.ldk = C; a.ldv = ldv; a.ldo = C;
+    a.impl = impl;
+    a.variant = variant;
+    sc.timed(iters, ms, [&] { launch_attention(a, sc.stream); });
+    std::vector<half_t> ot((size_t)B * Sq * C);
+    SD_HIP(hipMemcpy(ot.data(), o, ot.size() * 2, hipMemcpyDeviceToHost));
+    half_t* oh = reinterpret_cast<half_t*>(out);
+    for (int b = 0; b < B; ++b)
+      for (int c = 0; c < C; ++c)
+        for (int s = 0; s < Sq; ++s) oh[((size_t)b * C + c) * Sq + s] = ot[((size_t)b * Sq + s) * C + c];
+  });
+}
+
+int sd_op_layernorm(const void* x, const float* weight, const float* bias, void* out, int B, int C, int S, float eps,
+                    int iters, float* ms) {
+  return guarded([&] {
+    SD_REQUIRE(x && weight && bias && out, kInvalidArgument, "NULL argument");
+    Scratch sc;
+    // BC1S == NCHW with H=1, W=S
+    std::vector<half_t> xt = nchw_to_nhwc(reinterpret_cast<const half_t*>(x), B, C, 1, S);
+    half_t* dx = sc.dev<half_t>(xt.size(), xt.data());
+    half_t* dy = sc.dev<half_t>(xt.size());
+    float* dw = sc.dev<float>(C, weight);
+    float* db = sc.dev<float>(C, bias);
+    sc.timed(iters, ms, [&] { launch_layernorm(dx, dw, db, dy, B * S, C, eps, sc.stream); });
+    SD_HIP(hipMemcpy(xt.data(), dy, xt.size() * 2, hipMemcpyDeviceToHost));
+    nhwc_to_nchw(xt.data(), reinterpret_cast<half_t*>(out), B, C, 1, S);
+  });
+}
+
+int sd_op_groupnorm(const void* x, const float* weight, const float* bias, void* out, int B, int C, int H, int W,
+                    int groups, float eps, int silu, int iters, float* ms) {
+  return guarded([&] {
+    SD_REQUIRE(x && weight && bias && out, kInvalidArgument, "NULL argument");
+    Scratch sc;
+    std::vector<half_t> xt = nchw_to_nhwc(reinterpret_cast<const half_t*>(x), B, C, H, W);
+    half_t* dx = sc.dev<half_t>(xt.size(), xt.data());
+    half_t* dy = sc.dev<half_t>(xt.size());
+    float* dw = sc.dev<float>(C, weight);
+    float* db = sc.dev<float>(C, bias);
+    float* st = sc.dev<float>((size_t)B * groups * 2);
+    float* partial = sc.dev<float>(groupnorm_scratch_floats(B, H * W, groups));
+    sc.timed(iters, ms, [&] {
+      launch_groupnorm(dx, C, nullptr, 0, partial, st, dw, db, dy, B, H * W, groups, eps, silu, sc.stream);
+    });
+    SD_HIP(hipMemcpy(xt.data(), dy, xt.size() * 2, hipMemcpyDeviceToHost));
+    nhwc_to_nchw(xt.data(), reinterpret_cast<half_t*>(out), B, C, H, W);
+  });
+}
+
+int sd_op_conv2d(const void* x, const void* w, const float* bias, const void* res, void* out, int B, int Cin, int H,
+                 int W, int Cout, int ksize, int stride, int upsample, int tile, int splitk, int force_generic,
+                 int iters, float* ms) {
+  return guarded([&] {
+    SD_REQUIRE(x && w && out, kInvalidArgument, "NULL argument");
+    SD_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && (upsample == 0 || upsample == 1),
+               kInvalidArgument, "conv2d: ksize %d stride %d upsample %d not on the path", ksize, stride, upsample);
+    Scratch sc;
+    const int up = upsample ? 2 : 1, pad = ksize / 2;
+    const int Ho = (H * up + 2 * pad - ksize) / stride + 1, Wo = (W * up + 2 * pad - ksize) / stride + 1;
+    std::vector<half_t> xt = nchw_to_nhwc(reinterpret_cast<const half_t*>(x), B, Cin, H, W);
+    const half_t* wh = reinterpret_cast<const half_t*>(w);
+    const int kk = ksize * ksize;
+    std::vector<half_t> wt((size_t)Cout * Cin * kk);
+    for (int o = 0; o < Cout; ++o)
+      for (int c = 0; c < Cin; ++c)
+        for (int t = 0; t < kk; ++t) wt[((size_t)o * kk + t) * Cin + c] = wh[((size_t)o * Cin + c) * kk + t];
+    ConvDesc d;
+    d.x0 = sc.dev<half_t>(xt.size(), xt.data());
+    d.C0 = Cin;
+    d.w = sc.dev<half_t>(wt.size(), wt.data());
+    d.bias = bias ? sc.dev<float>(Cout, bias) : nullptr;
+    std::vector<half_t> rt;
+    if (res) {
+      rt = nchw_to_nhwc(reinterpret_cast<const half_t*>(res), B, Cout, Ho, Wo);
+      d.res = sc.dev<half_t>(rt.size(), rt.data());
+    }
+    const size_t on = (size_t)B * Ho * Wo * Cout;
+    half_t* dout = sc.dev<half_t>(on);
+    d.out = dout;
+    d.B = B; d.Hi = H; d.Wi = W; d.Ho = Ho; d.Wo = Wo;
+    d.ksize = ksize; d.stride = stride; d.up = up; d.N = Cout;
+    d.tile = tile;
+    d.splitk = splitk;
+    const bool fast = !force_generic && conv_fast_path_ok(d);
+    ConvWorkspace ws;
+    if (fast) {
+      ws.partial_bytes = conv_workspace_bytes(d);
+      if (ws.partial_bytes) ws.partial = reinterpret_cast<float*>(sc.dev<char>(ws.partial_bytes));
+    }
+    sc.timed(iters, ms, [&] {
+      if (fast)
+        launch_conv(d, ws, sc.stream);
+      else
+        launch_conv_generic(d, 0, sc.stream);
+    });
+    std::vector<half_t> ot(on);
+    SD_HIP(hipMemcpy(ot.data(), dout, on * 2, hipMemcpyDeviceToHost));
+    nhwc_to_nchw(ot.data(), reinterpret_cast<half_t*>(out), B, Cout, Ho, Wo);
+  });
+}
+
+int sd_op_geglu(const void* x, const void* w, const float* bias, void* out, int M, int C, int N2, int iters, float* ms) {
+  return guarded([&] {
+    SD_REQUIRE(x && w && out && N2 % 2 == 0, kInvalidArgument, "bad GEGLU arguments");
+    Scratch sc;
+    const half_t* wh = reinterpret_cast<const half_t*>(w);
+    const int half_n = N2 / 2;
+    SD_REQUIRE(half_n % 32 == 0, kUnsupported, "GEGLU needs (N/2) %% 32 == 0");
+    std::vector<half_t> wt((size_t)N2 * C);
+    std::vector<float> bt(N2, 0.f);
+    for (int o = 0; o < N2; ++o) {
+      const bool gate = o >= half_n;
+      const int j = gate ? o - half_n : o;
+      const int dst = (j / 32) * 64 + (gate ? 32 : 0) + (j % 32);
+      std::memcpy(&wt[(size_t)dst * C], &wh[(size_t)o * C], (size_t)C * 2);
+      if (bias) bt[dst] = bias[o];
+    }
+    ConvDesc d;
+    d.x0 = sc.dev<half_t>((size_t)M * C, reinterpret_cast<const half_t*>(x));
+    d.C0 = C;
+    d.w = sc.dev<half_t>(wt.size(), wt.data());
+    d.bias = bias ? sc.dev<float>(N2, bt.data()) : nullptr;
+    half_t* dout = sc.dev<half_t>((size_t)M * half_n);
+    d.out = dout;
+    d.B = 1; d.Hi = 1; d.Wi = M; d.Ho = 1; d.Wo = M;
+    d.N = N2;
+    d.out_mode = kOutGeglu;
+    const bool fast = conv_fast_path_ok(d);
+    ConvWorkspace ws;
+    sc.timed(iters, ms, [&] {
+      if (fast)
+        launch_conv(d, ws, sc.stream);
+      else
+        launch_conv_generic(d, 0, sc.stream);
+    });
+    SD_HIP(hipMemcpy(out, dout, (size_t)M * half_n * 2, hipMemcpyDeviceToHost));
+  });
+}
+
+int sd_op_timestep_embedding(const float* t, float* out, int n, int dim, int flip_sin_to_cos, float freq_shift) {
+  return guarded([&] {
+    SD_REQUIRE(t && out && n > 0 && dim > 0 && dim % 2 == 0, kInvalidArgument, "bad arguments");
+    SD_REQUIRE(flip_sin_to_cos == 1, kUnsupported, "flip_sin_to_cos=False is not on the path");
+    Scratch sc;
+    float* dt = sc.dev<float>(n, t);
+    float* dout = sc.dev<float>((size_t)n * dim);
+    launch_timestep_embedding(dt, dout, n, dim, freq_shift, sc.stream);
+    SD_HIP(hipStreamSynchronize(sc.stream));
+    SD_HIP(hipMemcpy(out, dout, (size_t)n * dim * sizeof(float), hipMemcpyDeviceToHost));
+  });
+}
+
+// numpy legacy RandomState: MT19937 + 53-bit doubles + Marsaglia polar method
+// (NumPyRandomSource.swift:28-102; golden: StableDiffusionTests.swift:52-62)
+int sd_numpy_randn(uint32_t seed, double* out, size_t n) {
+  return guarded([&] {
+    SD_REQUIRE(out || n == 0, kInvalidArgument, "NULL output");
+    uint32_t key[624];
+    uint32_t s = seed;
+    for (uint32_t i = 0; i < 624; ++i) {
+      key[i] = s;
+      s = 1812433253u * (s ^ (s >> 30)) + i + 1;
+    }
+    int pos = 624;
+    auto next_u32 = [&]() -> uint32_t {
+      if (pos == 624) {
+        for (int i = 0; i < 624; ++i) {
+          const uint32_t y = (key[i] & 0x80000000u) | (key[(i + 1) % 624] & 0x7fffffffu);
+          key[i] = key[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        pos = 0;
+      }
+      uint32_t y = key[pos++];
+      y ^= y >> 11;
+      y ^= (y << 7) & 0x9d2c5680u;
+      y ^= (y << 15) & 0xefc60000u;
+      y ^= y >> 18;
+      return y;
+    };
+    auto next_double = [&]() -> double {
+      const uint32_t a = next_u32() >> 5, b = next_u32() >> 6;
+      return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+    };
+    bool has_cached = false;
+    double cached = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+      if (has_cached) {
+        out[i] = cached;
+        has_cached = false;
+        continue;
+      }
+      double x1, x2, r2;
+      do {
+        x1 = 2.0 * next_double() - 1.0;
+        x2 = 2.0 * next_double() - 1.0;
+        r2 = x1 * x1 + x2 * x2;
+      } while (r2 >= 1.0 || r2 == 0.0);
+      const double f = std::sqrt(-2.0 * std::log(r2) / r2);
+      cached = f * x1;
+      has_cached = true;
+      out[i] = f * x2;
+    }
+  });
+}
+
+int sd_selftest_mfma(void) {
+  int rc = 0;
+  int st = guarded([&] {
+    require_device();
+    rc = selftest_mfma();
+  });
+  return st != kOk ? st : rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,598 @@
+// K4/K5 - implicit-GEMM convolution (3x3 / 1x1, stride 1/2, fused nearest-x2 gather, fused
+// channel-concat) on gfx950 MFMA (v_mfma_f32_32x32x16_f16), fp16 in / fp32 accumulate.
+//
+// Math (reference): nn.Conv2d calls of python_coreml_stable_diffusion/unet.py:74-84 (q/k/v/out
+// 1x1), :435-468 (resnet 3x3 + 1x1 shortcut), :496-510 (up/down-sample), :533-551 (proj_in/out),
+// :601-617 (GEGLU feed-forward), and the torch.cat([h, skip], dim=1) of :213-216 which we never
+// materialise (second K-source).
+//
+// Mapping: out[m][n] = sum_k X[m][k] W[n][k]; m = (b, oy, ox) output pixel, n = output channel,
+// k = tap * Ctot + c.  Both operands are K-contiguous in HBM (NHWC activations, [N][taps][C]
+// weights re-laid-out at load), which is exactly the MFMA A/B fragment shape (8 consecutive k
+// per lane), so tiles go HBM -> VGPR (16-B coalesced) -> LDS (padded rows, conflict-free
+// ds_read_b128) -> MFMA with a register-staged double buffer (one barrier per 64-deep K step).
+// The tile is computed TRANSPOSED (rows = n, cols = m) so each lane owns 4 consecutive output
+// channels of one pixel: bias / timestep-embedding / residual adds and the fp16 store are 8-byte
+// vector accesses with no cross-lane traffic.
+#include "kernels.h"
+
+namespace sd {
+
+namespace {
+
+constexpr int BK = 64;            // K step (halves)
+constexpr int LDS_ROW = BK + 8;   // padded row stride in halves (144 B): 16 rows -> 16 distinct 16-B slots
+
+struct IgemmArgs {
+  const half_t* x0;
+  const half_t* x1;
+  const half_t* w;
+  const float* bias;
+  const float* temb;
+  const half_t* res;
+  half_t* out;
+  float* partial;
+  int C0, C1, Ctot;
+  int B, Hi, Wi, Ho, Wo, HoWo;
+  int ksize, stride, up, pad;
+  int M, N, K;
+  int temb_stride;
+  int nk_total, nk_per_split, splitk;
+  int out_mode, ldT;
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// One 256-thread workgroup = 4 wavefronts laid out WGM x WGN over a BM x BN tile.
+template <int BM, int BN, int WGM, int WGN, bool TRANS_OUT>
+__global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
+  static_assert(WGM * WGN == 4, "4 waves");
+  constexpr int TM = BM / WGM / 32;   // 32x32 MFMA tiles per wave along m
+  constexpr int TN = BN / WGN / 32;
+  constexpr int XR = BM / 32;         // 16-B chunks each thread stages per K step (X tile)
+  constexpr int WR = BN / 32;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* Xs = reinterpret_cast<half_t*>(smem);                 // [2][BM][LDS_ROW]
+  half_t* Ws = Xs + 2 * BM * LDS_ROW;                           // [2][BN][LDS_ROW]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  // XCD-aware tile order: the dispatcher round-robins consecutive block ids over the 8 XCDs
+  // (MI355X_MICROARCH: block b -> XCD b % 8).  Remap so that each XCD walks a contiguous run of
+  // tiles that share the same weight panel (n-tile) -> the panel stays in that XCD's L2.
+  int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
+  int nwg = nbm * nbn;
+  int bid = blockIdx.x;
+  {
+    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    bid = base + idx;   // bijective for any nwg
+  }
+  const int bn_idx = bid / nbm, bm_idx = bid % nbm;   // consecutive ids share the weight panel
+  const int m_blk = bm_idx * BM, n_blk = bn_idx * BN;
+
+  const int split = blockIdx.y;
+  const int kt_begin = split * a.nk_per_split;
+  int kt_end = kt_begin + a.nk_per_split;
+  if (kt_end > a.nk_total) kt_end = a.nk_total;
+
+  // ---- per-thread staging coordinates (loop invariant) ----
+  const int chunk = tid & 7;        // which 16-B piece of the 128-B K row
+  const int lrow = tid >> 3;        // 0..31
+  int x_pix[XR];                    // b*Hi*Wi (or -1 when the row is past M)
+  int x_iy0[XR], x_ix0[XR];
+#pragma unroll
+  for (int i = 0; i < XR; ++i) {
+    int m = m_blk + lrow + 32 * i;
+    if (m < a.M) {
+      int b = m / a.HoWo;
+      int rem = m - b * a.HoWo;
+      int oy = rem / a.Wo;
+      int ox = rem - oy * a.Wo;
+      x_pix[i] = b * a.Hi * a.Wi;
+      x_iy0[i] = oy * a.stride - a.pad;
+      x_ix0[i] = ox * a.stride - a.pad;
+    } else {
+      x_pix[i] = -1;
+      x_iy0[i] = 0;
+      x_ix0[i] = 0;
+    }
+  }
+  const int Hup = a.Hi * a.up, Wup = a.Wi * a.up;
+  const int upshift = a.up >> 1;    // up in {1,2}
+
+  half8 xr[XR], wr[WR];
+  const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  auto load_tile = [&](int kt) {
+    const int k0 = kt * BK;
+    const int tap = k0 / a.Ctot;
+    int cc = k0 - tap * a.Ctot;
+    const half_t* src = a.x0;
+    int Csrc = a.C0;
+    if (cc >= a.C0) {
+      src = a.x1;
+      cc -= a.C0;
+      Csrc = a.C1;
+    }
+    const int ky = (a.ksize == 3) ? tap / 3 : 0;
+    const int kx = (a.ksize == 3) ? tap - ky * 3 : 0;
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+      int iy = x_iy0[i] + ky, ix = x_ix0[i] + kx;
+      bool ok = (x_pix[i] >= 0) && (iy >= 0) && (iy < Hup) && (ix >= 0) && (ix < Wup);
+      int sy = iy >> upshift, sx = ix >> upshift;
+      size_t off = ((size_t)(x_pix[i] + sy * a.Wi + sx)) * Csrc + cc + chunk * 8;
+      xr[i] = ok ? *reinterpret_cast<const half8*>(src + off) : zero8;
+    }
+#pragma unroll
+    for (int i = 0; i < WR; ++i) {
+      int n = n_blk + lrow + 32 * i;
+      size_t off = (size_t)n * a.K + k0 + chunk * 8;
+      wr[i] = (n < a.N) ? *reinterpret_cast<const half8*>(a.w + off) : zero8;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    half_t* xs = Xs + buf * BM * LDS_ROW;
+    half_t* ws = Ws + buf * BN * LDS_ROW;
+#pragma unroll
+    for (int i = 0; i < XR; ++i)
+      *reinterpret_cast<half8*>(xs + (lrow + 32 * i) * LDS_ROW + chunk * 8) = xr[i];
+#pragma unroll
+    for (int i = 0; i < WR; ++i)
+      *reinterpret_cast<half8*>(ws + (lrow + 32 * i) * LDS_ROW + chunk * 8) = wr[i];
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frow = lane & 31;           // fragment row (m or n within the 32-tile)
+  const int fk = (lane >> 5) * 8;       // k offset of this half-wave inside a 16-deep MFMA step
+
+  if (kt_begin < kt_end) {
+    load_tile(kt_begin);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int buf = (kt - kt_begin) & 1;
+    const bool more = (kt + 1) < kt_end;
+    if (more) load_tile(kt + 1);        // HBM/L2 latency hides under this tile's MFMAs
+
+    const half_t* xs = Xs + buf * BM * LDS_ROW + (wm * TM * 32 + frow) * LDS_ROW + fk;
+    const half_t* ws = Ws + buf * BN * LDS_ROW + (wn * TN * 32 + frow) * LDS_ROW + fk;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      half8 xf[TM], wf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const half8*>(xs + i * 32 * LDS_ROW + kk * 16);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const half8*>(ws + j * 32 * LDS_ROW + kk * 16);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if constexpr (TRANS_OUT)   // rows = m, cols = n
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[i], wf[j], acc[i][j], 0, 0, 0);
+          else                       // rows = n, cols = m
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---------------------------------- epilogue ----------------------------------
+  const int hi = lane >> 5;
+  if constexpr (TRANS_OUT) {
+    // acc[i][j][r]: m = m0 + (r&3) + 8*(r>>2) + 4*hi ; n = n0 + (lane&31).  out[b][n][s]
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n_blk + (wn * TN + j) * 32 + frow;
+        const int m0 = m_blk + (wm * TM + i) * 32 + 4 * hi;
+        if (n >= a.N) continue;
+        const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int m = m0 + 8 * q;
+          if ((a.HoWo & 3) == 0 && (a.ldT & 3) == 0 && m + 3 < a.M) {   // 4 tokens of one image, 8-B aligned
+            const int b = m / a.HoWo;
+            const int s = m - b * a.HoWo;
+            half4 o = {(half_t)(acc[i][j][4 * q] + bv), (half_t)(acc[i][j][4 * q + 1] + bv),
+                       (half_t)(acc[i][j][4 * q + 2] + bv), (half_t)(acc[i][j][4 * q + 3] + bv)};
+            *reinterpret_cast<half4*>(a.out + ((size_t)b * a.N + n) * a.ldT + s) = o;
+            continue;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            int mm = m + e;
+            if (mm < a.M) {
+              int b = mm / a.HoWo;
+              int s = mm - b * a.HoWo;
+              a.out[((size_t)b * a.N + n) * a.ldT + s] = (half_t)(acc[i][j][4 * q + e] + bv);
+            }
+          }
+        }
+      }
+    return;
+  } else {
+    // acc[i][j][r]: n = n0 + (r&3) + 8*(r>>2) + 4*hi ; m = m0 + (lane&31)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m_blk + (wm * TM + i) * 32 + frow;
+      if (m >= a.M) continue;
+      const int b = m / a.HoWo;
+      if (a.splitk > 1) {
+        float* prow = a.partial + ((size_t)split * a.M + m) * a.N;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int n = n_blk + (wn * TN + j) * 32 + 8 * q + 4 * hi;
+            if (n < a.N) {
+              floatx4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+              *reinterpret_cast<floatx4*>(prow + n) = v;
+            }
+          }
+        continue;
+      }
+      if (a.out_mode == kOutGeglu) {
+        if constexpr (TN % 2 == 0) {
+          const int NO = a.N >> 1;
+#pragma unroll
+          for (int j = 0; j < TN; j += 2)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int nv = n_blk + (wn * TN + j) * 32 + 8 * q + 4 * hi;      // value rows (interleaved W)
+              const int ng = nv + 32;                                            // gate rows
+              if (ng < a.N) {
+                const int no = (n_blk + (wn * TN + j) * 32) / 2 + 8 * q + 4 * hi;
+                half4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  float v = acc[i][j][4 * q + e] + (a.bias ? a.bias[nv + e] : 0.f);
+                  float g = acc[i][j + 1][4 * q + e] + (a.bias ? a.bias[ng + e] : 0.f);
+                  o[e] = (half_t)(v * gelu_erf(g));
+                }
+                *reinterpret_cast<half4*>(a.out + (size_t)m * NO + no) = o;
+              }
+            }
+        }
+        continue;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n_blk + (wn * TN + j) * 32 + 8 * q + 4 * hi;
+          if (n < a.N) {
+            float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            if (a.bias) {
+              floatx4 bb = *reinterpret_cast<const floatx4*>(a.bias + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += bb[e];
+            }
+            if (a.temb) {
+              floatx4 tt = *reinterpret_cast<const floatx4*>(a.temb + (size_t)b * a.temb_stride + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += tt[e];
+            }
+            if (a.res) {
+              half4 rr = *reinterpret_cast<const half4*>(a.res + (size_t)m * a.N + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+            }
+            half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            *reinterpret_cast<half4*>(a.out + (size_t)m * a.N + n) = o;
+          }
+        }
+    }
+  }
+}
+
+// split-K combine + the same epilogue (bias, temb broadcast, residual) -> fp16
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmArgs a) {
+  const size_t total4 = (size_t)a.M * a.N / 4;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total4;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t e0 = idx * 4;
+    const int m = (int)(e0 / a.N);
+    const int n = (int)(e0 - (size_t)m * a.N);
+    floatx4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < a.splitk; ++z) {
+      floatx4 p = *reinterpret_cast<const floatx4*>(a.partial + ((size_t)z * a.M + m) * a.N + n);
+      s += p;
+    }
+    if (a.bias) s += *reinterpret_cast<const floatx4*>(a.bias + n);
+    if (a.temb) {
+      const int b = m / a.HoWo;
+      s += *reinterpret_cast<const floatx4*>(a.temb + (size_t)b * a.temb_stride + n);
+    }
+    if (a.res) {
+      half4 rr = *reinterpret_cast<const half4*>(a.res + e0);
+      s[0] += (float)rr[0];
+      s[1] += (float)rr[1];
+      s[2] += (float)rr[2];
+      s[3] += (float)rr[3];
+    }
+    half4 o = {(half_t)s[0], (half_t)s[1], (half_t)s[2], (half_t)s[3]};
+    *reinterpret_cast<half4*>(a.out + e0) = o;
+  }
+}
+
+// ---- generic direct convolution: any shape, one thread per output element (tiny/odd layers) ----
+__global__ __launch_bounds__(256) void conv_generic_kernel(IgemmArgs a, int silu_out) {
+  const bool geglu = a.out_mode == kOutGeglu;
+  const int NO = geglu ? a.N / 2 : a.N;
+  const size_t total = (size_t)a.M * NO;
+  const int Hup = a.Hi * a.up, Wup = a.Wi * a.up, upshift = a.up >> 1;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(idx / NO), no = (int)(idx - (size_t)m * NO);
+    const int b = m / a.HoWo;
+    const int rem = m - b * a.HoWo;
+    const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+    auto dot = [&](int n) {
+      float acc = 0.f;
+      for (int ky = 0; ky < a.ksize; ++ky)
+        for (int kx = 0; kx < a.ksize; ++kx) {
+          const int iy = oy * a.stride - a.pad + ky, ix = ox * a.stride - a.pad + kx;
+          if (iy < 0 || iy >= Hup || ix < 0 || ix >= Wup) continue;
+          const size_t pix = (size_t)b * a.Hi * a.Wi + (size_t)(iy >> upshift) * a.Wi + (ix >> upshift);
+          const half_t* wrow = a.w + (size_t)n * a.K + (size_t)(ky * a.ksize + kx) * a.Ctot;
+          const half_t* p0 = a.x0 + pix * a.C0;
+          for (int c = 0; c < a.C0; ++c) acc += (float)p0[c] * (float)wrow[c];
+          if (a.C1) {
+            const half_t* p1 = a.x1 + pix * a.C1;
+            for (int c = 0; c < a.C1; ++c) acc += (float)p1[c] * (float)wrow[a.C0 + c];
+          }
+        }
+      return acc + (a.bias ? a.bias[n] : 0.f);
+    };
+    if (geglu) {   // interleaved rows: 32 value channels then their 32 gate channels
+      const int nv = (no / 32) * 64 + (no % 32);
+      a.out[idx] = (half_t)(dot(nv) * gelu_erf(dot(nv + 32)));
+      continue;
+    }
+    float acc = dot(no);
+    if (a.temb) acc += a.temb[(size_t)b * a.temb_stride + no];
+    if (a.res) acc += (float)a.res[idx];
+    if (silu_out) acc = acc / (1.f + __expf(-acc));
+    if (a.out_mode == kOutHalfT)
+      a.out[((size_t)b * a.N + no) * a.ldT + rem] = (half_t)acc;
+    else
+      a.out[idx] = (half_t)acc;
+  }
+}
+
+// ---- N <= 8 output channels (conv_out 320->4): one wavefront per output pixel ----
+template <int NMAX>
+__global__ __launch_bounds__(256) void conv_small_n_kernel(IgemmArgs a, float* out_nchw) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= a.M) return;
+  const int b = m / a.HoWo;
+  const int rem = m - b * a.HoWo;
+  const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+  const int Hup = a.Hi * a.up, Wup = a.Wi * a.up, upshift = a.up >> 1;
+  float acc[NMAX];
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n) acc[n] = 0.f;
+  const int chunks = a.Ctot >> 3;
+  for (int tap = 0; tap < a.ksize * a.ksize; ++tap) {
+    const int ky = tap / a.ksize, kx = tap - ky * a.ksize;
+    const int iy = oy * a.stride - a.pad + ky, ix = ox * a.stride - a.pad + kx;
+    if (iy < 0 || iy >= Hup || ix < 0 || ix >= Wup) continue;   // wave-uniform
+    const size_t pix = (size_t)b * a.Hi * a.Wi + (size_t)(iy >> upshift) * a.Wi + (ix >> upshift);
+    for (int ch = lane; ch < chunks; ch += 64) {
+      const int c = ch * 8;
+      half8 xv = (c < a.C0) ? *reinterpret_cast<const half8*>(a.x0 + pix * a.C0 + c)
+                            : *reinterpret_cast<const half8*>(a.x1 + pix * a.C1 + (c - a.C0));
+#pragma unroll
+      for (int n = 0; n < NMAX; ++n) {
+        if (n < a.N) {
+          half8 wv = *reinterpret_cast<const half8*>(a.w + (size_t)n * a.K + (size_t)tap * a.Ctot + c);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[n] += (float)xv[e] * (float)wv[e];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n) {
+    float v = acc[n];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    acc[n] = v;
+  }
+  if (lane == 0) {
+    for (int n = 0; n < a.N; ++n) {
+      float v = acc[n] + (a.bias ? a.bias[n] : 0.f);
+      if (out_nchw)
+        out_nchw[((size_t)b * a.N + n) * a.HoWo + rem] = v;
+      else
+        a.out[(size_t)m * a.N + n] = (half_t)v;
+    }
+  }
+}
+
+IgemmArgs make_args(const ConvDesc& d) {
+  IgemmArgs a{};
+  a.x0 = d.x0;
+  a.x1 = d.x1;
+  a.w = d.w;
+  a.bias = d.bias;
+  a.temb = d.temb;
+  a.res = d.res;
+  a.out = d.out;
+  a.partial = nullptr;
+  a.C0 = d.C0;
+  a.C1 = d.x1 ? d.C1 : 0;
+  a.Ctot = a.C0 + a.C1;
+  a.B = d.B;
+  a.Hi = d.Hi;
+  a.Wi = d.Wi;
+  a.Ho = d.Ho;
+  a.Wo = d.Wo;
+  a.HoWo = d.Ho * d.Wo;
+  a.ksize = d.ksize;
+  a.stride = d.stride;
+  a.up = d.up;
+  a.pad = d.ksize / 2;
+  a.M = d.B * d.Ho * d.Wo;
+  a.N = d.N;
+  a.K = d.ksize * d.ksize * a.Ctot;
+  a.temb_stride = d.temb_stride;
+  a.nk_total = a.K / BK;
+  a.nk_per_split = a.nk_total;
+  a.splitk = 1;
+  a.out_mode = d.out_mode;
+  a.ldT = d.ldT;
+  return a;
+}
+
+struct Plan {
+  int tile;     // 1: 128x128, 2: 128x64, 3: 64x64, 4: 64x128
+  int splitk;
+};
+
+void tile_dims(int tile, int& bm, int& bn) {
+  switch (tile) {
+    case 1: bm = 128; bn = 128; break;
+    case 2: bm = 128; bn = 64; break;
+    case 3: bm = 64; bn = 64; break;
+    default: bm = 64; bn = 128; break;
+  }
+}
+
+// Heuristic: keep >= ~2 workgroups per CU in flight (256 CUs); prefer the big tile when the
+// grid is already full, split K when M is small and K is deep (8x8 / 16x16 levels stream
+// weights: SURVEY.md 7.3(1)).
+Plan choose_plan(const ConvDesc& d, const IgemmArgs& a) {
+  Plan p{d.tile, d.splitk};
+  const bool geglu = d.out_mode == kOutGeglu;
+  auto blocks_of = [&](int c) {
+    int bm, bn;
+    tile_dims(c, bm, bn);
+    return (long)cdiv(a.M, bm) * cdiv(a.N, bn);
+  };
+  if (p.tile == 0) {
+    if (geglu) {                      // GEGLU value/gate pairs need 64 n-columns per wave
+      p.tile = blocks_of(1) >= 256 ? 1 : 4;
+    } else {
+      p.tile = 3;
+      for (int c : {1, 2, 4}) {
+        if (blocks_of(c) >= 448) { p.tile = c; break; }
+      }
+    }
+  }
+  if (geglu && p.tile != 1 && p.tile != 4) p.tile = 4;
+  if (p.splitk == 0) {
+    p.splitk = 1;
+    if (d.out_mode == kOutHalf) {
+      int bm, bn;
+      tile_dims(p.tile, bm, bn);
+      long blocks = (long)cdiv(a.M, bm) * cdiv(a.N, bn);
+      while (blocks * p.splitk < 384 && p.splitk < 16 && a.nk_total / (p.splitk * 2) >= 4) p.splitk *= 2;
+    }
+  }
+  if (d.out_mode != kOutHalf) p.splitk = 1;
+  if (p.splitk > a.nk_total) p.splitk = a.nk_total;
+  return p;
+}
+
+template <int BM, int BN, int WGM, int WGN>
+void launch_tile(const IgemmArgs& a, bool trans, hipStream_t s) {
+  const size_t lds = (size_t)2 * (BM + BN) * LDS_ROW * sizeof(half_t);
+  dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), a.splitk);
+  if (trans) {
+    auto k = igemm_kernel<BM, BN, WGM, WGN, true>;
+    static bool attr = false;
+    if (!attr) { SD_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+  } else {
+    auto k = igemm_kernel<BM, BN, WGM, WGN, false>;
+    static bool attr = false;
+    if (!attr) { SD_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+  }
+}
+
+}  // namespace
+
+bool conv_fast_path_ok(const ConvDesc& d) {
+  const int c1 = d.x1 ? d.C1 : 0;
+  if (d.C0 % BK != 0 || c1 % BK != 0) return false;
+  if (d.N % 4 != 0) return false;
+  if (d.out_mode == kOutGeglu && d.N % 64 != 0) return false;
+  if (!(d.ksize == 1 || d.ksize == 3)) return false;
+  if (!(d.up == 1 || d.up == 2)) return false;
+  return true;
+}
+
+size_t conv_workspace_bytes(const ConvDesc& d) {
+  if (!conv_fast_path_ok(d)) return 0;
+  IgemmArgs a = make_args(d);
+  Plan p = choose_plan(d, a);
+  return p.splitk > 1 ? (size_t)p.splitk * a.M * a.N * sizeof(float) : 0;
+}
+
+void launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
+  SD_REQUIRE(conv_fast_path_ok(d), kInvalidArgument, "launch_conv: shape not MFMA-tileable (C0=%d C1=%d N=%d k=%d)",
+             d.C0, d.C1, d.N, d.ksize);
+  IgemmArgs a = make_args(d);
+  Plan p = choose_plan(d, a);
+  a.splitk = p.splitk;
+  a.nk_per_split = cdiv(a.nk_total, p.splitk);
+  a.splitk = cdiv(a.nk_total, a.nk_per_split);   // no empty splits
+  if (a.splitk > 1) {
+    size_t need = (size_t)a.splitk * a.M * a.N * sizeof(float);
+    SD_REQUIRE(ws.partial && ws.partial_bytes >= need, kInternal, "split-K workspace too small (%zu < %zu)",
+               ws.partial_bytes, need);
+    a.partial = ws.partial;
+  }
+  const bool trans = d.out_mode == kOutHalfT;
+  switch (p.tile) {
+    case 1: launch_tile<128, 128, 2, 2>(a, trans, s); break;
+    case 2: launch_tile<128, 64, 2, 2>(a, trans, s); break;
+    case 3: launch_tile<64, 64, 2, 2>(a, trans, s); break;
+    default: launch_tile<64, 128, 2, 2>(a, trans, s); break;
+  }
+  if (a.splitk > 1) {
+    size_t total4 = (size_t)a.M * a.N / 4;
+    int blocks = (int)std::min<size_t>((total4 + 255) / 256, 2048);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a);
+  }
+  SD_HIP(hipGetLastError());
+}
+
+void launch_conv_generic(const ConvDesc& d, int act_silu_out, hipStream_t s) {
+  IgemmArgs a = make_args(d);
+  SD_REQUIRE(d.out_mode != kOutGeglu || d.N % 64 == 0, kUnsupported, "generic GEGLU needs N %% 64 == 0 (N=%d)", d.N);
+  size_t total = (size_t)a.M * a.N;
+  int blocks = (int)std::min<size_t>((total + 255) / 256, 65535);
+  hipLaunchKernelGGL(conv_generic_kernel, dim3(blocks), dim3(256), 0, s, a, act_silu_out);
+  SD_HIP(hipGetLastError());
+}
+
+void launch_conv_small_n(const ConvDesc& d, float* out_nchw_f32, hipStream_t s) {
+  IgemmArgs a = make_args(d);
+  SD_REQUIRE(a.N <= 8 && a.Ctot % 8 == 0 && a.C0 % 8 == 0, kInvalidArgument, "conv_small_n: N=%d Ctot=%d", a.N,
+             a.Ctot);
+  hipLaunchKernelGGL(conv_small_n_kernel<8>, dim3(cdiv(a.M, 4)), dim3(256), 0, s, a, out_nchw_f32);
+  SD_HIP(hipGetLastError());
+}
+
+}  // namespace sd

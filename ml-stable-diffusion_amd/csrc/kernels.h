@@ -1,0 +1,120 @@
+// Launch interfaces of the hand-written gfx950 kernels.  All activations are channels-last
+// fp16: an image tensor is [B][H][W][C] == a token matrix [M = B*H*W][C]; the reference's BC1S
+// sequence layout (layer_norm.py:25) is the same bytes read as [B][S][C].
+#pragma once
+#include "sd_common.h"
+
+namespace sd {
+
+// ---------------------------------------------------------------------------------------------
+// K4/K5: implicit-GEMM convolution / 1x1 GEMM on MFMA (igemm.hip)
+//   out[m][n] = epilogue( sum_k X[m][k] * W[n][k] ),  k = tap*(C0+C1) + c
+// ---------------------------------------------------------------------------------------------
+enum OutMode : int {
+  kOutHalf = 0,        // half out[M][N]
+  kOutHalfT = 1,       // half out[B][N][ldT]   (token-transposed: V^T for attention)
+  kOutGeglu = 2,       // half out[M][N/2] = (v+bv) * gelu_erf(g+bg); W rows interleaved 32/32
+};
+
+struct ConvDesc {
+  const half_t* x0 = nullptr;   // [B][Hi][Wi][C0]
+  const half_t* x1 = nullptr;   // optional second source (channel concat), [B][Hi][Wi][C1]
+  int C0 = 0, C1 = 0;
+  const half_t* w = nullptr;    // [N][K] K-major, K = ksize*ksize*(C0+C1), tap-major
+  const float* bias = nullptr;  // [N] or null
+  const float* temb = nullptr;  // [B][temb_stride] broadcast over pixels, or null
+  int temb_stride = 0;
+  const half_t* res = nullptr;  // [M][N] residual, or null
+  half_t* out = nullptr;
+  int B = 1, Hi = 1, Wi = 1;    // source spatial size (before nearest x2 upsampling)
+  int Ho = 1, Wo = 1;           // output spatial size
+  int ksize = 1, stride = 1, up = 1;
+  int N = 0;
+  int out_mode = kOutHalf;
+  int ldT = 0;                  // kOutHalfT: padded token stride
+  // tuning overrides (0 = heuristic)
+  int tile = 0;                 // 1: 128x128  2: 128x64  3: 64x64 4: 64x128
+  int splitk = 0;
+};
+
+struct ConvWorkspace {
+  float* partial = nullptr;     // split-K slabs
+  size_t partial_bytes = 0;
+};
+
+// Returns the workspace bytes this conv needs with its current heuristic (for planning).
+size_t conv_workspace_bytes(const ConvDesc& d);
+void launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s);
+bool conv_fast_path_ok(const ConvDesc& d);
+
+// direct conv for tiny / odd shapes (any Cin, any N): fp32 accumulate, one thread per output
+void launch_conv_generic(const ConvDesc& d, int act_silu_out, hipStream_t s);
+
+// N <= 8 outputs, K % 8 == 0: one wavefront per output pixel.  out_nchw_f32: write float
+// [B][N][Ho][Wo] (the UNet's noise_pred boundary), else half NHWC.
+void launch_conv_small_n(const ConvDesc& d, float* out_nchw_f32, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// K1-K3: attention (attention.hip).  q [B][Sq][ldq] (head h at column h*d), k [B][Sk][ldk],
+// vt [B][heads*d][ldv] (token-transposed), out [B][Sq][ldo].
+// ---------------------------------------------------------------------------------------------
+enum AttnImpl : int { kAttnOriginal = 0, kAttnSplitEinsum = 1, kAttnSplitEinsumV2 = 2 };
+
+struct AttnDesc {
+  const half_t* q = nullptr;
+  const half_t* k = nullptr;
+  const half_t* vt = nullptr;
+  half_t* out = nullptr;
+  int B = 1, heads = 1, d = 64, Sq = 0, Sk = 0;
+  int ldq = 0, ldk = 0, ldv = 0, ldo = 0;
+  int impl = kAttnOriginal;
+  int variant = 0;   // tuning/testing: bit0 = use ds_bpermute instead of DPP in ORIGINAL
+};
+void launch_attention(const AttnDesc& d, hipStream_t s);
+bool attention_supported(int d);
+
+// ---------------------------------------------------------------------------------------------
+// K6/K7: norms (norm.hip)
+// ---------------------------------------------------------------------------------------------
+// y[m][:] = (x[m][:]-mean)*rstd * w + b over the channel dim (LayerNormANE, layer_norm.py:51-80)
+void launch_layernorm(const half_t* x, const float* w, const float* b, half_t* y, int M, int C, float eps,
+                      hipStream_t s);
+// GroupNorm over NHWC with optional channel-concat second source: deterministic two-pass
+// statistics (partial: groupnorm_scratch_floats() floats, stats: [B][G][2] = mean, rstd) + apply.
+int groupnorm_num_slabs(int B, int HW);
+size_t groupnorm_scratch_floats(int B, int HW, int G);
+void launch_groupnorm(const half_t* x0, int C0, const half_t* x1, int C1, float* partial, float* stats,
+                      const float* gamma, const float* beta, half_t* y, int B, int HW, int G, float eps, int silu,
+                      hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// K8/K9 + boundary helpers (misc.hip)
+// ---------------------------------------------------------------------------------------------
+// sinusoidal embedding [cos|sin] (unet.py:703-728), fp32.  t: [n] fp32 -> out [n][dim]
+void launch_timestep_embedding(const float* t, float* out, int n, int dim, float freq_shift, hipStream_t s);
+// out[b][n] = act_out( sum_k W[n][k]*act_in(x[b][k]) + bias[n] ); x fp32 [B][ldx], out fp32 [B][ldo]
+void launch_gemv(const half_t* w, const float* bias, const float* x, int ldx, float* out, int ldo, int B, int N,
+                 int K, int silu_in, int silu_out, int accumulate, hipStream_t s);
+void launch_nchw_to_nhwc(const void* src, int src_is_f32, half_t* dst, int B, int C, int H, int W, hipStream_t s);
+void launch_nhwc_to_nchw_f32(const half_t* src, float* dst, int B, int C, int H, int W, hipStream_t s);
+void launch_half_to_float(const half_t* src, float* dst, size_t n, hipStream_t s);
+void launch_float_to_half(const float* src, half_t* dst, size_t n, hipStream_t s);
+// y = a + b (fp16), used for ControlNet residual adds when not fused
+void launch_add_half(const half_t* a, const half_t* b, half_t* y, size_t n, hipStream_t s);
+// BC1S (B,C,1,S) fp16 -> token-major [B][S][C] fp16 (encoder_hidden_states boundary)
+void launch_bc1s_to_tokens(const half_t* src, half_t* dst, int B, int C, int S, hipStream_t s);
+
+// Device-resident denoising loop helpers (pipeline.py:500-573).  `step` is a device counter.
+struct LoopTables {
+  const float* timesteps;   // [n_steps]
+  const float* coef;        // [n_steps][8]: cx, c_eps0..c_eps3 (linear multistep), spare
+  int* step;                // device scalar
+};
+// latents fp32 NCHW [Bimg][4][H][W] -> UNet sample fp16 NHWC [cfg*Bimg][H][W][4], timestep buffer
+void launch_loop_prep(const float* latents, half_t* sample, float* tbuf, LoopTables t, int Bimg, int C, int H,
+                      int W, int cfg, hipStream_t s);
+// eps = u + g*(c-u) (pipeline.py:561-562); latents = cx*latents + sum ce_i * eps_hist_i; step++
+void launch_cfg_sched_step(const float* noise_pred, float* latents, float* eps_hist, LoopTables t, float guidance,
+                           int Bimg, int CHW, int cfg, int hist, hipStream_t s);
+
+}  // namespace sd

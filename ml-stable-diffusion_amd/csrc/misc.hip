@@ -1,0 +1,238 @@
+// K8/K9 and boundary helpers: timestep sinusoid, weight-streaming GEMV for the time-embedding
+// MLPs, layout conversions at the 4-channel model boundary, and the device-resident
+// classifier-free-guidance + scheduler step (pipeline.py:500-573 without host round trips).
+#include "kernels.h"
+
+namespace sd {
+namespace {
+
+// unet.py:703-728: exponent_i = -ln(10000) * i / (half - freq_shift); arg = float32(t) * exp(.);
+// [sin | cos] flipped to [cos | sin] (flip_sin_to_cos=True).  fp32 throughout (unet.py:719).
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, float* __restrict__ out, int n, int dim,
+                                          float freq_shift) {
+  const int half = dim / 2;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * half) return;
+  const int row = idx / half, i = idx - row * half;
+  const float exponent = -9.210340371976184f * (float)i / ((float)half - freq_shift);
+  const float arg = t[row] * expf(exponent);
+  out[(size_t)row * dim + i] = cosf(arg);
+  out[(size_t)row * dim + half + i] = sinf(arg);
+}
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
+
+// out[b][n] (+)= act_out( sum_k W[n][k] * act_in(x[b][k]) + bias[n] ).  One wavefront per output
+// row n: the weight row is streamed once with 16-B loads (HBM-bound: this is the M<=8 regime where
+// an LDS round trip would be pure overhead), x stays in L1/L2.  B <= 8.
+template <int BMAX>
+__global__ __launch_bounds__(256) void gemv_kernel(const half_t* __restrict__ w, const float* __restrict__ bias,
+                                                   const float* __restrict__ x, int ldx, float* __restrict__ out,
+                                                   int ldo, int B, int N, int K, int silu_in, int silu_out,
+                                                   int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float acc[BMAX];
+#pragma unroll
+  for (int b = 0; b < BMAX; ++b) acc[b] = 0.f;
+  const half_t* wr = w + (size_t)n * K;
+  for (int k = lane * 8; k < K; k += 64 * 8) {
+    const half8 wv = *reinterpret_cast<const half8*>(wr + k);
+#pragma unroll
+    for (int b = 0; b < BMAX; ++b) {
+      if (b < B) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float xv = x[(size_t)b * ldx + k + e];
+          if (silu_in) xv = silu_f(xv);
+          acc[b] += (float)wv[e] * xv;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < BMAX; ++b) {
+    float v = acc[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0 && b < B) {
+      v += bias ? bias[n] : 0.f;
+      if (silu_out) v = silu_f(v);
+      float* dst = out + (size_t)b * ldo + n;
+      *dst = accumulate ? (*dst + v) : v;
+    }
+  }
+}
+
+__global__ void nchw_to_nhwc_kernel(const void* __restrict__ src, int src_is_f32, half_t* __restrict__ dst, int B,
+                                    int C, int HW) {
+  const size_t total = (size_t)B * C * HW;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % C);
+    const size_t bp = idx / C;
+    const int p = (int)(bp % HW);
+    const int b = (int)(bp / HW);
+    const size_t s = ((size_t)b * C + c) * HW + p;
+    dst[idx] = src_is_f32 ? (half_t) reinterpret_cast<const float*>(src)[s] : reinterpret_cast<const half_t*>(src)[s];
+  }
+}
+
+__global__ void nhwc_to_nchw_f32_kernel(const half_t* __restrict__ src, float* __restrict__ dst, int B, int C, int HW) {
+  const size_t total = (size_t)B * C * HW;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int p = (int)(idx % HW);
+    const size_t bc = idx / HW;
+    const int c = (int)(bc % C);
+    const int b = (int)(bc / C);
+    dst[idx] = (float)src[((size_t)b * HW + p) * C + c];
+  }
+}
+
+__global__ void half_to_float_kernel(const half_t* __restrict__ s, float* __restrict__ d, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    d[i] = (float)s[i];
+}
+__global__ void float_to_half_kernel(const float* __restrict__ s, half_t* __restrict__ d, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    d[i] = (half_t)s[i];
+}
+__global__ void add_half_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b, half_t* __restrict__ y,
+                                size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const half8 x = reinterpret_cast<const half8*>(a)[i], z = reinterpret_cast<const half8*>(b)[i];
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)x[e] + (float)z[e]);
+    reinterpret_cast<half8*>(y)[i] = o;
+  }
+}
+// (B, C, 1, S) -> [B][S][C]
+__global__ void bc1s_to_tokens_kernel(const half_t* __restrict__ src, half_t* __restrict__ dst, int B, int C, int S) {
+  const size_t total = (size_t)B * C * S;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % C);
+    const size_t bs = idx / C;
+    const int s = (int)(bs % S);
+    const int b = (int)(bs / S);
+    dst[idx] = src[((size_t)b * C + c) * S + s];
+  }
+}
+
+// pipeline.py:502-511: duplicate the latents for CFG, cast to fp16, timestep [t, t]
+__global__ void loop_prep_kernel(const float* __restrict__ latents, half_t* __restrict__ sample,
+                                 float* __restrict__ tbuf, LoopTables t, int Bimg, int C, int HW, int cfg) {
+  const int step = *t.step;
+  const size_t per = (size_t)C * HW;
+  const size_t total = (size_t)Bimg * per;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % C);
+    const size_t bp = idx / C;
+    const int p = (int)(bp % HW);
+    const int b = (int)(bp / HW);
+    const half_t v = (half_t)latents[((size_t)b * C + c) * HW + p];   // fp16 cast at the UNet boundary (:532)
+    for (int r = 0; r < cfg; ++r) sample[((size_t)(r * Bimg + b) * HW + p) * C + c] = v;   // [uncond..., cond...]
+  }
+  if (blockIdx.x == 0 && threadIdx.x < cfg * Bimg) tbuf[threadIdx.x] = t.timesteps[step];
+}
+
+// pipeline.py:539, 561-569.  noise_pred fp32 NCHW [cfg*Bimg][CHW]; rows [0,Bimg) uncond, [Bimg,2Bimg) text.
+// latents <- cx * latents + sum_i ce_i * eps_hist_i, eps_hist_0 = this step's guided eps.
+__global__ void cfg_sched_step_kernel(const float* __restrict__ noise_pred, float* __restrict__ latents,
+                                      float* __restrict__ eps_hist, LoopTables t, float guidance, int Bimg,
+                                      int CHW, int cfg, int hist) {
+  const int step = *t.step;
+  const float* cf = t.coef + (size_t)step * 8;
+  const size_t total = (size_t)Bimg * CHW;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    float eps = noise_pred[idx];
+    if (cfg == 2) {
+      const float c = noise_pred[total + idx];
+      eps = eps + guidance * (c - eps);
+    }
+    float x = cf[0] * latents[idx] + cf[1] * eps;
+    // linear multistep history (PLMS / DPM++ style): slot j holds eps from j+1 steps ago
+    for (int j = hist - 1; j >= 0; --j) {
+      const float old = eps_hist[(size_t)j * total + idx];
+      x += cf[2 + j] * old;
+      if (j + 1 < hist) eps_hist[(size_t)(j + 1) * total + idx] = old;
+    }
+    if (hist > 0) eps_hist[idx] = eps;
+    latents[idx] = x;
+  }
+}
+__global__ void step_increment_kernel(int* step) { *step += 1; }
+
+inline int grid_for(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 2048); }
+
+}  // namespace
+
+void launch_timestep_embedding(const float* t, float* out, int n, int dim, float freq_shift, hipStream_t s) {
+  const int total = n * (dim / 2);
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, t, out, n, dim, freq_shift);
+  SD_HIP(hipGetLastError());
+}
+
+void launch_gemv(const half_t* w, const float* bias, const float* x, int ldx, float* out, int ldo, int B, int N,
+                 int K, int silu_in, int silu_out, int accumulate, hipStream_t s) {
+  SD_REQUIRE(K % 8 == 0, kUnsupported, "gemv: K=%d must be a multiple of 8", K);
+  for (int b0 = 0; b0 < B; b0 += 8) {
+    const int nb = std::min(8, B - b0);
+    hipLaunchKernelGGL(gemv_kernel<8>, dim3(cdiv(N, 4)), dim3(256), 0, s, w, bias, x + (size_t)b0 * ldx, ldx,
+                       out + (size_t)b0 * ldo, ldo, nb, N, K, silu_in, silu_out, accumulate);
+  }
+  SD_HIP(hipGetLastError());
+}
+
+void launch_nchw_to_nhwc(const void* src, int src_is_f32, half_t* dst, int B, int C, int H, int W, hipStream_t s) {
+  const size_t n = (size_t)B * C * H * W;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(n)), dim3(256), 0, s, src, src_is_f32, dst, B, C, H * W);
+  SD_HIP(hipGetLastError());
+}
+void launch_nhwc_to_nchw_f32(const half_t* src, float* dst, int B, int C, int H, int W, hipStream_t s) {
+  const size_t n = (size_t)B * C * H * W;
+  hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, dim3(grid_for(n)), dim3(256), 0, s, src, dst, B, C, H * W);
+  SD_HIP(hipGetLastError());
+}
+void launch_half_to_float(const half_t* src, float* dst, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(half_to_float_kernel, dim3(grid_for(n)), dim3(256), 0, s, src, dst, n);
+  SD_HIP(hipGetLastError());
+}
+void launch_float_to_half(const float* src, half_t* dst, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(float_to_half_kernel, dim3(grid_for(n)), dim3(256), 0, s, src, dst, n);
+  SD_HIP(hipGetLastError());
+}
+void launch_add_half(const half_t* a, const half_t* b, half_t* y, size_t n, hipStream_t s) {
+  SD_REQUIRE(n % 8 == 0, kInvalidArgument, "add_half: n %% 8 != 0");
+  hipLaunchKernelGGL(add_half_kernel, dim3(grid_for(n / 8)), dim3(256), 0, s, a, b, y, n / 8);
+  SD_HIP(hipGetLastError());
+}
+void launch_bc1s_to_tokens(const half_t* src, half_t* dst, int B, int C, int S, hipStream_t s) {
+  const size_t n = (size_t)B * C * S;
+  hipLaunchKernelGGL(bc1s_to_tokens_kernel, dim3(grid_for(n)), dim3(256), 0, s, src, dst, B, C, S);
+  SD_HIP(hipGetLastError());
+}
+
+void launch_loop_prep(const float* latents, half_t* sample, float* tbuf, LoopTables t, int Bimg, int C, int H, int W,
+                      int cfg, hipStream_t s) {
+  const size_t n = (size_t)Bimg * C * H * W;
+  hipLaunchKernelGGL(loop_prep_kernel, dim3(grid_for(n)), dim3(256), 0, s, latents, sample, tbuf, t, Bimg, C, H * W,
+                     cfg);
+  SD_HIP(hipGetLastError());
+}
+
+void launch_cfg_sched_step(const float* noise_pred, float* latents, float* eps_hist, LoopTables t, float guidance,
+                           int Bimg, int CHW, int cfg, int hist, hipStream_t s) {
+  const size_t n = (size_t)Bimg * CHW;
+  hipLaunchKernelGGL(cfg_sched_step_kernel, dim3(grid_for(n)), dim3(256), 0, s, noise_pred, latents, eps_hist, t,
+                     guidance, Bimg, CHW, cfg, hist);
+  hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, s, t.step);
+  SD_HIP(hipGetLastError());
+}
+
+}  // namespace sd

@@ -1,0 +1,239 @@
+// K6/K7 - normalisation kernels (HBM-bound; VALU + wavefront-shuffle reductions, fp32 statistics).
+//
+//   layernorm:  LayerNormANE over the channel dim of BC1S (layer_norm.py:51-80; with the load hook
+//               unet.py:132-138 the affine is x_hat*w + b on the checkpoint tensors), eps 1e-5,
+//               biased variance computed as mean((x-mu)^2) exactly like the reference.
+//               One wavefront per token row: the row lives in registers (16-B loads), two
+//               shuffle-reductions, one 16-B store per lane-chunk.
+//   groupnorm:  torch.nn.GroupNorm(32) of unet.py:430-451 (eps = norm_eps 1e-5), :528-531
+//               (SpatialTransformer, eps hard-coded 1e-6) and :966-968.  Channels-last makes a group
+//               a strided set, so statistics are a column reduction: each thread owns one 8-channel
+//               chunk column over a slab of pixels; partial (sum, sumsq) are merged per group in LDS
+//               in a fixed order and written per (sample, slab, group) - no atomics, so results are
+//               bitwise reproducible; a tiny second pass folds the slabs.  The apply pass fuses the
+//               affine, the optional SiLU (unet.py:473,481) and the channel concat of the up-block
+//               inputs (unet.py:213-216) into a single read-modify-write.
+#include "kernels.h"
+
+namespace sd {
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+constexpr int LN_MAX_CHUNKS = 4;   // C <= 64 lanes * 4 chunks * 8 = 2048
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, half_t* __restrict__ y, int M,
+                                                        int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nchunk = C >> 3;
+  const half_t* xr = x + (size_t)row * C;
+  float v[LN_MAX_CHUNKS][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nchunk) {
+      const half8 h = *reinterpret_cast<const half8*>(xr + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[i][e] = (float)h[e];
+        sum += v[i][e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    }
+  }
+  const float mean = wave_sum(sum) / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nchunk) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float dlt = v[i][e] - mean;
+        sq += dlt * dlt;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+  half_t* yr = y + (size_t)row * C;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nchunk) {
+      half8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (half_t)((v[i][e] - mean) * rstd * w[ch * 8 + e] + b[ch * 8 + e]);
+      *reinterpret_cast<half8*>(yr + ch * 8) = o;
+    }
+  }
+}
+
+// Pass 1, grid (pixel slabs, B): deterministic partial (sum, sumsq) per (sample, slab, group).
+// No atomics anywhere: bitwise run-to-run reproducibility of the whole UNet depends on it.
+__global__ __launch_bounds__(256) void groupnorm_partial_kernel(const half_t* __restrict__ x0, int C0,
+                                                                const half_t* __restrict__ x1, int C1,
+                                                                float* __restrict__ partial, int HW, int G,
+                                                                int pix_per_block) {
+  __shared__ float part[256][17];          // per-thread (sum[8], sumsq[8]); +1 pad against bank conflicts
+  __shared__ float chs[2048], chq[2048];   // per-channel sums of the current column block
+  const int C = C0 + C1;
+  const int ncol = C >> 3;                 // 8-channel chunk columns
+  const int cpg = C / G;
+  const int b = blockIdx.y;
+  const int p0 = blockIdx.x * pix_per_block;
+  const int p1 = min(p0 + pix_per_block, HW);
+  const int t = threadIdx.x;
+  float gs = 0.f, gq = 0.f;                // thread g < G accumulates group g across column blocks
+  for (int cb = 0; cb < ncol; cb += 256) { // C <= 2048 -> one pass; C = 2560 -> two
+    const int cols = min(256, ncol - cb);
+    const int rows = 256 / cols;           // pixel rows in flight
+    const int col = cb + t % cols;
+    const int r0 = t / cols;
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+    if (r0 < rows) {
+      const int c = col * 8;
+      const half_t* src = (c < C0) ? x0 + c : x1 + (c - C0);
+      const int Cs = (c < C0) ? C0 : C1;
+      for (int p = p0 + r0; p < p1; p += rows) {
+        const half8 h = *reinterpret_cast<const half8*>(src + ((size_t)b * HW + p) * Cs);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float f = (float)h[e];
+          s[e] += f;
+          q[e] += f * f;
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      part[t][e] = s[e];
+      part[t][8 + e] = q[e];
+    }
+    __syncthreads();
+    for (int cc = t; cc < cols * 8; cc += 256) {   // fixed-order reduction over the rows in flight
+      const int cl = cc >> 3, e = cc & 7;
+      float a = 0.f, d = 0.f;
+      for (int r = 0; r < rows; ++r) {
+        a += part[r * cols + cl][e];
+        d += part[r * cols + cl][8 + e];
+      }
+      chs[cc] = a;
+      chq[cc] = d;
+    }
+    __syncthreads();
+    if (t < G) {                                   // channels of group t inside this column block
+      const int lo = max(t * cpg, cb * 8), hi = min((t + 1) * cpg, (cb + cols) * 8);
+      for (int c = lo; c < hi; ++c) {
+        gs += chs[c - cb * 8];
+        gq += chq[c - cb * 8];
+      }
+    }
+    __syncthreads();
+  }
+  if (t < G) {
+    float* dst = partial + (((size_t)b * gridDim.x + blockIdx.x) * G + t) * 2;
+    dst[0] = gs;
+    dst[1] = gq;
+  }
+}
+
+// Pass 2, one thread per (sample, group): fixed-order sum over slabs -> (mean, rstd)
+__global__ void groupnorm_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats, int BG, int G,
+                                          int slabs, float inv_n, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= BG) return;
+  const int b = i / G, g = i - b * G;
+  float s = 0.f, q = 0.f;
+  for (int k = 0; k < slabs; ++k) {
+    const float* src = partial + (((size_t)b * slabs + k) * G + g) * 2;
+    s += src[0];
+    q += src[1];
+  }
+  const float mean = s * inv_n;
+  const float var = fmaxf(q * inv_n - mean * mean, 0.f);
+  stats[i * 2] = mean;
+  stats[i * 2 + 1] = rsqrtf(var + eps);
+}
+
+__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const half_t* __restrict__ x0, int C0,
+                                                              const half_t* __restrict__ x1, int C1,
+                                                              const float* __restrict__ stats,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, half_t* __restrict__ y,
+                                                              int B, int HW, int G, int silu) {
+  const int C = C0 + C1;
+  const int ncol = C >> 3;
+  const int cpg = C / G;
+  const size_t total = (size_t)B * HW * ncol;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int col = (int)(idx % ncol);
+    const size_t pix = idx / ncol;              // b*HW + p
+    const int b = (int)(pix / HW);
+    const int c = col * 8;
+    const half8 h = (c < C0) ? *reinterpret_cast<const half8*>(x0 + pix * C0 + c)
+                             : *reinterpret_cast<const half8*>(x1 + pix * C1 + (c - C0));
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int g = (c + e) / cpg;
+      const float mean = stats[((size_t)b * G + g) * 2];
+      const float rstd = stats[((size_t)b * G + g) * 2 + 1];
+      float v = ((float)h[e] - mean) * rstd * gamma[c + e] + beta[c + e];
+      if (silu) v = v / (1.0f + __expf(-v));
+      o[e] = (half_t)v;
+    }
+    *reinterpret_cast<half8*>(y + pix * C + c) = o;
+  }
+}
+
+}  // namespace
+
+void launch_layernorm(const half_t* x, const float* w, const float* b, half_t* y, int M, int C, float eps,
+                      hipStream_t s) {
+  SD_REQUIRE(C % 8 == 0 && C <= 64 * 8 * LN_MAX_CHUNKS, kUnsupported, "layernorm: C=%d (need C %% 8 == 0, C <= 2048)", C);
+  hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, x, w, b, y, M, C, eps);
+  SD_HIP(hipGetLastError());
+}
+
+int groupnorm_num_slabs(int B, int HW) {
+  // ~256+ blocks in total keeps every CU busy; at least 16 pixels per block; <= 128 slabs
+  int want = std::max(1, 512 / std::max(1, B));
+  return std::max(1, std::min(std::min(want, 128), std::max(1, HW / 16)));
+}
+
+size_t groupnorm_scratch_floats(int B, int HW, int G) { return (size_t)B * groupnorm_num_slabs(B, HW) * G * 2; }
+
+void launch_groupnorm(const half_t* x0, int C0, const half_t* x1, int C1, float* partial, float* stats,
+                      const float* gamma, const float* beta, half_t* y, int B, int HW, int G, float eps, int silu,
+                      hipStream_t s) {
+  if (!x1) C1 = 0;
+  const int C = C0 + C1;
+  SD_REQUIRE(C % G == 0 && C0 % 8 == 0 && C1 % 8 == 0 && G <= 64, kUnsupported, "groupnorm: C0=%d C1=%d G=%d", C0, C1, G);
+  int slabs = groupnorm_num_slabs(B, HW);
+  const int ppb = cdiv(HW, slabs);
+  slabs = cdiv(HW, ppb);   // <= groupnorm_num_slabs
+  hipLaunchKernelGGL(groupnorm_partial_kernel, dim3(slabs, B), dim3(256), 0, s, x0, C0, x1, C1, partial, HW, G, ppb);
+  const float inv_n = 1.0f / ((float)(C / G) * (float)HW);
+  hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(cdiv(B * G, 64)), dim3(64), 0, s, partial, stats, B * G, G, slabs,
+                     inv_n, eps);
+  const size_t total = (size_t)B * HW * (C / 8);
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(blocks), dim3(256), 0, s, x0, C0, x1, C1, stats, gamma, beta, y, B, HW,
+                     G, silu);
+  SD_HIP(hipGetLastError());
+}
+
+}  // namespace sd

@@ -50,7 +50,7 @@ struct Error : std::runtime_error {
   } while (0)
 
 // ---- device memory ---------------------------------------------------------------------------
-// One arena per model handle: a single hipMalloc carved by a bump pointer (256-B aligned).
+// One arena per model handle: a few large hipMallocs carved by a bump pointer (256-B aligned).
 // 288 GB of HBM per GPU means we never recycle activation buffers inside a forward: every
 // tensor of the static graph owns its bytes, which is what makes HIP-graph replay trivially safe.
 class Arena {
@@ -59,18 +59,14 @@ class Arena {
   ~Arena();
   Arena(const Arena&) = delete;
   Arena& operator=(const Arena&) = delete;
-  // two-phase: plan (count bytes) then commit (allocate) then hand out pointers in the same order
-  void* alloc(size_t bytes);
-  void commit();             // allocate everything planned so far; later alloc() calls carve it
-  size_t planned() const { return planned_; }
-  size_t capacity() const { return capacity_; }
-  bool committed() const { return base_ != nullptr; }
+  void* alloc(size_t bytes);          // 256-B aligned, zero-initialised
+  template <typename T>
+  T* alloc_n(size_t n) { return reinterpret_cast<T*>(alloc(n * sizeof(T))); }
+  size_t bytes() const { return total_; }
 
  private:
-  char* base_ = nullptr;
-  size_t planned_ = 0, capacity_ = 0, cursor_ = 0;
-  std::vector<size_t> plan_;   // sizes requested before commit (re-issued in order after commit)
-  size_t replay_ = 0;
+  std::vector<void*> chunks_;
+  size_t cap_ = 0, cur_ = 0, total_ = 0;
 };
 
 template <typename T>

@@ -1,0 +1,110 @@
+// Host-side builder/executor of the UNet (and ControlNet) launch graph.
+// Spec: python_coreml_stable_diffusion/unet.py:798-1152, controlnet.py:49-250.
+#pragma once
+#include <functional>
+
+#include "../../include/sd_mi355x.h"
+#include "kernels.h"
+#include "weights.h"
+
+namespace sd {
+
+struct Tensor {
+  half_t* p = nullptr;
+  int B = 0, H = 0, W = 0, C = 0;
+  int M() const { return B * H * W; }
+  size_t numel() const { return (size_t)B * H * W * C; }
+};
+
+using Op = std::function<void(hipStream_t)>;
+
+class UNet {
+ public:
+  UNet(const sd_unet_config& cfg, const WeightStore& ws, int device);
+  ~UNet();
+
+  void forward(const sd_unet_io& io);
+  float time_forward(int warmup, int iters);
+  void denoise_loop(const sd_unet_io& io, float* latents, int n_images, int n_steps, const float* timesteps,
+                    const float* coef, int history, float guidance, float* ms_per_step);
+  void set_attention(int impl);
+  int num_residuals() const { return (int)res_shapes_.size(); }
+  size_t device_bytes() const { return arena_.bytes(); }
+  const sd_unet_config& config() const { return cfg_; }
+
+ private:
+  // ---- build ----
+  void build_unet();
+  Tensor new_tensor(int B, int H, int W, int C);
+  half_t* upload_conv_weight(const std::string& name, int cout, int cin, int k, bool geglu);
+  float* upload_vec(const std::string& name, int n, bool geglu = false);
+  Tensor conv(std::vector<Op>& ops, const std::string& name, const Tensor& x, const Tensor* x2, int cout, int k,
+              int stride, int up, bool bias, const float* temb, const half_t* res, int out_mode = kOutHalf,
+              int ldT = 0, bool silu_out = false);
+  Tensor group_norm(std::vector<Op>& ops, const std::string& name, const Tensor& x, const Tensor* x2, float eps,
+                    bool silu);
+  Tensor layer_norm(std::vector<Op>& ops, const std::string& name, const Tensor& x);
+  Tensor resnet(std::vector<Op>& ops, const std::string& p, const Tensor& x, const Tensor* x2, int cout);
+  Tensor transformer(std::vector<Op>& ops, const std::string& p, const Tensor& x, int heads, int depth);
+  Tensor transformer_block(std::vector<Op>& ops, const std::string& b, const Tensor& h, int heads);
+  Tensor attention(std::vector<Op>& ops, const Tensor& q, const half_t* k, const half_t* vt, int heads, int Sq,
+                   int Sk, int ldk, int ldv);
+  void down_and_mid(std::vector<Op>& ops, Tensor& h, std::vector<Tensor>& skips);
+  const float* register_temb(const std::string& name, int cout);
+  void finalize_temb();
+  void upload_inputs(const sd_unet_io& io, bool loop_mode);
+  void run_ops(const std::vector<Op>& ops);
+  void ensure_graph();
+
+  sd_unet_config cfg_;
+  const WeightStore* ws_ = nullptr;   // only valid during construction
+  int device_ = 0;
+  hipStream_t stream_ = nullptr;
+  Arena arena_;
+
+  // static-shape input/output device buffers
+  half_t* in_sample_ = nullptr;     // NCHW f16
+  half_t* in_timestep_ = nullptr;   // (B,) f16
+  half_t* in_ehs_ = nullptr;        // BC1S f16
+  half_t* in_time_ids_ = nullptr;
+  half_t* in_text_embeds_ = nullptr;
+  half_t* in_cond_ = nullptr;       // ControlNet conditioning image NCHW f16
+  std::vector<half_t*> in_res_nchw_;   // support_controlnet: residual inputs (NCHW f16)
+  std::vector<Tensor> res_nhwc_;       // ... converted to NHWC
+  std::vector<std::vector<int>> res_shapes_;   // (B,C,H,W) of each residual
+  float* noise_pred_ = nullptr;     // NCHW f32
+  std::vector<float*> res_out_;     // ControlNet outputs NCHW f32
+  std::vector<Tensor> cn_out_;      // ControlNet outputs NHWC f16
+
+  Tensor x_in_;                     // NHWC sample
+  float* tbuf_ = nullptr;           // (B,) f32 timesteps
+  float* emb_ = nullptr;            // (B, temb_dim)
+  float* temb_all_ = nullptr;       // (B, kTembCap)
+  int temb_used_ = 0;
+  std::vector<std::pair<std::string, int>> temb_layers_;
+  half_t* temb_w_all_ = nullptr;
+  float* temb_b_all_ = nullptr;
+  Tensor ctx_;                      // encoder_hidden_states as tokens [B][L][Cctx]
+  ConvWorkspace ws_conv_;
+  size_t ws_need_ = 0;
+
+  std::vector<Op> in_ops_, time_ops_, ctx_ops_, cond_ops_, main_ops_;
+  std::vector<uint16_t> last_ehs_, last_cond_;
+  bool have_ctx_ = false, have_cond_ = false, have_inputs_ = false;
+  hipGraphExec_t graph_ = nullptr, loop_graph_ = nullptr;
+  int loop_graph_key_ = -1;
+
+  // denoise-loop state
+  float* latents_ = nullptr;
+  float* eps_hist_ = nullptr;
+  float* tab_timesteps_ = nullptr;
+  float* tab_coef_ = nullptr;
+  int* step_ = nullptr;
+  int tab_cap_ = 0;
+};
+
+}  // namespace sd
+
+struct sd_unet {
+  std::unique_ptr<sd::UNet> impl;
+};

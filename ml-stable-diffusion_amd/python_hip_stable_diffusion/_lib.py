@@ -1,0 +1,213 @@
+"""ctypes binding of ``libsdmi355.so`` (include/sd_mi355x.h).
+
+The library is the product; this module only marshals numpy arrays across the C ABI and maps
+status codes onto the exception classes the reference raises at the same seam
+(python_coreml_stable_diffusion/coreml_model.py:97-116, :176-178).  There is no CPU fallback:
+a missing library is an ImportError-class failure with build instructions, and a missing GPU
+surfaces as RuntimeError from the first call that needs one.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("SD_MI355X_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libsdmi355.so"))
+
+SD_MAX_LEVELS = 6
+SD_FLAG_DEVICE_PTRS = 1
+ATTENTION_IMPLEMENTATIONS = {"ORIGINAL": 0, "SPLIT_EINSUM": 1, "SPLIT_EINSUM_V2": 2}
+
+
+class LibraryNotBuilt(ImportError):
+    pass
+
+
+class UNetConfig(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("in_channels", C.c_int32), ("out_channels", C.c_int32),
+        ("height", C.c_int32), ("width", C.c_int32), ("n_levels", C.c_int32),
+        ("block_out_channels", C.c_int32 * SD_MAX_LEVELS),
+        ("down_cross_attn", C.c_int32 * SD_MAX_LEVELS),
+        ("up_cross_attn", C.c_int32 * SD_MAX_LEVELS),
+        ("layers_per_block", C.c_int32),
+        ("attention_head_dim", C.c_int32 * SD_MAX_LEVELS),
+        ("transformer_layers_per_block", C.c_int32 * SD_MAX_LEVELS),
+        ("cross_attention_dim", C.c_int32), ("context_len", C.c_int32),
+        ("norm_num_groups", C.c_int32), ("norm_eps", C.c_float),
+        ("flip_sin_to_cos", C.c_int32), ("freq_shift", C.c_float),
+        ("addition_time_embed_dim", C.c_int32), ("projection_class_embeddings_input_dim", C.c_int32),
+        ("num_time_ids", C.c_int32), ("support_controlnet", C.c_int32), ("is_controlnet", C.c_int32),
+        ("attention_impl", C.c_int32), ("use_graph", C.c_int32),
+    ]
+
+
+class UNetIO(C.Structure):
+    _fields_ = [
+        ("sample", C.c_void_p), ("timestep", C.c_void_p), ("encoder_hidden_states", C.c_void_p),
+        ("time_ids", C.c_void_p), ("text_embeds", C.c_void_p), ("controlnet_cond", C.c_void_p),
+        ("additional_residuals", C.POINTER(C.c_void_p)), ("num_additional_residuals", C.c_int32),
+        ("noise_pred", C.c_void_p), ("residual_outputs", C.POINTER(C.c_void_p)), ("flags", C.c_int32),
+    ]
+
+
+_lib = None
+
+# every symbol include/sd_mi355x.h declares: (name, restype, argtypes)
+_P, _I, _F = C.c_void_p, C.c_int, C.c_float
+_FP = C.POINTER(C.c_float)
+SYMBOLS = [
+    ("sd_last_error", C.c_char_p, []),
+    ("sd_version", C.c_char_p, []),
+    ("sd_device_count", _I, []),
+    ("sd_weights_create", _I, [C.POINTER(_P)]),
+    ("sd_weights_add", _I, [_P, C.c_char_p, _P, _I, C.POINTER(C.c_int64), _I]),
+    ("sd_weights_load_safetensors", _I, [_P, C.c_char_p, C.c_char_p]),
+    ("sd_weights_count", _I, [_P]),
+    ("sd_weights_destroy", None, [_P]),
+    ("sd_unet_create", _I, [C.POINTER(UNetConfig), _P, _I, C.POINTER(_P)]),
+    ("sd_unet_destroy", None, [_P]),
+    ("sd_unet_set_attention", _I, [_P, _I]),
+    ("sd_unet_num_residuals", _I, [_P]),
+    ("sd_unet_device_bytes", C.c_size_t, [_P]),
+    ("sd_unet_forward", _I, [_P, C.POINTER(UNetIO)]),
+    ("sd_unet_time_forward", _I, [_P, _I, _I, _FP]),
+    ("sd_unet_denoise_loop", _I, [_P, C.POINTER(UNetIO), _FP, _I, _I, _FP, _FP, _I, _F, _FP]),
+    ("sd_op_attention", _I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _FP]),
+    ("sd_op_layernorm", _I, [_P, _FP, _FP, _P, _I, _I, _I, _F, _I, _FP]),
+    ("sd_op_groupnorm", _I, [_P, _FP, _FP, _P, _I, _I, _I, _I, _I, _F, _I, _I, _FP]),
+    ("sd_op_conv2d", _I, [_P, _P, _FP, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _FP]),
+    ("sd_op_geglu", _I, [_P, _P, _FP, _P, _I, _I, _I, _I, _FP]),
+    ("sd_op_timestep_embedding", _I, [_FP, _FP, _I, _I, _I, _F]),
+    ("sd_numpy_randn", _I, [C.c_uint32, C.POINTER(C.c_double), C.c_size_t]),
+    ("sd_selftest_mfma", _I, []),
+]
+
+
+def lib():
+    """Load the shared library (once).  torch is imported first when available so that both bind
+    the same HIP runtime (torch ships its own libamdhip64 with the same soname)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LibraryNotBuilt(
+            f"{LIB_PATH} is missing - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C ml-stable-diffusion_amd/csrc`. There is no CPU fallback.")
+    try:
+        import torch  # noqa: F401  (plumbing only: shares libamdhip64 / RCCL with torch.distributed)
+    except Exception:  # pragma: no cover - torch is optional for the library itself
+        pass
+    handle = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(handle, name)   # AttributeError here == header/library mismatch
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = handle
+    return handle
+
+
+_EXC = {-1: ValueError, -2: FileNotFoundError, -3: RuntimeError, -4: NotImplementedError, -5: RuntimeError}
+
+
+def check(status):
+    if status != 0:
+        msg = lib().sd_last_error().decode("utf-8", "replace")
+        raise _EXC.get(status, RuntimeError)(msg)
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def fptr(a):
+    return None if a is None else a.ctypes.data_as(_FP)
+
+
+def f16(a):
+    return np.ascontiguousarray(a, dtype=np.float16)
+
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# ------------------------------------------------------------------------------------------------
+# operator-level wrappers (tests / micro-benchmarks); all take & return the reference layouts
+# ------------------------------------------------------------------------------------------------
+def attention(impl, q, k, v, heads, dim_head, variant=0, iters=1):
+    """attention.py:24-168.  q (B,h*d,1,Sq), k/v (B,h*d,1,Sk) -> (B,h*d,1,Sq) fp16, ms."""
+    if impl not in ATTENTION_IMPLEMENTATIONS:
+        raise ValueError(f"unknown attention implementation {impl!r}")
+    q, k, v = f16(q), f16(k), f16(v)
+    B, Cq, _, Sq = q.shape
+    Sk = k.shape[3]
+    if Cq != heads * dim_head or k.shape[1] != Cq or v.shape != k.shape:
+        raise ValueError("attention: inconsistent q/k/v shapes")
+    out = np.empty_like(q)
+    ms = C.c_float(0)
+    check(lib().sd_op_attention(ATTENTION_IMPLEMENTATIONS[impl], ptr(q), ptr(k), ptr(v), ptr(out), B, heads,
+                                dim_head, Sq, Sk, variant, iters, C.byref(ms)))
+    return out, ms.value
+
+
+def layernorm(x, weight, bias, eps=1e-5, iters=1):
+    x, weight, bias = f16(x), f32(weight), f32(bias)
+    B, Cn, _, S = x.shape
+    out = np.empty_like(x)
+    ms = C.c_float(0)
+    check(lib().sd_op_layernorm(ptr(x), fptr(weight), fptr(bias), ptr(out), B, Cn, S, eps, iters, C.byref(ms)))
+    return out, ms.value
+
+
+def groupnorm(x, weight, bias, groups=32, eps=1e-5, silu=False, iters=1):
+    x, weight, bias = f16(x), f32(weight), f32(bias)
+    B, Cn, H, W = x.shape
+    out = np.empty_like(x)
+    ms = C.c_float(0)
+    check(lib().sd_op_groupnorm(ptr(x), fptr(weight), fptr(bias), ptr(out), B, Cn, H, W, groups, eps, int(silu),
+                                iters, C.byref(ms)))
+    return out, ms.value
+
+
+def conv2d(x, w, bias=None, res=None, stride=1, upsample=False, tile=0, splitk=0, force_generic=False, iters=1):
+    x, w = f16(x), f16(w)
+    B, Cin, H, W = x.shape
+    Cout, Cin2, k, k2 = w.shape
+    if Cin2 != Cin or k != k2:
+        raise ValueError("conv2d: weight shape does not match input")
+    up = 2 if upsample else 1
+    pad = k // 2
+    Ho = (H * up + 2 * pad - k) // stride + 1
+    Wo = (W * up + 2 * pad - k) // stride + 1
+    bias = None if bias is None else f32(bias)
+    res = None if res is None else f16(res)
+    out = np.empty((B, Cout, Ho, Wo), np.float16)
+    ms = C.c_float(0)
+    check(lib().sd_op_conv2d(ptr(x), ptr(w), fptr(bias), ptr(res), ptr(out), B, Cin, H, W, Cout, k, stride,
+                             int(upsample), tile, splitk, int(force_generic), iters, C.byref(ms)))
+    return out, ms.value
+
+
+def geglu(x, w, bias=None, iters=1):
+    x, w = f16(x), f16(w)
+    M, Cn = x.shape
+    N2 = w.shape[0]
+    bias = None if bias is None else f32(bias)
+    out = np.empty((M, N2 // 2), np.float16)
+    ms = C.c_float(0)
+    check(lib().sd_op_geglu(ptr(x), ptr(w), fptr(bias), ptr(out), M, Cn, N2, iters, C.byref(ms)))
+    return out, ms.value
+
+
+def timestep_embedding(t, dim, flip_sin_to_cos=True, freq_shift=0.0):
+    t = f32(t)
+    out = np.empty((t.shape[0], dim), np.float32)
+    check(lib().sd_op_timestep_embedding(fptr(t), fptr(out), t.shape[0], dim, int(flip_sin_to_cos), freq_shift))
+    return out
+
+
+def numpy_randn(seed, n):
+    out = np.empty(n, np.float64)
+    check(lib().sd_numpy_randn(seed, out.ctypes.data_as(C.POINTER(C.c_double)), n))
+    return out

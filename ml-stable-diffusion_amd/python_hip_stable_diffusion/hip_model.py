@@ -1,0 +1,316 @@
+"""``HipModel`` - the MI355X drop-in for the reference's model-runner seam.
+
+Duck-types ``CoreMLModel`` (python_coreml_stable_diffusion/coreml_model.py:36-120): same
+``expected_inputs`` attribute ({name: {"shape", "dtype"}}, coreml_model.py:58-64), same call
+signature ``model(**np.ndarray) -> dict[str, np.ndarray]`` (:118-120), same input validation
+and exception classes (``_verify_inputs`` :97-116), same tensor names/layouts/dtypes at the
+boundary (torch2coreml.py:857-863, :905-908, :952, :988, :1412) with fp32 outputs like the
+Core ML models declare (torch2coreml.py:135).  Behind it sits ``libsdmi355.so`` instead of
+``MLModel.predict``; static shapes are fixed at construction exactly as conversion fixes them
+for a .mlpackage (pipeline.py:112-114).  The attention implementation, a conversion-time flag
+in the reference (torch2coreml.py:1678-1685 -> unet.py:39), is a per-handle run-time switch.
+"""
+import ctypes as C
+import logging
+import time
+
+import numpy as np
+
+from . import _lib
+
+logger = logging.getLogger(__name__)
+
+CROSS_ATTN_DOWN, DOWN = "CrossAttnDownBlock2D", "DownBlock2D"
+CROSS_ATTN_UP, UP = "CrossAttnUpBlock2D", "UpBlock2D"
+
+# Public HF config.json values (not in the reference: it reads them via **pipe.unet.config,
+# torch2coreml.py:915).  Validated by parameter count in SURVEY.md Appendix B.
+UNET_CONFIGS = {
+    "stabilityai/stable-diffusion-2-1-base": dict(
+        block_out_channels=(320, 640, 1280, 1280), attention_head_dim=(5, 10, 20, 20), cross_attention_dim=1024),
+    "runwayml/stable-diffusion-v1-5": dict(
+        block_out_channels=(320, 640, 1280, 1280), attention_head_dim=8, cross_attention_dim=768),
+    "stabilityai/stable-diffusion-xl-base-1.0": dict(
+        sample_size=128, block_out_channels=(320, 640, 1280), down_block_types=(DOWN, CROSS_ATTN_DOWN, CROSS_ATTN_DOWN),
+        up_block_types=(CROSS_ATTN_UP, CROSS_ATTN_UP, UP), attention_head_dim=(5, 10, 20), cross_attention_dim=2048,
+        transformer_layers_per_block=(1, 2, 10), addition_embed_type="text_time", addition_time_embed_dim=256,
+        projection_class_embeddings_input_dim=2816),
+    "stabilityai/stable-diffusion-xl-refiner-1.0": dict(
+        sample_size=128, block_out_channels=(384, 768, 1536, 1536),
+        down_block_types=(DOWN, CROSS_ATTN_DOWN, CROSS_ATTN_DOWN, DOWN),
+        up_block_types=(UP, CROSS_ATTN_UP, CROSS_ATTN_UP, UP), attention_head_dim=(6, 12, 24, 24),
+        cross_attention_dim=1280, transformer_layers_per_block=4, addition_embed_type="text_time",
+        addition_time_embed_dim=256, projection_class_embeddings_input_dim=2560),
+}
+
+
+def normalize_unet_config(config):
+    """Fill UNet2DConditionModel.__init__ defaults (unet.py:801-833) and reject what the
+    reference rejects (unet.py:835-880)."""
+    if isinstance(config, str):
+        if config not in UNET_CONFIGS:
+            raise ValueError(f"unknown model version {config!r}; known: {sorted(UNET_CONFIGS)}")
+        config = UNET_CONFIGS[config]
+    cfg = dict(
+        in_channels=4, out_channels=4, sample_size=64, block_out_channels=(320, 640, 1280, 1280),
+        down_block_types=(CROSS_ATTN_DOWN,) * 3 + (DOWN,), up_block_types=(UP,) + (CROSS_ATTN_UP,) * 3,
+        layers_per_block=2, attention_head_dim=8, cross_attention_dim=768, transformer_layers_per_block=1,
+        norm_num_groups=32, norm_eps=1e-5, flip_sin_to_cos=True, freq_shift=0, addition_embed_type=None,
+        addition_time_embed_dim=None, projection_class_embeddings_input_dim=None, support_controlnet=False,
+        only_cross_attention=False, mid_block_type="UNetMidBlock2DCrossAttn", center_input_sample=False)
+    unknown_ok = {"use_linear_projection", "act_fn", "downsample_padding", "mid_block_scale_factor",
+                  "time_cond_proj_dim", "upcast_attention", "resnet_time_scale_shift", "_class_name",
+                  "_diffusers_version", "num_class_embeds", "dual_cross_attention", "class_embed_type",
+                  "conditioning_embedding_out_channels", "num_time_ids"}
+    for k, v in dict(config).items():
+        if k not in cfg and k not in unknown_ok:
+            logger.warning("ignoring unknown UNet config key %r", k)
+        cfg[k] = v
+    if cfg.get("dual_cross_attention") or cfg.get("num_class_embeds") or cfg["only_cross_attention"]:
+        raise NotImplementedError("dual_cross_attention / class embeddings / only_cross_attention (unet.py:835-840)")
+    if cfg["addition_embed_type"] not in (None, "text_time"):
+        raise NotImplementedError(f"addition_embed_type {cfg['addition_embed_type']!r} (unet.py:868-880)")
+    if cfg["mid_block_type"] != "UNetMidBlock2DCrossAttn" or cfg["center_input_sample"]:
+        raise NotImplementedError("mid_block_type / center_input_sample outside the path (unet.py:919, :987)")
+    n = len(cfg["block_out_channels"])
+    if n > _lib.SD_MAX_LEVELS:
+        raise NotImplementedError(f"more than {_lib.SD_MAX_LEVELS} resolution levels")
+    for key in ("attention_head_dim", "transformer_layers_per_block"):
+        v = cfg[key]
+        cfg[key] = tuple([v] * n) if isinstance(v, int) else tuple(v)
+    for t in cfg["down_block_types"]:
+        if t not in (CROSS_ATTN_DOWN, DOWN):
+            raise NotImplementedError(f"down block type {t}")
+    for t in cfg["up_block_types"]:
+        if t not in (CROSS_ATTN_UP, UP):
+            raise NotImplementedError(f"up block type {t}")
+    return cfg
+
+
+def _fill(arr, values):
+    for i, v in enumerate(values):
+        arr[i] = int(v)
+
+
+class Weights:
+    """Owns an ``sd_weights`` store (checkpoint tensors keyed by diffusers names)."""
+
+    def __init__(self, tensors=None, safetensors_path=None, prefix=None):
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().sd_weights_create(C.byref(self._h)))
+        if safetensors_path is not None:
+            _lib.check(_lib.lib().sd_weights_load_safetensors(
+                self._h, str(safetensors_path).encode(), None if prefix is None else prefix.encode()))
+        for name, t in (tensors or {}).items():
+            self.add(name, t)
+
+    def add(self, name, t):
+        t = np.asarray(t)
+        if t.dtype == np.float16:
+            dt = 0
+        else:
+            t = t.astype(np.float32, copy=False)
+            dt = 1
+        t = np.ascontiguousarray(t)
+        shape = (C.c_int64 * max(1, t.ndim))(*t.shape)
+        _lib.check(_lib.lib().sd_weights_add(self._h, name.encode(), _lib.ptr(t), dt, shape, t.ndim))
+
+    def __len__(self):
+        return _lib.lib().sd_weights_count(self._h)
+
+    def close(self):
+        if self._h:
+            _lib.lib().sd_weights_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HipModel:
+    """UNet / control-UNet / ControlNet on one MI355X behind the CoreMLModel interface."""
+
+    def __init__(self, config, weights, kind="unet", batch=2, latent_height=None, latent_width=None,
+                 attention_implementation="SPLIT_EINSUM", device=0, use_graph=True, context_len=77):
+        if kind not in ("unet", "controlnet"):
+            raise ValueError(f"kind must be 'unet' or 'controlnet', got {kind!r}")
+        if attention_implementation not in _lib.ATTENTION_IMPLEMENTATIONS:
+            raise ValueError(f"--attention-implementation must be one of {list(_lib.ATTENTION_IMPLEMENTATIONS)}")
+        start = time.time()
+        cfg = normalize_unet_config(config)
+        self.config = cfg
+        self.kind = kind
+        h = latent_height or cfg["sample_size"]
+        w = latent_width or cfg["sample_size"]
+        n = len(cfg["block_out_channels"])
+        xl = cfg["addition_embed_type"] == "text_time"
+        c = _lib.UNetConfig()
+        c.batch, c.in_channels, c.out_channels = batch, cfg["in_channels"], cfg["out_channels"]
+        c.height, c.width, c.n_levels = h, w, n
+        _fill(c.block_out_channels, cfg["block_out_channels"])
+        _fill(c.down_cross_attn, [t == CROSS_ATTN_DOWN for t in cfg["down_block_types"]])
+        _fill(c.up_cross_attn, [t == CROSS_ATTN_UP for t in cfg["up_block_types"]])
+        c.layers_per_block = cfg["layers_per_block"]
+        _fill(c.attention_head_dim, cfg["attention_head_dim"])
+        _fill(c.transformer_layers_per_block, cfg["transformer_layers_per_block"])
+        c.cross_attention_dim, c.context_len = cfg["cross_attention_dim"], context_len
+        c.norm_num_groups, c.norm_eps = cfg["norm_num_groups"], cfg["norm_eps"]
+        c.flip_sin_to_cos, c.freq_shift = int(cfg["flip_sin_to_cos"]), float(cfg["freq_shift"])
+        self.num_time_ids = 0
+        self.text_embed_dim = 0
+        if xl:
+            c.addition_time_embed_dim = cfg["addition_time_embed_dim"]
+            c.projection_class_embeddings_input_dim = cfg["projection_class_embeddings_input_dim"]
+            # base: 6 ids + 1280-d pooled text; refiner: 5 ids + 1280-d (StableDiffusionXLPipeline.swift:326-358)
+            self.num_time_ids = int(cfg.get("num_time_ids") or
+                                    (5 if cfg["projection_class_embeddings_input_dim"] == 2560 else 6))
+            c.num_time_ids = self.num_time_ids
+            self.text_embed_dim = (cfg["projection_class_embeddings_input_dim"] -
+                                   self.num_time_ids * cfg["addition_time_embed_dim"])
+        c.support_controlnet = int(bool(cfg["support_controlnet"]) and kind == "unet")
+        c.is_controlnet = int(kind == "controlnet")
+        c.attention_impl = _lib.ATTENTION_IMPLEMENTATIONS[attention_implementation]
+        c.use_graph = int(use_graph)
+        self._cfg_struct = c
+        own = not isinstance(weights, Weights)
+        wstore = weights if not own else (Weights(safetensors_path=weights) if isinstance(weights, (str, bytes))
+                                          else Weights(tensors=weights))
+        self._h = C.c_void_p()
+        try:
+            _lib.check(_lib.lib().sd_unet_create(C.byref(c), wstore._h, device, C.byref(self._h)))
+        finally:
+            if own:
+                wstore.close()
+        self.batch, self.latent_height, self.latent_width = batch, h, w
+        self.attention_implementation = attention_implementation
+        self.num_residuals = _lib.lib().sd_unet_num_residuals(self._h)
+
+        f16 = np.dtype(np.float16)
+        ei = {
+            "sample": {"shape": (batch, cfg["in_channels"], h, w), "dtype": f16},
+            "timestep": {"shape": (batch,), "dtype": f16},
+            "encoder_hidden_states": {"shape": (batch, cfg["cross_attention_dim"], 1, context_len), "dtype": f16},
+        }
+        if xl:
+            ei["time_ids"] = {"shape": (batch, self.num_time_ids), "dtype": f16}
+            ei["text_embeds"] = {"shape": (batch, self.text_embed_dim), "dtype": f16}
+        self._res_shapes = self._residual_shapes(cfg, batch, h, w)
+        if kind == "controlnet":
+            ei["controlnet_cond"] = {"shape": (batch, 3, h * 8, w * 8), "dtype": f16}
+        elif c.support_controlnet:
+            for i, s in enumerate(self._res_shapes):
+                ei[f"additional_residual_{i}"] = {"shape": s, "dtype": f16}
+        self.expected_inputs = ei
+        logger.info("HipModel(%s) ready in %.1f s, %.2f GB of HBM", kind, time.time() - start,
+                    _lib.lib().sd_unet_device_bytes(self._h) / 1e9)
+
+    @staticmethod
+    def _residual_shapes(cfg, batch, h, w):
+        boc = cfg["block_out_channels"]
+        shapes = [(batch, boc[0], h, w)]
+        for i in range(len(boc)):
+            shapes += [(batch, boc[i], h, w)] * cfg["layers_per_block"]
+            if i != len(boc) - 1:
+                h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+                shapes.append((batch, boc[i], h, w))
+        shapes.append((batch, boc[-1], h, w))
+        return shapes
+
+    # coreml_model.py:97-116
+    def _verify_inputs(self, **kwargs):
+        for k, v in kwargs.items():
+            if k in self.expected_inputs:
+                if not isinstance(v, np.ndarray):
+                    raise TypeError(f"Expected numpy.ndarray, got {v} for input: {k}")
+                expected_dtype = self.expected_inputs[k]["dtype"]
+                if not v.dtype == expected_dtype:
+                    raise TypeError(f"Expected dtype {expected_dtype}, got {v.dtype} for input: {k}")
+                expected_shape = self.expected_inputs[k]["shape"]
+                if not v.shape == expected_shape:
+                    raise TypeError(f"Expected shape {expected_shape}, got {v.shape} for input: {k}")
+            else:
+                raise ValueError(f"Received unexpected input kwarg: {k}")
+        missing = [k for k in self.expected_inputs if k not in kwargs]
+        if missing:
+            raise ValueError(f"Missing input kwargs: {missing}")
+
+    def _io(self, kwargs, keep):
+        io = _lib.UNetIO()
+
+        def put(field, name):
+            if name in kwargs:
+                a = np.ascontiguousarray(kwargs[name])
+                keep.append(a)
+                setattr(io, field, a.ctypes.data)
+
+        for f in ("sample", "timestep", "encoder_hidden_states", "time_ids", "text_embeds", "controlnet_cond"):
+            put(f, f)
+        if self.kind == "unet" and self._cfg_struct.support_controlnet:
+            arrs = [np.ascontiguousarray(kwargs[f"additional_residual_{i}"]) for i in range(self.num_residuals)]
+            keep.extend(arrs)
+            ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+            keep.append(ptrs)
+            io.additional_residuals = C.cast(ptrs, C.POINTER(C.c_void_p))
+            io.num_additional_residuals = len(arrs)
+        return io
+
+    def __call__(self, **kwargs):
+        self._verify_inputs(**kwargs)
+        keep = []
+        io = self._io(kwargs, keep)
+        if self.kind == "unet":
+            out = np.empty((self.batch, self.config["out_channels"], self.latent_height, self.latent_width),
+                           np.float32)
+            io.noise_pred = out.ctypes.data
+            _lib.check(_lib.lib().sd_unet_forward(self._h, C.byref(io)))
+            return {"noise_pred": out}
+        outs = [np.empty(s, np.float32) for s in self._res_shapes]
+        ptrs = (C.c_void_p * len(outs))(*[o.ctypes.data for o in outs])
+        io.residual_outputs = C.cast(ptrs, C.POINTER(C.c_void_p))
+        _lib.check(_lib.lib().sd_unet_forward(self._h, C.byref(io)))
+        return {f"additional_residual_{i}": o for i, o in enumerate(outs)}
+
+    # ---- beyond the reference surface -----------------------------------------------------
+    def set_attention_implementation(self, name):
+        if name not in _lib.ATTENTION_IMPLEMENTATIONS:
+            raise ValueError(f"--attention-implementation must be one of {list(_lib.ATTENTION_IMPLEMENTATIONS)}")
+        _lib.check(_lib.lib().sd_unet_set_attention(self._h, _lib.ATTENTION_IMPLEMENTATIONS[name]))
+        self.attention_implementation = name
+
+    def time_forward(self, warmup=2, iters=10):
+        """HIP-event milliseconds per forward on the handle's stream (inputs of the last call)."""
+        ms = C.c_float(0)
+        _lib.check(_lib.lib().sd_unet_time_forward(self._h, warmup, iters, C.byref(ms)))
+        return ms.value
+
+    def denoise_loop(self, latents, timesteps, coef, guidance_scale, history=0, **kwargs):
+        """Device-resident pipeline.py:500-573.  latents (n_img, C, H, W) float32 -> final latents,
+        per-step HIP-event milliseconds."""
+        keep = []
+        io = self._io(kwargs, keep)
+        lat = np.ascontiguousarray(latents, dtype=np.float32).copy()
+        ts = np.ascontiguousarray(timesteps, dtype=np.float32)
+        cf = np.ascontiguousarray(coef, dtype=np.float32).reshape(len(ts), 8)
+        ms = np.zeros(len(ts), np.float32)
+        _lib.check(_lib.lib().sd_unet_denoise_loop(self._h, C.byref(io), _lib.fptr(lat), lat.shape[0], len(ts),
+                                                   _lib.fptr(ts), _lib.fptr(cf), history, float(guidance_scale),
+                                                   _lib.fptr(ms)))
+        return lat, ms
+
+    @property
+    def device_bytes(self):
+        return _lib.lib().sd_unet_device_bytes(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().sd_unet_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

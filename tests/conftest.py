@@ -1,0 +1,35 @@
+"""pytest configuration: `-m "not gpu"` runs on the CPU-only build container (oracle vs golden
+vectors, host logic, C-ABI symbol checks); `-m gpu` runs the parity tests proper on an MI355X
+through the C ABI.  GPU tests never skip on a missing library: that is a failure."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "ml-stable-diffusion_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
+
+
+@pytest.fixture(scope="session")
+def sdlib():
+    """The loaded C-ABI library; a missing/unbuilt library is an error, never a skip."""
+    from python_hip_stable_diffusion import _lib
+    return _lib.lib()

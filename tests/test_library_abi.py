@@ -1,0 +1,92 @@
+"""CPU suite: the C-ABI library loads, exports every symbol include/sd_mi355x.h declares, and its
+host-only entry points behave (no compute call needs a GPU here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from oracle import rng_ref
+from python_hip_stable_diffusion import _lib, hip_model
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "sd_mi355x.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(sdlib):
+    declared = _header_functions()
+    assert len(declared) >= 20
+    bound = sorted(name for name, _, _ in _lib.SYMBOLS)
+    assert declared == bound, set(declared) ^ set(bound)
+    for name in declared:
+        assert hasattr(sdlib, name), name
+
+
+def test_version_and_error_string(sdlib):
+    assert b"gfx950" in sdlib.sd_version()
+    assert isinstance(sdlib.sd_last_error(), bytes)
+
+
+def test_numpy_randn_is_bit_exact_host_side(sdlib):
+    """StableDiffusionTests.swift:52-62 golden + numpy itself (pipeline.py:331,:726 stream)."""
+    got = _lib.numpy_randn(rng_ref.GOLDEN_SEED, rng_ref.GOLDEN_COUNT)
+    np.testing.assert_allclose(got[-5:], rng_ref.GOLDEN_LAST5, atol=1e-8)
+    np.random.seed(rng_ref.GOLDEN_SEED)
+    assert np.array_equal(got, np.random.randn(rng_ref.GOLDEN_COUNT))
+    np.random.seed(93)                                   # the CLI default seed (pipeline.py:800)
+    assert np.array_equal(_lib.numpy_randn(93, 4 * 64 * 64 + 1), np.random.randn(4 * 64 * 64 + 1))
+    assert _lib.numpy_randn(0, 0).shape == (0,)
+
+
+def test_weight_store_and_safetensors_reader(sdlib, tmp_path):
+    from safetensors.numpy import save_file
+    rs = np.random.RandomState(0)
+    tensors = {"unet.conv_in.weight": rs.randn(8, 4, 3, 3).astype(np.float16),
+               "unet.conv_in.bias": rs.randn(8).astype(np.float32)}
+    path = tmp_path / "w.safetensors"
+    save_file(tensors, str(path), metadata={"format": "pt"})
+    w = hip_model.Weights(safetensors_path=str(path), prefix="unet.")
+    assert len(w) == 2
+    w.add("extra", np.zeros((2, 2), np.float32))
+    assert len(w) == 3
+    w.close()
+    with pytest.raises(FileNotFoundError):
+        hip_model.Weights(safetensors_path=str(tmp_path / "missing.safetensors"))
+
+
+def test_config_normalisation_mirrors_reference_rejections():
+    cfg = hip_model.normalize_unet_config("stabilityai/stable-diffusion-2-1-base")
+    assert cfg["attention_head_dim"] == (5, 10, 20, 20) and cfg["cross_attention_dim"] == 1024
+    with pytest.raises(NotImplementedError):      # unet.py:835-840
+        hip_model.normalize_unet_config(dict(only_cross_attention=True))
+    with pytest.raises(NotImplementedError):      # unet.py:868-880
+        hip_model.normalize_unet_config(dict(addition_embed_type="text"))
+    with pytest.raises(ValueError):
+        hip_model.normalize_unet_config("no/such-model")
+
+
+def test_no_cpu_fallback_without_a_gpu(sdlib):
+    """On a box without a GPU every compute entry point fails loudly (RuntimeError), it never
+    computes on the host."""
+    if sdlib.sd_device_count() > 0:
+        pytest.skip("a GPU is visible: the loud-failure path is exercised on CPU-only boxes")
+    q = np.zeros((1, 64, 1, 64), np.float16)
+    with pytest.raises(RuntimeError):
+        _lib.attention("ORIGINAL", q, q, q, 1, 64)
+    with pytest.raises(RuntimeError):
+        hip_model.HipModel(dict(block_out_channels=(32, 64), down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
+                                up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"), layers_per_block=1,
+                                attention_head_dim=(2, 4), cross_attention_dim=48, sample_size=8), weights={})
+
+
+def test_argument_validation_happens_before_any_device_work():
+    with pytest.raises(ValueError):
+        _lib.attention("FLASH", np.zeros((1, 64, 1, 8), np.float16), np.zeros((1, 64, 1, 8), np.float16),
+                       np.zeros((1, 64, 1, 8), np.float16), 1, 64)
+    with pytest.raises(ValueError):
+        hip_model.HipModel("stabilityai/stable-diffusion-2-1-base", weights={}, attention_implementation="FAST")

@@ -1,0 +1,220 @@
+"""GPU parity tests of the individual kernels, called through the C ABI (sd_op_*), against the
+oracle on the same seeded inputs.  Tolerances (fp16 I/O, fp32 accumulate):
+  * PSNR (reference formula, torch2coreml.py:59-74) >= 60 dB  [reference floor: 35 dB]
+  * max |err| <= 4e-3 * max|ref| + 1e-3
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+from oracle import attention_ref, psnr, unet_ref
+from python_hip_stable_diffusion import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def close(got, ref, what, min_psnr=60.0, rel=4e-3):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert np.isfinite(got).all(), what
+    p = psnr.compute_psnr(got, ref)
+    err = np.abs(got - ref).max()
+    bound = rel * np.abs(ref).max() + 1e-3
+    assert p >= min_psnr and err <= bound, f"{what}: PSNR {p:.1f} dB, max|err| {err:.3e} (bound {bound:.3e})"
+
+
+def h16(a):
+    return np.asarray(a, np.float32).astype(np.float16)
+
+
+def test_hardware_layout_selftest(sdlib):
+    assert sdlib.sd_device_count() >= 1
+    assert sdlib.sd_selftest_mfma() == 0, "MFMA / DPP lane layout differs from what the kernels assume"
+
+
+# ------------------------------------------------------------------ attention
+IMPLS = ["ORIGINAL", "SPLIT_EINSUM", "SPLIT_EINSUM_V2"]
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_attention_reference_golden(impl):
+    g = load_golden("attention_golden.npz")
+    for c in sorted({k.split("_")[0] for k in g}):
+        b, h, d, sq, sk = (int(v) for v in g[f"{c}_meta"])
+        q, k, v = h16(g[f"{c}_q"]), h16(g[f"{c}_k"]), h16(g[f"{c}_v"])
+        out, _ = _lib.attention(impl, q, k, v, h, d)
+        ref = attention_ref.IMPLS[impl](q.astype(np.float32), k.astype(np.float32), v.astype(np.float32), h, d)
+        close(out, ref, f"{impl} golden {c}")
+        close(out, g[f"{c}_out"], f"{impl} golden {c} (stored reference output)", min_psnr=55)
+
+
+SHAPES = [  # (B, heads, d, Sq, Sk)
+    (2, 5, 64, 1024, 1024), (2, 5, 64, 1024, 77), (1, 10, 64, 256, 256), (2, 20, 64, 64, 77), (1, 20, 64, 64, 64),
+    (1, 2, 64, 4096, 4096), (1, 2, 64, 4096, 77),
+    (1, 8, 40, 256, 77), (1, 8, 80, 256, 256), (1, 2, 160, 64, 64), (1, 2, 160, 64, 77),   # SD1.5 head dims
+    (1, 2, 16, 64, 64), (1, 4, 16, 16, 77), (1, 1, 32, 100, 50),                              # ragged / tiny
+    (1, 1, 64, 1, 1), (1, 1, 64, 33, 65), (1, 3, 64, 127, 129),
+]
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_attention_matches_oracle(impl, shape):
+    b, h, d, sq, sk = shape
+    rs = np.random.RandomState(hash(shape) % (2 ** 31))
+    q, k, v = (h16(rs.randn(b, h * d, 1, n)) for n in (sq, sk, sk))
+    if impl == "SPLIT_EINSUM_V2" and sq >= 512 and sq % 512:
+        with pytest.raises(ValueError):
+            _lib.attention(impl, q, k, v, h, d)
+        return
+    out, _ = _lib.attention(impl, q, k, v, h, d)
+    ref = attention_ref.IMPLS[impl](q.astype(np.float32), k.astype(np.float32), v.astype(np.float32), h, d)
+    close(out, ref, f"{impl} {shape}")
+
+
+def test_attention_v2_rejects_the_tail_the_reference_drops():
+    q = np.zeros((1, 64, 1, 576), np.float16)
+    k = np.zeros((1, 64, 1, 77), np.float16)
+    with pytest.raises(ValueError, match="512"):
+        _lib.attention("SPLIT_EINSUM_V2", q, k, k, 1, 64)
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_attention_running_max_rescale_branch(impl):
+    """Force the online-softmax rescale: late key tiles carry much larger scores than early ones
+    (a bounded random test never exercises a wrong rescale)."""
+    b, h, d, sq, sk = 1, 2, 64, 512, 512
+    rs = np.random.RandomState(5)
+    q, k, v = (rs.randn(b, h * d, 1, n).astype(np.float32) for n in (sq, sk, sk))
+    k[:, :, :, 300:] *= 6.0          # scores jump after tile 4
+    k[:, :, :, 470] = 3.0 * q[:, :, :, 7]   # one key dominates query 7
+    q, k, v = h16(q), h16(k), h16(v)
+    out, _ = _lib.attention(impl, q, k, v, h, d)
+    ref = attention_ref.original(q.astype(np.float32), k.astype(np.float32), v.astype(np.float32), h, d)
+    close(out, ref, f"{impl} rescale")
+
+
+def test_attention_original_dpp_and_bpermute_variants_agree():
+    rs = np.random.RandomState(3)
+    q, k, v = (h16(rs.randn(1, 128, 1, n)) for n in (256, 200, 200))
+    a, _ = _lib.attention("ORIGINAL", q, k, v, 2, 64, variant=0)
+    b, _ = _lib.attention("ORIGINAL", q, k, v, 2, 64, variant=1)
+    assert np.array_equal(a, b)
+
+
+def test_three_attention_schedules_agree_with_each_other():
+    rs = np.random.RandomState(9)
+    q, k, v = (h16(rs.randn(2, 320, 1, n)) for n in (1024, 1024, 1024))
+    outs = [_lib.attention(i, q, k, v, 5, 64)[0].astype(np.float32) for i in IMPLS]
+    for o in outs[1:]:
+        close(o, outs[0], "cross-schedule", min_psnr=55)
+
+
+# ------------------------------------------------------------------ norms
+def test_layernorm_reference_golden():
+    g = load_golden("layernorm_golden.npz")
+    out, _ = _lib.layernorm(h16(g["x"]), g["w"], g["b"])
+    ref = unet_ref.layer_norm_ane(torch.from_numpy(h16(g["x"]).astype(np.float32)), torch.from_numpy(g["w"]),
+                                  torch.from_numpy(g["b"])).numpy()
+    close(out, ref, "layernorm golden")
+
+
+@pytest.mark.parametrize("shape", [(2, 320, 4096), (2, 640, 1024), (2, 1280, 64), (1, 1536, 40), (3, 32, 7), (1, 8, 1)])
+def test_layernorm_matches_oracle(shape):
+    b, c, s = shape
+    rs = np.random.RandomState(c)
+    x = h16(rs.randn(b, c, 1, s) * 2 + 0.5)
+    w, bb = (1 + 0.2 * rs.randn(c)).astype(np.float32), (0.3 * rs.randn(c)).astype(np.float32)
+    out, _ = _lib.layernorm(x, w, bb)
+    ref = unet_ref.layer_norm_ane(torch.from_numpy(x.astype(np.float32)), torch.from_numpy(w), torch.from_numpy(bb)).numpy()
+    close(out, ref, f"layernorm {shape}")
+
+
+@pytest.mark.parametrize("shape,eps,silu", [((2, 320, 64, 64), 1e-5, True), ((2, 320, 32, 32), 1e-6, False),
+                                            ((2, 1920, 16, 16), 1e-5, True), ((2, 2560, 8, 8), 1e-5, True),
+                                            ((1, 64, 5, 3), 1e-5, True), ((2, 32, 8, 8), 1e-6, False),
+                                            ((1, 960, 17, 9), 1e-5, True)])
+def test_groupnorm_matches_torch(shape, eps, silu):
+    b, c, hh, ww = shape
+    rs = np.random.RandomState(c + hh)
+    x = h16(rs.randn(*shape) * 1.5 + 0.3)
+    w, bb = (1 + 0.2 * rs.randn(c)).astype(np.float32), (0.3 * rs.randn(c)).astype(np.float32)
+    out, _ = _lib.groupnorm(x, w, bb, groups=32, eps=eps, silu=silu)
+    ref = F.group_norm(torch.from_numpy(x.astype(np.float32)), 32, torch.from_numpy(w), torch.from_numpy(bb), eps)
+    if silu:
+        ref = F.silu(ref)
+    close(out, ref.numpy(), f"groupnorm {shape}")
+
+
+# ------------------------------------------------------------------ convolutions
+def conv_ref(x, w, bias, res, stride, upsample):
+    xt = torch.from_numpy(x.astype(np.float32))
+    if upsample:
+        xt = F.interpolate(xt, scale_factor=2.0, mode="nearest")        # unet.py:498-500
+    y = F.conv2d(xt, torch.from_numpy(w.astype(np.float32)), None if bias is None else torch.from_numpy(bias),
+                 stride=stride, padding=w.shape[2] // 2)
+    if res is not None:
+        y = y + torch.from_numpy(res.astype(np.float32))
+    return y.numpy()
+
+
+CONVS = [  # (B, Cin, H, W, Cout, k, stride, upsample, bias, res)
+    (2, 320, 32, 32, 320, 3, 1, False, True, True), (2, 64, 16, 16, 128, 3, 1, False, True, False),
+    (2, 128, 16, 16, 128, 3, 2, False, True, False), (1, 128, 8, 8, 64, 3, 1, True, True, False),
+    (2, 640, 16, 16, 320, 1, 1, False, True, True), (2, 320, 8, 8, 1280, 1, 1, False, False, False),
+    (1, 64, 7, 5, 64, 3, 1, False, True, True), (1, 64, 7, 5, 64, 3, 2, False, False, False),
+    (1, 64, 3, 3, 192, 3, 1, True, True, False), (2, 1280, 8, 8, 1280, 3, 1, False, True, True),
+    (1, 1024, 1, 77, 320, 1, 1, False, False, False),
+    (2, 4, 16, 16, 64, 3, 1, False, True, False), (2, 32, 8, 8, 48, 3, 1, False, True, True),      # generic path
+    (1, 64, 8, 8, 3, 3, 1, False, True, False), (1, 3, 32, 32, 16, 3, 2, False, True, False),
+]
+
+
+@pytest.mark.parametrize("case", CONVS, ids=lambda c: "-".join(map(str, c)))
+def test_conv2d_matches_torch(case):
+    b, cin, hh, ww, cout, k, stride, ups, has_bias, has_res = case
+    rs = np.random.RandomState(cin * 7 + cout)
+    x = h16(rs.randn(b, cin, hh, ww))
+    w = h16(rs.randn(cout, cin, k, k) / np.sqrt(cin * k * k))
+    bias = (0.1 * rs.randn(cout)).astype(np.float32) if has_bias else None
+    up = 2 if ups else 1
+    ho, wo = (hh * up + 2 * (k // 2) - k) // stride + 1, (ww * up + 2 * (k // 2) - k) // stride + 1
+    res = h16(rs.randn(b, cout, ho, wo)) if has_res else None
+    out, _ = _lib.conv2d(x, w, bias, res, stride=stride, upsample=ups)
+    close(out, conv_ref(x, w, bias, res, stride, ups), f"conv {case}")
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("splitk", [1, 2, 5])
+def test_conv2d_every_tile_and_splitk(tile, splitk):
+    rs = np.random.RandomState(tile * 10 + splitk)
+    x = h16(rs.randn(2, 192, 9, 11))          # M = 198: not a multiple of any tile
+    w = h16(rs.randn(100, 192, 3, 3) / 40)    # N = 100: ragged n-tile
+    bias = (0.1 * rs.randn(100)).astype(np.float32)
+    res = h16(rs.randn(2, 100, 9, 11))
+    out, _ = _lib.conv2d(x, w, bias, res, tile=tile, splitk=splitk)
+    close(out, conv_ref(x, w, bias, res, 1, False), f"conv tile {tile} splitk {splitk}")
+    gen, _ = _lib.conv2d(x, w, bias, res, force_generic=True)
+    close(gen, conv_ref(x, w, bias, res, 1, False), "generic conv")
+
+
+@pytest.mark.parametrize("m,c", [(512, 320), (77, 64), (128, 1280), (40, 32)])
+def test_geglu_matches_oracle(m, c):
+    rs = np.random.RandomState(m + c)
+    x = h16(rs.randn(m, c))
+    w = h16(rs.randn(8 * c, c) / np.sqrt(c))
+    bias = (0.1 * rs.randn(8 * c)).astype(np.float32)
+    out, _ = _lib.geglu(x, w, bias)
+    hcat = torch.from_numpy(x.astype(np.float32)) @ torch.from_numpy(w.astype(np.float32)).T + torch.from_numpy(bias)
+    val, gate = hcat.chunk(2, dim=1)                                   # unet.py:616-617
+    close(out, (val * F.gelu(gate)).numpy(), f"geglu {m}x{c}")
+
+
+def test_timestep_embedding_reference_golden():
+    g = load_golden("timestep_golden.npz")
+    out = _lib.timestep_embedding(g["t"], 320)
+    np.testing.assert_allclose(out, g["out"], atol=2e-5)
+    ts = np.array([951, 901, 1, 999, 0], np.float32)
+    np.testing.assert_allclose(_lib.timestep_embedding(ts, 256), unet_ref.timestep_embedding(torch.from_numpy(ts), 256).numpy(), atol=2e-5)

@@ -1,0 +1,125 @@
+"""CPU suite: the oracle against the golden vectors written by oracle/pin_against_reference.py
+(which compared it with the real reference modules) and against the reference's own
+known-answer tests (numpy RNG golden of swift/StableDiffusionTests/StableDiffusionTests.swift:52-62)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import attention_ref, psnr, rng_ref, scheduler_ref, unet_ref, weights
+
+
+def test_attention_oracle_matches_reference_golden():
+    g = load_golden("attention_golden.npz")
+    cases = sorted({k.split("_")[0] for k in g})
+    assert cases
+    for c in cases:
+        b, h, d, sq, sk = g[f"{c}_meta"]
+        for impl, fn in attention_ref.IMPLS.items():
+            out = fn(g[f"{c}_q"], g[f"{c}_k"], g[f"{c}_v"], int(h), int(d))
+            assert out.shape == (b, h * d, 1, sq)
+            np.testing.assert_allclose(out, g[f"{c}_out"], atol=2e-6, rtol=0, err_msg=f"{c} {impl}")
+
+
+def test_split_einsum_v2_rejects_tail_instead_of_dropping_it():
+    q = np.zeros((1, 64, 1, 576), np.float32)
+    k = np.zeros((1, 64, 1, 77), np.float32)
+    with pytest.raises(ValueError):
+        attention_ref.split_einsum_v2(q, k, k, 1, 64)
+    # < 512 falls back to SPLIT_EINSUM (attention.py:88-92)
+    q = np.random.RandomState(0).randn(1, 64, 1, 96).astype(np.float32)
+    k = np.random.RandomState(1).randn(1, 64, 1, 77).astype(np.float32)
+    np.testing.assert_allclose(attention_ref.split_einsum_v2(q, k, k, 1, 64), attention_ref.split_einsum(q, k, k, 1, 64))
+
+
+def test_layernorm_oracle_matches_reference_golden():
+    g = load_golden("layernorm_golden.npz")
+    out = unet_ref.layer_norm_ane(torch.from_numpy(g["x"]), torch.from_numpy(g["w"]), torch.from_numpy(g["b"])).numpy()
+    np.testing.assert_allclose(out, g["out"], atol=2e-6)
+
+
+def test_timestep_embedding_oracle_matches_reference_golden():
+    g = load_golden("timestep_golden.npz")
+    out = unet_ref.timestep_embedding(torch.from_numpy(g["t"]), 320).numpy()
+    np.testing.assert_array_equal(out, g["out"])
+    half = 160     # [cos | sin] order (unet.py:721-724)
+    np.testing.assert_allclose(out[:, 0], np.cos(g["t"]), atol=1e-4)
+    np.testing.assert_allclose(out[:, half], np.sin(g["t"]), atol=1e-4)
+
+
+def _run_unet_golden(name):
+    g = load_golden(f"unet_{name}_golden.npz")
+    cfg = unet_ref.CONFIGS[name]
+    shapes = unet_ref.unet_param_shapes(cfg)
+    assert sum(int(np.prod(s)) for s in shapes.values()) == int(g["n_params"])
+    sd = weights.to_torch(weights.round_to_fp16(weights.make_state_dict(shapes, seed=int(g["seed"]))))
+    kw = {}
+    if "time_ids" in g:
+        kw = dict(time_ids=torch.from_numpy(g["time_ids"]), text_embeds=torch.from_numpy(g["text_embeds"]))
+    if cfg["support_controlnet"]:
+        n = len(unet_ref.residual_shapes(cfg, 2))
+        kw["additional_residuals"] = [torch.from_numpy(g[f"additional_residual_{i}"].astype(np.float32)) for i in range(n)]
+    out = unet_ref.unet_forward(sd, cfg, torch.from_numpy(g["sample"].astype(np.float32)), torch.from_numpy(g["timestep"]),
+                                torch.from_numpy(g["encoder_hidden_states"].astype(np.float32)), **kw).numpy()
+    return out, g["noise_pred"]
+
+
+@pytest.mark.parametrize("name", ["tiny", "mini", "mini-xl", "mini-control"])
+def test_unet_oracle_matches_reference_golden(name):
+    out, ref = _run_unet_golden(name)
+    assert np.abs(out - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    assert psnr.compute_psnr(out, ref) > 100
+
+
+def test_controlnet_oracle_matches_reference_golden():
+    g = load_golden("controlnet_mini_golden.npz")
+    cfg = unet_ref.CONFIGS["mini-control"]
+    sd = weights.to_torch(weights.round_to_fp16(weights.make_state_dict(unet_ref.controlnet_param_shapes(cfg), seed=int(g["seed"]))))
+    res = unet_ref.controlnet_forward(sd, cfg, torch.from_numpy(g["sample"].astype(np.float32)), torch.from_numpy(g["timestep"]),
+                                      torch.from_numpy(g["encoder_hidden_states"].astype(np.float32)),
+                                      torch.from_numpy(g["controlnet_cond"].astype(np.float32)))
+    assert len(res) == 13
+    for i, r in enumerate(res):
+        np.testing.assert_allclose(r.numpy(), g[f"additional_residual_{i}"], atol=3e-5)
+
+
+def test_parameter_count_of_the_baseline_model():
+    n = sum(int(np.prod(s)) for s in unet_ref.unet_param_shapes(unet_ref.CONFIGS["sd21-base"]).values())
+    assert n == 865_910_724          # SURVEY.md / BASELINE.md: 865.91 M
+    assert len(unet_ref.residual_shapes(unet_ref.CONFIGS["sd15-control"], 2)) == 13   # controlnet.py:191-197
+
+
+def test_numpy_rng_restatement_matches_swift_golden_and_numpy():
+    r = rng_ref.NumpyLegacyRandom(rng_ref.GOLDEN_SEED).randn(rng_ref.GOLDEN_COUNT)
+    np.testing.assert_allclose(r[-5:], rng_ref.GOLDEN_LAST5, atol=1e-8)
+    np.random.seed(rng_ref.GOLDEN_SEED)
+    assert np.array_equal(np.array(r), np.random.randn(rng_ref.GOLDEN_COUNT))
+
+
+def test_psnr_matches_reference_formula():
+    b = np.array([1.0, -2.0, 0.5])
+    a = b + np.array([0.01, -0.01, 0.0])
+    want = 20 * np.log10((2.0 + 1e-5) / (np.sqrt(2e-4 / 3) + 1e-10))
+    assert abs(psnr.compute_psnr(a, b) - want) < 1e-9
+    assert psnr.ABSOLUTE_MIN_PSNR == 35
+
+
+def test_ddim_schedule_and_step_algebra():
+    s = scheduler_ref.DDIM()
+    ts = s.set_timesteps(20)
+    assert list(ts[:3]) == [951, 901, 851] and ts[-1] == 1
+    rs = np.random.RandomState(0)
+    x, e = rs.randn(4, 8).astype(np.float32), rs.randn(4, 8).astype(np.float32)
+    for t in (951, 1):
+        cx, ce = s.coefficients(int(t))
+        np.testing.assert_allclose(s.step(e, int(t), x), cx * x + ce * e, rtol=2e-5, atol=2e-6)
+
+
+def test_pndm_schedule_matches_swift_restatement():
+    s = scheduler_ref.PNDM()
+    ts = s.set_timesteps(50)
+    assert len(ts) == 51 and ts[0] == 981 and ts[1] == 961 and ts[2] == 961 and ts[-1] == 1
+    x = np.ones((2, 3), np.float32)
+    for t in ts[:6]:
+        x = s.step(0.1 * np.ones_like(x), int(t), x)
+    assert np.isfinite(x).all()
