@@ -246,10 +246,9 @@ int sd_op_groupnorm(const void* x, const float* weight, const float* bias, void*
     half_t* dy = sc.dev<half_t>(xt.size());
     float* dw = sc.dev<float>(C, weight);
     float* db = sc.dev<float>(C, bias);
-    float* st = sc.dev<float>((size_t)B * groups * 2);
     float* partial = sc.dev<float>(groupnorm_scratch_floats(B, H * W, groups));
     sc.timed(iters, ms, [&] {
-      launch_groupnorm(dx, C, nullptr, 0, partial, st, dw, db, dy, B, H * W, groups, eps, silu, sc.stream);
+      launch_groupnorm(dx, C, nullptr, 0, partial, dw, db, dy, B, H * W, groups, eps, silu, sc.stream);
     });
     SD_HIP(hipMemcpy(xt.data(), dy, xt.size() * 2, hipMemcpyDeviceToHost));
     nhwc_to_nchw(xt.data(), reinterpret_cast<half_t*>(out), B, C, H, W);
@@ -288,7 +287,8 @@ int sd_op_conv2d(const void* x, const void* w, const float* bias, const void* re
     d.out = dout;
     d.B = B; d.Hi = H; d.Wi = W; d.Ho = Ho; d.Wo = Wo;
     d.ksize = ksize; d.stride = stride; d.up = up; d.N = Cout;
-    d.tile = tile;
+    d.tile = tile % 10;          // tile >= 10: register-staged A/B variant of the same tile
+    d.reg_staging = tile >= 10;
     d.splitk = splitk;
     const bool fast = !force_generic && conv_fast_path_ok(d);
     ConvWorkspace ws;
@@ -353,7 +353,9 @@ int sd_op_timestep_embedding(const float* t, float* out, int n, int dim, int fli
     Scratch sc;
     float* dt = sc.dev<float>(n, t);
     float* dout = sc.dev<float>((size_t)n * dim);
-    launch_timestep_embedding(dt, dout, n, dim, freq_shift, sc.stream);
+    std::vector<float> f = timestep_freq_table(dim, freq_shift);
+    float* df = sc.dev<float>(f.size(), f.data());
+    launch_timestep_embedding(dt, df, dout, n, dim, sc.stream);
     SD_HIP(hipStreamSynchronize(sc.stream));
     SD_HIP(hipMemcpy(out, dout, (size_t)n * dim * sizeof(float), hipMemcpyDeviceToHost));
   });

@@ -43,22 +43,31 @@ struct IgemmArgs {
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
+// 16 bytes of zeros: source of every out-of-image (padding) / out-of-range lane of the LDS-DMA loader
+__device__ __attribute__((aligned(16))) half_t g_zero_chunk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
 // One 256-thread workgroup = 4 wavefronts laid out WGM x WGN over a BM x BN tile.
-template <int BM, int BN, int WGM, int WGN, bool TRANS_OUT>
+// GLDS = true: tiles go HBM -> LDS directly (global_load_lds_dwordx4, no VGPR round trip and no
+// ds_write pass: the write pass was ~60 % of the LDS-pipe time of the register-staged version).
+// The DMA writes lane-linear 1-KiB pieces (8 rows x 128 B), so the bank swizzle lives on the
+// per-lane SOURCE address: physical 16-B chunk p of row r holds logical chunk p ^ ((r >> 1) & 7),
+// and fragment reads apply the same XOR (conflict-free ds_read_b128, cdna guide rule 21).
+template <int BM, int BN, int WGM, int WGN, bool TRANS_OUT, bool GLDS>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   static_assert(WGM * WGN == 4, "4 waves");
   constexpr int TM = BM / WGM / 32;   // 32x32 MFMA tiles per wave along m
   constexpr int TN = BN / WGN / 32;
   constexpr int XR = BM / 32;         // 16-B chunks each thread stages per K step (X tile)
   constexpr int WR = BN / 32;
+  constexpr int ROW = GLDS ? BK : LDS_ROW;   // LDS row stride in halves
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  half_t* Xs = reinterpret_cast<half_t*>(smem);                 // [2][BM][LDS_ROW]
-  half_t* Ws = Xs + 2 * BM * LDS_ROW;                           // [2][BN][LDS_ROW]
+  half_t* Xs = reinterpret_cast<half_t*>(smem);                 // [2][BM][ROW]
+  half_t* Ws = Xs + 2 * BM * ROW;                               // [2][BN][ROW]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (LDS-DMA base -> M0)
   const int wm = wave / WGN, wn = wave % WGN;
 
   // XCD-aware tile order: the dispatcher round-robins consecutive block ids over the 8 XCDs
@@ -81,8 +90,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   if (kt_end > a.nk_total) kt_end = a.nk_total;
 
   // ---- per-thread staging coordinates (loop invariant) ----
-  const int chunk = tid & 7;        // which 16-B piece of the 128-B K row
-  const int lrow = tid >> 3;        // 0..31
+  const int pchunk = tid & 7;       // physical 16-B slot of the 128-B K row this thread fills
+  const int lrow = tid >> 3;        // 0..31  (= wave * 8 + lane / 8)
   int x_pix[XR];                    // b*Hi*Wi (or -1 when the row is past M)
   int x_iy0[XR], x_ix0[XR];
 #pragma unroll
@@ -104,14 +113,40 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   }
   const int Hup = a.Hi * a.up, Wup = a.Wi * a.up;
   const int upshift = a.up >> 1;    // up in {1,2}
+  // logical chunk this thread fetches for its rows: rows lrow+32*i share (row >> 1) & 7 == (lrow >> 1) & 7
+  const int chunk = GLDS ? (pchunk ^ ((lrow >> 1) & 7)) : pchunk;
 
-  half8 xr[XR], wr[WR];
+  half8 xr[GLDS ? 1 : XR], wr[GLDS ? 1 : WR];
   const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-  auto load_tile = [&](int kt) {
+  // K-tile iterator: tiles are visited in order, so (tap, channel offset) advance incrementally and
+  // the per-row source pixel (the expensive part of the im2col address) is recomputed only when
+  // the 3x3 tap changes (every Ctot/64 tiles), not every tile.
+  int it_tap = (kt_begin * BK) / a.Ctot;
+  int it_cc = kt_begin * BK - it_tap * a.Ctot;
+  int pix_tap = -1;
+  int x_src_pix[XR];                // source pixel index of row i for tap pix_tap, -1 = zero padding
+  const half_t* wrow[WR];           // this thread's weight rows (nullptr past N)
+#pragma unroll
+  for (int i = 0; i < WR; ++i) {
+    int n = n_blk + lrow + 32 * i;
+    wrow[i] = (n < a.N) ? a.w + (size_t)n * a.K + chunk * 8 : nullptr;
+  }
+
+  auto load_tile = [&](int kt, int stage) {
     const int k0 = kt * BK;
-    const int tap = k0 / a.Ctot;
-    int cc = k0 - tap * a.Ctot;
+    if (it_tap != pix_tap) {          // wave-uniform
+      pix_tap = it_tap;
+      const int ky = (a.ksize == 3) ? it_tap / 3 : 0;
+      const int kx = (a.ksize == 3) ? it_tap - ky * 3 : 0;
+#pragma unroll
+      for (int i = 0; i < XR; ++i) {
+        int iy = x_iy0[i] + ky, ix = x_ix0[i] + kx;
+        bool ok = (x_pix[i] >= 0) && (iy >= 0) && (iy < Hup) && (ix >= 0) && (ix < Wup);
+        x_src_pix[i] = ok ? x_pix[i] + (iy >> upshift) * a.Wi + (ix >> upshift) : -1;
+      }
+    }
+    int cc = it_cc;
     const half_t* src = a.x0;
     int Csrc = a.C0;
     if (cc >= a.C0) {
@@ -119,32 +154,46 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
       cc -= a.C0;
       Csrc = a.C1;
     }
-    const int ky = (a.ksize == 3) ? tap / 3 : 0;
-    const int kx = (a.ksize == 3) ? tap - ky * 3 : 0;
-#pragma unroll
-    for (int i = 0; i < XR; ++i) {
-      int iy = x_iy0[i] + ky, ix = x_ix0[i] + kx;
-      bool ok = (x_pix[i] >= 0) && (iy >= 0) && (iy < Hup) && (ix >= 0) && (ix < Wup);
-      int sy = iy >> upshift, sx = ix >> upshift;
-      size_t off = ((size_t)(x_pix[i] + sy * a.Wi + sx)) * Csrc + cc + chunk * 8;
-      xr[i] = ok ? *reinterpret_cast<const half8*>(src + off) : zero8;
+    src += cc + chunk * 8;
+    it_cc += BK;                      // advance the iterator for the next call
+    if (it_cc >= a.Ctot) {
+      it_cc = 0;
+      ++it_tap;
     }
+    if constexpr (GLDS) {
+      char* xs = reinterpret_cast<char*>(Xs + stage * BM * ROW) + wave * 1024;   // wave-uniform piece base
+      char* ws = reinterpret_cast<char*>(Ws + stage * BN * ROW) + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < WR; ++i) {
-      int n = n_blk + lrow + 32 * i;
-      size_t off = (size_t)n * a.K + k0 + chunk * 8;
-      wr[i] = (n < a.N) ? *reinterpret_cast<const half8*>(a.w + off) : zero8;
+      for (int i = 0; i < XR; ++i) {
+        const half_t* p = (x_src_pix[i] >= 0) ? src + (size_t)x_src_pix[i] * Csrc : g_zero_chunk;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                         (__attribute__((address_space(3))) void*)(xs + i * 4096), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < WR; ++i) {
+        const half_t* p = wrow[i] ? wrow[i] + k0 : g_zero_chunk;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                         (__attribute__((address_space(3))) void*)(ws + i * 4096), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < XR; ++i)
+        xr[i] = (x_src_pix[i] >= 0) ? *reinterpret_cast<const half8*>(src + (size_t)x_src_pix[i] * Csrc) : zero8;
+#pragma unroll
+      for (int i = 0; i < WR; ++i) wr[i] = wrow[i] ? *reinterpret_cast<const half8*>(wrow[i] + k0) : zero8;
     }
   };
-  auto store_tile = [&](int buf) {
-    half_t* xs = Xs + buf * BM * LDS_ROW;
-    half_t* ws = Ws + buf * BN * LDS_ROW;
+  auto store_tile = [&](int buf) {   // register-staged variant only
+    if constexpr (!GLDS) {
+      half_t* xs = Xs + buf * BM * ROW;
+      half_t* ws = Ws + buf * BN * ROW;
 #pragma unroll
-    for (int i = 0; i < XR; ++i)
-      *reinterpret_cast<half8*>(xs + (lrow + 32 * i) * LDS_ROW + chunk * 8) = xr[i];
+      for (int i = 0; i < XR; ++i)
+        *reinterpret_cast<half8*>(xs + (lrow + 32 * i) * ROW + chunk * 8) = xr[i];
 #pragma unroll
-    for (int i = 0; i < WR; ++i)
-      *reinterpret_cast<half8*>(ws + (lrow + 32 * i) * LDS_ROW + chunk * 8) = wr[i];
+      for (int i = 0; i < WR; ++i)
+        *reinterpret_cast<half8*>(ws + (lrow + 32 * i) * ROW + chunk * 8) = wr[i];
+    }
   };
 
   floatx16 acc[TM][TN];
@@ -157,27 +206,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
 
   const int frow = lane & 31;           // fragment row (m or n within the 32-tile)
   const int fk = (lane >> 5) * 8;       // k offset of this half-wave inside a 16-deep MFMA step
+  const int fsw = (frow >> 1) & 7;      // GLDS: swizzle of this lane's fragment rows (tile bases are multiples of 32)
 
-  if (kt_begin < kt_end) {
-    load_tile(kt_begin);
-    store_tile(0);
-  }
-  __syncthreads();
-
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int buf = (kt - kt_begin) & 1;
-    const bool more = (kt + 1) < kt_end;
-    if (more) load_tile(kt + 1);        // HBM/L2 latency hides under this tile's MFMAs
-
-    const half_t* xs = Xs + buf * BM * LDS_ROW + (wm * TM * 32 + frow) * LDS_ROW + fk;
-    const half_t* ws = Ws + buf * BN * LDS_ROW + (wn * TN * 32 + frow) * LDS_ROW + fk;
+  auto compute = [&](int buf) {
+    const half_t* xs = Xs + buf * BM * ROW + (wm * TM * 32 + frow) * ROW;
+    const half_t* ws = Ws + buf * BN * ROW + (wn * TN * 32 + frow) * ROW;
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
+      const int koff = GLDS ? (((kk * 2 + (lane >> 5)) ^ fsw) * 8) : (kk * 16 + fk);
       half8 xf[TM], wf[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const half8*>(xs + i * 32 * LDS_ROW + kk * 16);
+      for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const half8*>(xs + i * 32 * ROW + koff);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const half8*>(ws + j * 32 * LDS_ROW + kk * 16);
+      for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const half8*>(ws + j * 32 * ROW + koff);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -188,8 +229,32 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
         }
     }
-    if (more) store_tile(buf ^ 1);
+  };
+
+  if constexpr (GLDS) {
+    if (kt_begin < kt_end) load_tile(kt_begin, 0);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const int buf = (kt - kt_begin) & 1;
+      // vmcnt(0) + barrier: this tile's DMA has landed for every wave, and every wave is done
+      // reading the other stage, which the next DMA may now overwrite
+      __syncthreads();
+      if (kt + 1 < kt_end) load_tile(kt + 1, buf ^ 1);
+      compute(buf);
+    }
+  } else {
+    if (kt_begin < kt_end) {
+      load_tile(kt_begin, 0);
+      store_tile(0);
+    }
     __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const int buf = (kt - kt_begin) & 1;
+      const bool more = (kt + 1) < kt_end;
+      if (more) load_tile(kt + 1, 0);     // HBM/L2 latency hides under this tile's MFMAs
+      compute(buf);
+      if (more) store_tile(buf ^ 1);
+      __syncthreads();
+    }
   }
 
   // ---------------------------------- epilogue ----------------------------------
@@ -477,56 +542,87 @@ void tile_dims(int tile, int& bm, int& bn) {
   }
 }
 
-// Heuristic: keep >= ~2 workgroups per CU in flight (256 CUs); prefer the big tile when the
-// grid is already full, split K when M is small and K is deep (8x8 / 16x16 levels stream
-// weights: SURVEY.md 7.3(1)).
+// Heuristic (overridden per shape by the measured table in tuned_convs.inc when present):
+// prefer the biggest tile whose grid, multiplied by the split-K it can afford (>= 8 K-tiles per
+// split), still gives every CU work (>= ~1.5 workgroups per CU); deep-K small-M layers (8x8 /
+// 16x16 levels stream weights: SURVEY.md 7.3(1)) end up split, shallow 1x1 GEMMs end up on the
+// small tile with many workgroups.
+struct TunedConv { int ksize, stride, up, ctot, n, m, tile, splitk; };
+#if __has_include("tuned_convs.inc")
+static const TunedConv kTuned[] = {
+#include "tuned_convs.inc"
+};
+static const int kNumTuned = sizeof(kTuned) / sizeof(kTuned[0]);
+#else
+static const TunedConv* kTuned = nullptr;
+static const int kNumTuned = 0;
+#endif
+
 Plan choose_plan(const ConvDesc& d, const IgemmArgs& a) {
   Plan p{d.tile, d.splitk};
   const bool geglu = d.out_mode == kOutGeglu;
+  const bool can_split = d.out_mode == kOutHalf;
   auto blocks_of = [&](int c) {
     int bm, bn;
     tile_dims(c, bm, bn);
     return (long)cdiv(a.M, bm) * cdiv(a.N, bn);
   };
-  if (p.tile == 0) {
-    if (geglu) {                      // GEGLU value/gate pairs need 64 n-columns per wave
-      p.tile = blocks_of(1) >= 256 ? 1 : 4;
-    } else {
-      p.tile = 3;
-      for (int c : {1, 2, 4}) {
-        if (blocks_of(c) >= 448) { p.tile = c; break; }
+  auto max_split = [&]() {
+    int s = 1;
+    while (can_split && s < 16 && a.nk_total / (s * 2) >= 8) s *= 2;
+    return s;
+  };
+  if (p.tile == 0 && p.splitk == 0 && can_split) {
+    for (int i = 0; i < kNumTuned; ++i) {
+      const TunedConv& t = kTuned[i];
+      if (t.ksize == a.ksize && t.stride == a.stride && t.up == a.up && t.ctot == a.Ctot && t.n == a.N && t.m == a.M) {
+        p.tile = t.tile;
+        p.splitk = t.splitk;
+        break;
       }
     }
+  }
+  if (p.tile == 0) {
+    const int ms = max_split();
+    p.tile = 3;
+    for (int c : {1, 2, 4, 3}) {
+      if (geglu && c != 1 && c != 4) continue;   // GEGLU value/gate pairs need 64 n-columns per wave
+      if (blocks_of(c) * ms >= 384 || c == 3) { p.tile = c; break; }
+    }
+    if (geglu && p.tile == 3) p.tile = 4;
   }
   if (geglu && p.tile != 1 && p.tile != 4) p.tile = 4;
   if (p.splitk == 0) {
     p.splitk = 1;
-    if (d.out_mode == kOutHalf) {
-      int bm, bn;
-      tile_dims(p.tile, bm, bn);
-      long blocks = (long)cdiv(a.M, bm) * cdiv(a.N, bn);
-      while (blocks * p.splitk < 384 && p.splitk < 16 && a.nk_total / (p.splitk * 2) >= 4) p.splitk *= 2;
-    }
+    const int ms = max_split();
+    while (blocks_of(p.tile) * p.splitk < 384 && p.splitk < ms) p.splitk *= 2;
   }
-  if (d.out_mode != kOutHalf) p.splitk = 1;
+  if (!can_split) p.splitk = 1;
   if (p.splitk > a.nk_total) p.splitk = a.nk_total;
   return p;
 }
 
-template <int BM, int BN, int WGM, int WGN>
-void launch_tile(const IgemmArgs& a, bool trans, hipStream_t s) {
-  const size_t lds = (size_t)2 * (BM + BN) * LDS_ROW * sizeof(half_t);
+template <int BM, int BN, int WGM, int WGN, bool TRANS, bool GLDS>
+void launch_variant(const IgemmArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)2 * (BM + BN) * (GLDS ? BK : LDS_ROW) * sizeof(half_t);
   dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), a.splitk);
+  auto k = igemm_kernel<BM, BN, WGM, WGN, TRANS, GLDS>;
+  static bool attr = false;
+  if (!attr) {
+    SD_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+}
+
+template <int BM, int BN, int WGM, int WGN>
+void launch_tile(const IgemmArgs& a, bool trans, bool glds, hipStream_t s) {
   if (trans) {
-    auto k = igemm_kernel<BM, BN, WGM, WGN, true>;
-    static bool attr = false;
-    if (!attr) { SD_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+    if (glds) launch_variant<BM, BN, WGM, WGN, true, true>(a, s);
+    else launch_variant<BM, BN, WGM, WGN, true, false>(a, s);
   } else {
-    auto k = igemm_kernel<BM, BN, WGM, WGN, false>;
-    static bool attr = false;
-    if (!attr) { SD_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+    if (glds) launch_variant<BM, BN, WGM, WGN, false, true>(a, s);
+    else launch_variant<BM, BN, WGM, WGN, false, false>(a, s);
   }
 }
 
@@ -564,11 +660,12 @@ void launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
     a.partial = ws.partial;
   }
   const bool trans = d.out_mode == kOutHalfT;
+  const bool glds = !d.reg_staging;
   switch (p.tile) {
-    case 1: launch_tile<128, 128, 2, 2>(a, trans, s); break;
-    case 2: launch_tile<128, 64, 2, 2>(a, trans, s); break;
-    case 3: launch_tile<64, 64, 2, 2>(a, trans, s); break;
-    default: launch_tile<64, 128, 2, 2>(a, trans, s); break;
+    case 1: launch_tile<128, 128, 2, 2>(a, trans, glds, s); break;
+    case 2: launch_tile<128, 64, 2, 2>(a, trans, glds, s); break;
+    case 3: launch_tile<64, 64, 2, 2>(a, trans, glds, s); break;
+    default: launch_tile<64, 128, 2, 2>(a, trans, glds, s); break;
   }
   if (a.splitk > 1) {
     size_t total4 = (size_t)a.M * a.N / 4;

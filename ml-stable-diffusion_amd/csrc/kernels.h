@@ -35,6 +35,7 @@ struct ConvDesc {
   // tuning overrides (0 = heuristic)
   int tile = 0;                 // 1: 128x128  2: 128x64  3: 64x64 4: 64x128
   int splitk = 0;
+  int reg_staging = 0;           // 1: HBM->VGPR->LDS staging instead of LDS-DMA (A/B testing)
 };
 
 struct ConvWorkspace {
@@ -80,18 +81,19 @@ bool attention_supported(int d);
 void launch_layernorm(const half_t* x, const float* w, const float* b, half_t* y, int M, int C, float eps,
                       hipStream_t s);
 // GroupNorm over NHWC with optional channel-concat second source: deterministic two-pass
-// statistics (partial: groupnorm_scratch_floats() floats, stats: [B][G][2] = mean, rstd) + apply.
+// statistics (partial: groupnorm_scratch_floats() floats per call) + apply.
 int groupnorm_num_slabs(int B, int HW);
 size_t groupnorm_scratch_floats(int B, int HW, int G);
-void launch_groupnorm(const half_t* x0, int C0, const half_t* x1, int C1, float* partial, float* stats,
-                      const float* gamma, const float* beta, half_t* y, int B, int HW, int G, float eps, int silu,
-                      hipStream_t s);
+void launch_groupnorm(const half_t* x0, int C0, const half_t* x1, int C1, float* partial, const float* gamma,
+                      const float* beta, half_t* y, int B, int HW, int G, float eps, int silu, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // K8/K9 + boundary helpers (misc.hip)
 // ---------------------------------------------------------------------------------------------
-// sinusoidal embedding [cos|sin] (unet.py:703-728), fp32.  t: [n] fp32 -> out [n][dim]
-void launch_timestep_embedding(const float* t, float* out, int n, int dim, float freq_shift, hipStream_t s);
+// sinusoidal embedding [cos|sin] (unet.py:703-728), fp32.  t: [n] fp32, freq: [dim/2] device
+// copy of timestep_freq_table(dim, freq_shift) -> out [n][dim]
+std::vector<float> timestep_freq_table(int dim, float freq_shift);
+void launch_timestep_embedding(const float* t, const float* freq, float* out, int n, int dim, hipStream_t s);
 // out[b][n] = act_out( sum_k W[n][k]*act_in(x[b][k]) + bias[n] ); x fp32 [B][ldx], out fp32 [B][ldo]
 void launch_gemv(const half_t* w, const float* bias, const float* x, int ldx, float* out, int ldo, int B, int N,
                  int K, int silu_in, int silu_out, int accumulate, hipStream_t s);

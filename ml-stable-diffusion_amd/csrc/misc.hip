@@ -1,21 +1,25 @@
 // K8/K9 and boundary helpers: timestep sinusoid, weight-streaming GEMV for the time-embedding
 // MLPs, layout conversions at the 4-channel model boundary, and the device-resident
 // classifier-free-guidance + scheduler step (pipeline.py:500-573 without host round trips).
+#include <cmath>
+
 #include "kernels.h"
 
 namespace sd {
 namespace {
 
-// unet.py:703-728: exponent_i = -ln(10000) * i / (half - freq_shift); arg = float32(t) * exp(.);
-// [sin | cos] flipped to [cos | sin] (flip_sin_to_cos=True).  fp32 throughout (unet.py:719).
-__global__ void timestep_embedding_kernel(const float* __restrict__ t, float* __restrict__ out, int n, int dim,
-                                          float freq_shift) {
+// unet.py:703-728: freq_i = exp(-ln(10000) * i / (half - freq_shift)); arg = float32(t) * freq_i;
+// [sin | cos] flipped to [cos | sin] (flip_sin_to_cos=True).  fp32 throughout (unet.py:719).  The
+// frequency table is computed on the host (correctly rounded float32 of the double value) so the
+// argument t*freq matches the reference's torch.exp table to the last bit wherever torch's own
+// float32 exp is correctly rounded.
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, const float* __restrict__ freq,
+                                          float* __restrict__ out, int n, int dim) {
   const int half = dim / 2;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n * half) return;
   const int row = idx / half, i = idx - row * half;
-  const float exponent = -9.210340371976184f * (float)i / ((float)half - freq_shift);
-  const float arg = t[row] * expf(exponent);
+  const float arg = t[row] * freq[i];
   out[(size_t)row * dim + i] = cosf(arg);
   out[(size_t)row * dim + half + i] = sinf(arg);
 }
@@ -172,9 +176,19 @@ inline int grid_for(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 20
 
 }  // namespace
 
-void launch_timestep_embedding(const float* t, float* out, int n, int dim, float freq_shift, hipStream_t s) {
+std::vector<float> timestep_freq_table(int dim, float freq_shift) {
+  const int half = dim / 2;
+  std::vector<float> f(half);
+  for (int i = 0; i < half; ++i) {
+    const float exponent = (-9.210340371976184f * (float)i) / ((float)half - freq_shift);   // fp32 like torch
+    f[i] = (float)std::exp((double)exponent);
+  }
+  return f;
+}
+
+void launch_timestep_embedding(const float* t, const float* freq, float* out, int n, int dim, hipStream_t s) {
   const int total = n * (dim / 2);
-  hipLaunchKernelGGL(timestep_embedding_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, t, out, n, dim, freq_shift);
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, t, freq, out, n, dim);
   SD_HIP(hipGetLastError());
 }
 

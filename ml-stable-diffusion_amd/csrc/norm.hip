@@ -10,7 +10,7 @@
 //               a strided set, so statistics are a column reduction: each thread owns one 8-channel
 //               chunk column over a slab of pixels; partial (sum, sumsq) are merged per group in LDS
 //               in a fixed order and written per (sample, slab, group) - no atomics, so results are
-//               bitwise reproducible; a tiny second pass folds the slabs.  The apply pass fuses the
+//               bitwise reproducible.  The apply pass folds the slabs in its prologue and fuses the
 //               affine, the optional SiLU (unet.py:473,481) and the channel concat of the up-block
 //               inputs (unet.py:213-216) into a single read-modify-write.
 #include "kernels.h"
@@ -149,53 +149,75 @@ __global__ __launch_bounds__(256) void groupnorm_partial_kernel(const half_t* __
   }
 }
 
-// Pass 2, one thread per (sample, group): fixed-order sum over slabs -> (mean, rstd)
-__global__ void groupnorm_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats, int BG, int G,
-                                          int slabs, float inv_n, float eps) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= BG) return;
-  const int b = i / G, g = i - b * G;
-  float s = 0.f, q = 0.f;
-  for (int k = 0; k < slabs; ++k) {
-    const float* src = partial + (((size_t)b * slabs + k) * G + g) * 2;
-    s += src[0];
-    q += src[1];
-  }
-  const float mean = s * inv_n;
-  const float var = fmaxf(q * inv_n - mean * mean, 0.f);
-  stats[i * 2] = mean;
-  stats[i * 2 + 1] = rsqrtf(var + eps);
-}
-
+// Pass 2, grid (pixel slabs, B): every block first folds the per-slab partials of its sample in a
+// fixed order (4 lanes per group + two shuffles: deterministic), turns them into per-channel
+// scale/shift held in registers, then streams its pixel slab: one 16-B load, 8 FMAs (+SiLU), one
+// 16-B store per thread-iteration.  Fusing the fold here saves a dependent launch per GroupNorm.
 __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const half_t* __restrict__ x0, int C0,
                                                               const half_t* __restrict__ x1, int C1,
-                                                              const float* __restrict__ stats,
+                                                              const float* __restrict__ partial, int slabs,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, half_t* __restrict__ y,
-                                                              int B, int HW, int G, int silu) {
+                                                              int HW, int G, float eps, int silu, int pix_per_block) {
+  __shared__ float s_mean[64], s_rstd[64];
   const int C = C0 + C1;
   const int ncol = C >> 3;
   const int cpg = C / G;
-  const size_t total = (size_t)B * HW * ncol;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (size_t)gridDim.x * blockDim.x) {
-    const int col = (int)(idx % ncol);
-    const size_t pix = idx / ncol;              // b*HW + p
-    const int b = (int)(pix / HW);
+  const int b = blockIdx.y;
+  const int t = threadIdx.x;
+  {
+    const int g = t >> 2, j = t & 3;
+    float s = 0.f, q = 0.f;
+    if (g < G) {
+      for (int k = j; k < slabs; k += 4) {
+        const float* src = partial + (((size_t)b * slabs + k) * G + g) * 2;
+        s += src[0];
+        q += src[1];
+      }
+    }
+    s += __shfl_xor(s, 1);
+    q += __shfl_xor(q, 1);
+    s += __shfl_xor(s, 2);
+    q += __shfl_xor(q, 2);
+    if (g < G && j == 0) {
+      const float inv_n = 1.0f / ((float)cpg * (float)HW);
+      const float mean = s * inv_n;
+      const float var = fmaxf(q * inv_n - mean * mean, 0.f);
+      s_mean[g] = mean;
+      s_rstd[g] = rsqrtf(var + eps);
+    }
+  }
+  __syncthreads();
+  const int p0 = blockIdx.x * pix_per_block;
+  const int p1 = min(p0 + pix_per_block, HW);
+  for (int cb = 0; cb < ncol; cb += 256) {
+    const int cols = min(256, ncol - cb);
+    const int rows = 256 / cols;
+    const int col = cb + t % cols;
+    const int r0 = t / cols;
+    if (r0 >= rows) continue;
     const int c = col * 8;
-    const half8 h = (c < C0) ? *reinterpret_cast<const half8*>(x0 + pix * C0 + c)
-                             : *reinterpret_cast<const half8*>(x1 + pix * C1 + (c - C0));
-    half8 o;
+    float sc[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int g = (c + e) / cpg;
-      const float mean = stats[((size_t)b * G + g) * 2];
-      const float rstd = stats[((size_t)b * G + g) * 2 + 1];
-      float v = ((float)h[e] - mean) * rstd * gamma[c + e] + beta[c + e];
-      if (silu) v = v / (1.0f + __expf(-v));
-      o[e] = (half_t)v;
+      sc[e] = s_rstd[g] * gamma[c + e];
+      sh[e] = beta[c + e] - s_mean[g] * sc[e];
     }
-    *reinterpret_cast<half8*>(y + pix * C + c) = o;
+    const half_t* src = (c < C0) ? x0 + c : x1 + (c - C0);
+    const int Cs = (c < C0) ? C0 : C1;
+    for (int p = p0 + r0; p < p1; p += rows) {
+      const size_t pix = (size_t)b * HW + p;
+      const half8 h = *reinterpret_cast<const half8*>(src + pix * Cs);
+      half8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = (float)h[e] * sc[e] + sh[e];
+        if (silu) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+        o[e] = (half_t)v;
+      }
+      *reinterpret_cast<half8*>(y + pix * C + c) = o;
+    }
   }
 }
 
@@ -216,9 +238,8 @@ int groupnorm_num_slabs(int B, int HW) {
 
 size_t groupnorm_scratch_floats(int B, int HW, int G) { return (size_t)B * groupnorm_num_slabs(B, HW) * G * 2; }
 
-void launch_groupnorm(const half_t* x0, int C0, const half_t* x1, int C1, float* partial, float* stats,
-                      const float* gamma, const float* beta, half_t* y, int B, int HW, int G, float eps, int silu,
-                      hipStream_t s) {
+void launch_groupnorm(const half_t* x0, int C0, const half_t* x1, int C1, float* partial, const float* gamma,
+                      const float* beta, half_t* y, int B, int HW, int G, float eps, int silu, hipStream_t s) {
   if (!x1) C1 = 0;
   const int C = C0 + C1;
   SD_REQUIRE(C % G == 0 && C0 % 8 == 0 && C1 % 8 == 0 && G <= 64, kUnsupported, "groupnorm: C0=%d C1=%d G=%d", C0, C1, G);
@@ -226,13 +247,8 @@ void launch_groupnorm(const half_t* x0, int C0, const half_t* x1, int C1, float*
   const int ppb = cdiv(HW, slabs);
   slabs = cdiv(HW, ppb);   // <= groupnorm_num_slabs
   hipLaunchKernelGGL(groupnorm_partial_kernel, dim3(slabs, B), dim3(256), 0, s, x0, C0, x1, C1, partial, HW, G, ppb);
-  const float inv_n = 1.0f / ((float)(C / G) * (float)HW);
-  hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(cdiv(B * G, 64)), dim3(64), 0, s, partial, stats, B * G, G, slabs,
-                     inv_n, eps);
-  const size_t total = (size_t)B * HW * (C / 8);
-  const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
-  hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(blocks), dim3(256), 0, s, x0, C0, x1, C1, stats, gamma, beta, y, B, HW,
-                     G, silu);
+  hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(slabs, B), dim3(256), 0, s, x0, C0, x1, C1, partial, slabs, gamma, beta,
+                     y, HW, G, eps, silu, ppb);
   SD_HIP(hipGetLastError());
 }
 

@@ -158,7 +158,6 @@ Tensor UNet::group_norm(std::vector<Op>& ops, const std::string& name, const Ten
   const int G = cfg_.norm_num_groups;
   SD_REQUIRE(C % G == 0, kUnsupported, "%s: %d channels not divisible by %d groups", name.c_str(), C, G);
   float* partial = arena_.alloc_n<float>(groupnorm_scratch_floats(x.B, x.H * x.W, G));
-  float* stats = arena_.alloc_n<float>((size_t)x.B * G * 2);
   const float* gamma = upload_vec(name + ".weight", C);
   const float* beta = upload_vec(name + ".bias", C);
   Tensor y = new_tensor(x.B, x.H, x.W, C);
@@ -167,7 +166,7 @@ Tensor UNet::group_norm(std::vector<Op>& ops, const std::string& name, const Ten
   const int C0 = x.C, C1 = x2 ? x2->C : 0, B = x.B, HW = x.H * x.W, si = silu ? 1 : 0;
   half_t* yp = y.p;
   ops.push_back([=](hipStream_t s) {
-    launch_groupnorm(p0, C0, p1, C1, partial, stats, gamma, beta, yp, B, HW, G, eps, si, s);
+    launch_groupnorm(p0, C0, p1, C1, partial, gamma, beta, yp, B, HW, G, eps, si, s);
   });
   return y;
 }
@@ -350,6 +349,13 @@ void UNet::build_unet() {
 
   // ---- time embedding (unet.py:983-984; XL :1076-1088) ----
   {
+    auto upload_freq = [&](int dim) {
+      std::vector<float> f = timestep_freq_table(dim, cfg_.freq_shift);
+      float* d = arena_.alloc_n<float>(f.size());
+      SD_HIP(hipMemcpy(d, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice));
+      return d;
+    };
+    const float* freq = upload_freq(C0);
     float* t_emb = arena_.alloc_n<float>((size_t)B * C0);
     float* e1 = arena_.alloc_n<float>((size_t)B * tdim);
     half_t* w1 = upload_conv_weight("time_embedding.linear_1", tdim, C0, 1, false);
@@ -358,10 +364,9 @@ void UNet::build_unet() {
     float* b2 = upload_vec("time_embedding.linear_2.bias", tdim);
     float* tb = tbuf_;
     float* emb = emb_;
-    const float fshift = cfg_.freq_shift;
     SD_REQUIRE(cfg_.flip_sin_to_cos == 1, kUnsupported, "flip_sin_to_cos=False is not on the path");
     time_ops_.push_back([=](hipStream_t s) {
-      launch_timestep_embedding(tb, t_emb, B, C0, fshift, s);
+      launch_timestep_embedding(tb, freq, t_emb, B, C0, s);
       launch_gemv(w1, b1, t_emb, C0, e1, tdim, B, tdim, C0, 0, 1, 0, s);
       launch_gemv(w2, b2, e1, tdim, emb, tdim, B, tdim, tdim, 0, 0, 0, s);
     });
@@ -380,11 +385,12 @@ void UNet::build_unet() {
       float* ab1 = upload_vec("add_embedding.linear_1.bias", tdim);
       half_t* aw2 = upload_conv_weight("add_embedding.linear_2", tdim, tdim, 1, false);
       float* ab2 = upload_vec("add_embedding.linear_2.bias", tdim);
+      const float* afreq = upload_freq(adim);
       half_t* tids = in_time_ids_;
       half_t* txt = in_text_embeds_;
       time_ops_.push_back([=](hipStream_t s) {
         launch_half_to_float(tids, tid_f, (size_t)B * nt, s);
-        launch_timestep_embedding(tid_f, te, B * nt, adim, fshift, s);   // time_ids.flatten() (unet.py:1079)
+        launch_timestep_embedding(tid_f, afreq, te, B * nt, adim, s);   // time_ids.flatten() (unet.py:1079)
         for (int b = 0; b < B; ++b) {   // concat([text_embeds, time_embeds], dim=-1) (unet.py:1082)
           launch_half_to_float(txt + (size_t)b * text_dim, add_in + (size_t)b * pin, text_dim, s);
           SD_HIP(hipMemcpyAsync(add_in + (size_t)b * pin + text_dim, te + (size_t)b * nt * adim,

@@ -21,10 +21,11 @@ run ops_other 900 $PY -m pytest tests/test_ops_gpu.py -m gpu -q -k "not attentio
 run unet_small 1200 $PY -m pytest tests/test_unet_gpu.py -m gpu -q -k "not full" --timeout 600
 run unet_full 1200 $PY -m pytest tests/test_unet_gpu.py -m gpu -q -k "full" --timeout 1000
 run smoke 600 $PY -c "import __graft_entry__ as g; g.smoke()"
-run bench 1200 $PY bench.py --steps 10 --warmup 2
+run bench 1200 $PY bench.py --steps 10 --warmup 2 --cpu-steps ${CPU_STEPS:-0}
+run bench_split 600 $PY bench.py --steps 10 --warmup 2 --cpu-steps 0 --attention SPLIT_EINSUM
 if [ "${1:-}" != "quick" ]; then
   run microbench 900 $PY tools/microbench.py
-  cd /tmp && rocprofv3 --kernel-trace --stats -d /root/repo/$OUT/prof -o bench -- python /root/repo/bench.py --steps 5 --warmup 1 --cpu-steps 0 > /root/repo/$OUT/rocprof.log 2>&1
+  cd /tmp && rocprofv3 --kernel-trace --stats -d /root/repo/$OUT/prof -o bench -- python /root/repo/bench.py --steps 5 --warmup 1 --cpu-steps 0 --no-graph > /root/repo/$OUT/rocprof.log 2>&1
   cd /root/repo
   ls -la $OUT/prof 2>/dev/null | head -20 >> $OUT/summary.log
 fi
