@@ -287,8 +287,8 @@ int sd_op_conv2d(const void* x, const void* w, const float* bias, const void* re
     d.out = dout;
     d.B = B; d.Hi = H; d.Wi = W; d.Ho = Ho; d.Wo = Wo;
     d.ksize = ksize; d.stride = stride; d.up = up; d.N = Cout;
-    d.tile = tile % 10;          // tile >= 10: register-staged A/B variant of the same tile
-    d.reg_staging = tile >= 10;
+    d.tile = tile % 10;          // tile / 10 selects the staging variant of the same tile (A/B testing)
+    d.staging = tile / 10;
     d.splitk = splitk;
     const bool fast = !force_generic && conv_fast_path_ok(d);
     ConvWorkspace ws;

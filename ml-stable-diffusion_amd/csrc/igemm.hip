@@ -52,7 +52,7 @@ __device__ __attribute__((aligned(16))) half_t g_zero_chunk[8] = {0, 0, 0, 0, 0,
 // The DMA writes lane-linear 1-KiB pieces (8 rows x 128 B), so the bank swizzle lives on the
 // per-lane SOURCE address: physical 16-B chunk p of row r holds logical chunk p ^ ((r >> 1) & 7),
 // and fragment reads apply the same XOR (conflict-free ds_read_b128, cdna guide rule 21).
-template <int BM, int BN, int WGM, int WGN, bool TRANS_OUT, bool GLDS>
+template <int BM, int BN, int WGM, int WGN, bool TRANS_OUT, bool GLDS, int NST>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   static_assert(WGM * WGN == 4, "4 waves");
   constexpr int TM = BM / WGM / 32;   // 32x32 MFMA tiles per wave along m
@@ -62,8 +62,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   constexpr int ROW = GLDS ? BK : LDS_ROW;   // LDS row stride in halves
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  half_t* Xs = reinterpret_cast<half_t*>(smem);                 // [2][BM][ROW]
-  half_t* Ws = Xs + 2 * BM * ROW;                               // [2][BN][ROW]
+  half_t* Xs = reinterpret_cast<half_t*>(smem);                 // [NST][BM][ROW]
+  half_t* Ws = Xs + NST * BM * ROW;                             // [NST][BN][ROW]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -231,7 +231,24 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     }
   };
 
-  if constexpr (GLDS) {
+  if constexpr (GLDS && NST == 3) {
+    // 3-stage ring: the DMA of tile kt+2 is issued while tile kt is computed and tile kt+1 is
+    // still in flight.  Raw s_barrier + COUNTED vmcnt (a __syncthreads() would drain vmcnt(0) and
+    // serialise the ring, cdna guide section 5 "Pipelining across barriers"); wait + barrier sit in
+    // one asm statement with a memory clobber so no LDS access is scheduled across them.
+    constexpr int PER_TILE = XR + WR;    // LDS-DMA instructions per wave per tile
+    if (kt_begin < kt_end) load_tile(kt_begin, 0);
+    if (kt_begin + 1 < kt_end) load_tile(kt_begin + 1, 1);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const int rel = kt - kt_begin;
+      if (kt + 1 < kt_end)
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PER_TILE) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      if (kt + 2 < kt_end) load_tile(kt + 2, (rel + 2) % 3);
+      compute(rel % 3);
+    }
+  } else if constexpr (GLDS) {
     if (kt_begin < kt_end) load_tile(kt_begin, 0);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       const int buf = (kt - kt_begin) & 1;
@@ -442,6 +459,52 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(IgemmArgs a, int silu
   }
 }
 
+// ---- tiny input-channel count (conv_in 4->320, K = 36): 16 output pixels per workgroup, the
+// im2col patches live in LDS (broadcast reads), each thread keeps one output channel's K weights
+// in registers.  Replaces the generic one-thread-per-output kernel (95 us -> a few us).
+constexpr int SC_PIX = 16, SC_KMAX = 72;
+__global__ __launch_bounds__(256) void conv_small_cin_kernel(IgemmArgs a, int silu_out) {
+  __shared__ float patch[SC_PIX][SC_KMAX];
+  const int m0 = blockIdx.x * SC_PIX;
+  const int Hup = a.Hi * a.up, Wup = a.Wi * a.up, upshift = a.up >> 1;
+  for (int idx = threadIdx.x; idx < SC_PIX * a.K; idx += blockDim.x) {
+    const int p = idx / a.K, k = idx - p * a.K;
+    const int m = m0 + p;
+    float v = 0.f;
+    if (m < a.M) {
+      const int b = m / a.HoWo;
+      const int rem = m - b * a.HoWo;
+      const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+      const int tap = k / a.Ctot, c = k - tap * a.Ctot;
+      const int ky = tap / a.ksize, kx = tap - ky * a.ksize;
+      const int iy = oy * a.stride - a.pad + ky, ix = ox * a.stride - a.pad + kx;
+      if (iy >= 0 && iy < Hup && ix >= 0 && ix < Wup) {
+        const size_t pix = (size_t)b * a.Hi * a.Wi + (size_t)(iy >> upshift) * a.Wi + (ix >> upshift);
+        v = (c < a.C0) ? (float)a.x0[pix * a.C0 + c] : (float)a.x1[pix * a.C1 + (c - a.C0)];
+      }
+    }
+    patch[p][k] = v;
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < a.N; n += blockDim.x) {
+    float w[SC_KMAX];
+#pragma unroll
+    for (int k = 0; k < SC_KMAX; ++k) w[k] = (k < a.K) ? (float)a.w[(size_t)n * a.K + k] : 0.f;
+    const float bv = a.bias ? a.bias[n] : 0.f;
+    for (int p = 0; p < SC_PIX; ++p) {
+      const int m = m0 + p;
+      if (m >= a.M) break;
+      float acc = bv;
+#pragma unroll
+      for (int k = 0; k < SC_KMAX; ++k) acc += w[k] * patch[p][k];   // patch rows beyond K are never read as non-zero w
+      if (a.temb) acc += a.temb[(size_t)(m / a.HoWo) * a.temb_stride + n];
+      if (a.res) acc += (float)a.res[(size_t)m * a.N + n];
+      if (silu_out) acc = acc / (1.f + __expf(-acc));
+      a.out[(size_t)m * a.N + n] = (half_t)acc;
+    }
+  }
+}
+
 // ---- N <= 8 output channels (conv_out 320->4): one wavefront per output pixel ----
 template <int NMAX>
 __global__ __launch_bounds__(256) void conv_small_n_kernel(IgemmArgs a, float* out_nchw) {
@@ -602,11 +665,11 @@ Plan choose_plan(const ConvDesc& d, const IgemmArgs& a) {
   return p;
 }
 
-template <int BM, int BN, int WGM, int WGN, bool TRANS, bool GLDS>
+template <int BM, int BN, int WGM, int WGN, bool TRANS, bool GLDS, int NST>
 void launch_variant(const IgemmArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)2 * (BM + BN) * (GLDS ? BK : LDS_ROW) * sizeof(half_t);
+  const size_t lds = (size_t)NST * (BM + BN) * (GLDS ? BK : LDS_ROW) * sizeof(half_t);
   dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), a.splitk);
-  auto k = igemm_kernel<BM, BN, WGM, WGN, TRANS, GLDS>;
+  auto k = igemm_kernel<BM, BN, WGM, WGN, TRANS, GLDS, NST>;
   static bool attr = false;
   if (!attr) {
     SD_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -615,14 +678,17 @@ void launch_variant(const IgemmArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
 }
 
+// staging: 0 = LDS-DMA 2 stages, 1 = register staging (A/B reference), 2 = LDS-DMA 3-stage ring
 template <int BM, int BN, int WGM, int WGN>
-void launch_tile(const IgemmArgs& a, bool trans, bool glds, hipStream_t s) {
+void launch_tile(const IgemmArgs& a, bool trans, int staging, hipStream_t s) {
   if (trans) {
-    if (glds) launch_variant<BM, BN, WGM, WGN, true, true>(a, s);
-    else launch_variant<BM, BN, WGM, WGN, true, false>(a, s);
+    if (staging == 1) launch_variant<BM, BN, WGM, WGN, true, false, 2>(a, s);
+    else if (staging == 2) launch_variant<BM, BN, WGM, WGN, true, true, 3>(a, s);
+    else launch_variant<BM, BN, WGM, WGN, true, true, 2>(a, s);
   } else {
-    if (glds) launch_variant<BM, BN, WGM, WGN, false, true>(a, s);
-    else launch_variant<BM, BN, WGM, WGN, false, false>(a, s);
+    if (staging == 1) launch_variant<BM, BN, WGM, WGN, false, false, 2>(a, s);
+    else if (staging == 2) launch_variant<BM, BN, WGM, WGN, false, true, 3>(a, s);
+    else launch_variant<BM, BN, WGM, WGN, false, true, 2>(a, s);
   }
 }
 
@@ -660,12 +726,12 @@ void launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
     a.partial = ws.partial;
   }
   const bool trans = d.out_mode == kOutHalfT;
-  const bool glds = !d.reg_staging;
+  const int st = d.staging;
   switch (p.tile) {
-    case 1: launch_tile<128, 128, 2, 2>(a, trans, glds, s); break;
-    case 2: launch_tile<128, 64, 2, 2>(a, trans, glds, s); break;
-    case 3: launch_tile<64, 64, 2, 2>(a, trans, glds, s); break;
-    default: launch_tile<64, 128, 2, 2>(a, trans, glds, s); break;
+    case 1: launch_tile<128, 128, 2, 2>(a, trans, st, s); break;
+    case 2: launch_tile<128, 64, 2, 2>(a, trans, st, s); break;
+    case 3: launch_tile<64, 64, 2, 2>(a, trans, st, s); break;
+    default: launch_tile<64, 128, 2, 2>(a, trans, st, s); break;
   }
   if (a.splitk > 1) {
     size_t total4 = (size_t)a.M * a.N / 4;
@@ -677,6 +743,11 @@ void launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
 
 void launch_conv_generic(const ConvDesc& d, int act_silu_out, hipStream_t s) {
   IgemmArgs a = make_args(d);
+  if (a.K <= SC_KMAX && d.out_mode == kOutHalf && a.N >= 64) {
+    hipLaunchKernelGGL(conv_small_cin_kernel, dim3(cdiv(a.M, SC_PIX)), dim3(256), 0, s, a, act_silu_out);
+    SD_HIP(hipGetLastError());
+    return;
+  }
   SD_REQUIRE(d.out_mode != kOutGeglu || d.N % 64 == 0, kUnsupported, "generic GEGLU needs N %% 64 == 0 (N=%d)", d.N);
   size_t total = (size_t)a.M * a.N;
   int blocks = (int)std::min<size_t>((total + 255) / 256, 65535);

@@ -35,7 +35,7 @@ struct ConvDesc {
   // tuning overrides (0 = heuristic)
   int tile = 0;                 // 1: 128x128  2: 128x64  3: 64x64 4: 64x128
   int splitk = 0;
-  int reg_staging = 0;           // 1: HBM->VGPR->LDS staging instead of LDS-DMA (A/B testing)
+  int staging = 0;              // 0: LDS-DMA 2-stage, 1: HBM->VGPR->LDS (A/B reference), 2: LDS-DMA 3-stage ring
 };
 
 struct ConvWorkspace {

@@ -24,6 +24,7 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+constexpr int kGnMaxSlabs = 128;  // partial layout [B][G][kGnMaxSlabs][2]; unused slabs stay zero
 constexpr int LN_MAX_CHUNKS = 4;   // C <= 64 lanes * 4 chunks * 8 = 2048
 
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, const float* __restrict__ w,
@@ -106,14 +107,23 @@ __global__ __launch_bounds__(256) void groupnorm_partial_kernel(const half_t* __
       const int c = col * 8;
       const half_t* src = (c < C0) ? x0 + c : x1 + (c - C0);
       const int Cs = (c < C0) ? C0 : C1;
-      for (int p = p0 + r0; p < p1; p += rows) {
-        const half8 h = *reinterpret_cast<const half8*>(src + ((size_t)b * HW + p) * Cs);
+      // 4 independent 16-B loads in flight per thread (a dependent one-load-per-iteration loop
+      // would expose the full memory latency every iteration)
+      for (int p = p0 + r0; p < p1; p += 4 * rows) {
+        half8 h[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float f = (float)h[e];
-          s[e] += f;
-          q[e] += f * f;
+        for (int u = 0; u < 4; ++u) {
+          const int pp = p + u * rows;
+          h[u] = (pp < p1) ? *reinterpret_cast<const half8*>(src + ((size_t)b * HW + pp) * Cs) : half8{0, 0, 0, 0, 0, 0, 0, 0};
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float f = (float)h[u][e];
+            s[e] += f;
+            q[e] += f * f;
+          }
       }
     }
 #pragma unroll
@@ -143,7 +153,7 @@ __global__ __launch_bounds__(256) void groupnorm_partial_kernel(const half_t* __
     __syncthreads();
   }
   if (t < G) {
-    float* dst = partial + (((size_t)b * gridDim.x + blockIdx.x) * G + t) * 2;
+    float* dst = partial + (((size_t)b * G + t) * kGnMaxSlabs + blockIdx.x) * 2;   // [b][g][slab][2]
     dst[0] = gs;
     dst[1] = gq;
   }
@@ -166,19 +176,27 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const half_t* __re
   const int b = blockIdx.y;
   const int t = threadIdx.x;
   {
-    const int g = t >> 2, j = t & 3;
+    // fold the slabs: LPG lanes per group, each sums a contiguous run of kGnMaxSlabs/LPG slab entries
+    // (unused entries are zero) loaded as independent float4s, then a fixed-order shuffle tree.
+    const int LPG = (G <= 32) ? 8 : 4;
+    const int g = t / LPG, j = t % LPG;
+    const int per = kGnMaxSlabs / LPG;                 // 16 or 32 slab entries = 8 or 16 float4
     float s = 0.f, q = 0.f;
     if (g < G) {
-      for (int k = j; k < slabs; k += 4) {
-        const float* src = partial + (((size_t)b * slabs + k) * G + g) * 2;
-        s += src[0];
-        q += src[1];
+      const floatx4* src = reinterpret_cast<const floatx4*>(partial + (((size_t)b * G + g) * kGnMaxSlabs + j * per) * 2);
+      floatx4 v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] = (k < per / 2) ? src[k] : floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        s += v[k][0] + v[k][2];
+        q += v[k][1] + v[k][3];
       }
     }
-    s += __shfl_xor(s, 1);
-    q += __shfl_xor(q, 1);
-    s += __shfl_xor(s, 2);
-    q += __shfl_xor(q, 2);
+    for (int o = 1; o < LPG; o <<= 1) {
+      s += __shfl_xor(s, o);
+      q += __shfl_xor(q, o);
+    }
     if (g < G && j == 0) {
       const float inv_n = 1.0f / ((float)cpg * (float)HW);
       const float mean = s * inv_n;
@@ -206,17 +224,27 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const half_t* __re
     }
     const half_t* src = (c < C0) ? x0 + c : x1 + (c - C0);
     const int Cs = (c < C0) ? C0 : C1;
-    for (int p = p0 + r0; p < p1; p += rows) {
-      const size_t pix = (size_t)b * HW + p;
-      const half8 h = *reinterpret_cast<const half8*>(src + pix * Cs);
-      half8 o;
+    for (int p = p0 + r0; p < p1; p += 4 * rows) {
+      half8 h[4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float v = (float)h[e] * sc[e] + sh[e];
-        if (silu) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
-        o[e] = (half_t)v;
+      for (int u = 0; u < 4; ++u) {
+        const int pp = p + u * rows;
+        if (pp < p1) h[u] = *reinterpret_cast<const half8*>(src + ((size_t)b * HW + pp) * Cs);
       }
-      *reinterpret_cast<half8*>(y + pix * C + c) = o;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pp = p + u * rows;
+        if (pp < p1) {
+          half8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float v = (float)h[u][e] * sc[e] + sh[e];
+            if (silu) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+            o[e] = (half_t)v;
+          }
+          *reinterpret_cast<half8*>(y + ((size_t)b * HW + pp) * C + c) = o;
+        }
+      }
     }
   }
 }
@@ -236,7 +264,7 @@ int groupnorm_num_slabs(int B, int HW) {
   return std::max(1, std::min(std::min(want, 128), std::max(1, HW / 16)));
 }
 
-size_t groupnorm_scratch_floats(int B, int HW, int G) { return (size_t)B * groupnorm_num_slabs(B, HW) * G * 2; }
+size_t groupnorm_scratch_floats(int B, int HW, int G) { return (size_t)B * G * kGnMaxSlabs * 2; }
 
 void launch_groupnorm(const half_t* x0, int C0, const half_t* x1, int C1, float* partial, const float* gamma,
                       const float* beta, half_t* y, int B, int HW, int G, float eps, int silu, hipStream_t s) {

@@ -186,7 +186,7 @@ def test_conv2d_matches_torch(case):
     close(out, conv_ref(x, w, bias, res, stride, ups), f"conv {case}")
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 11, 12, 13, 14, 21, 22, 23, 24])
 @pytest.mark.parametrize("splitk", [1, 2, 5])
 def test_conv2d_every_tile_and_splitk(tile, splitk):
     rs = np.random.RandomState(tile * 10 + splitk)
@@ -215,6 +215,9 @@ def test_geglu_matches_oracle(m, c):
 def test_timestep_embedding_reference_golden():
     g = load_golden("timestep_golden.npz")
     out = _lib.timestep_embedding(g["t"], 320)
-    np.testing.assert_allclose(out, g["out"], atol=2e-5)
+    # fp32 argument t*f reaches ~1e3 where one ulp is 6e-5: a 1-ulp difference between the host
+    # frequency table and torch's vectorised exp moves sin/cos by that much (3 of 960 entries)
+    np.testing.assert_allclose(out, g["out"], atol=1e-4)
+    assert np.mean(np.abs(out - g["out"]) > 2e-6) < 0.02
     ts = np.array([951, 901, 1, 999, 0], np.float32)
-    np.testing.assert_allclose(_lib.timestep_embedding(ts, 256), unet_ref.timestep_embedding(torch.from_numpy(ts), 256).numpy(), atol=2e-5)
+    np.testing.assert_allclose(_lib.timestep_embedding(ts, 256), unet_ref.timestep_embedding(torch.from_numpy(ts), 256).numpy(), atol=1e-4)
