@@ -290,7 +290,9 @@ int sd_op_conv2d(const void* x, const void* w, const float* bias, const void* re
     d.tile = tile % 10;          // tile / 10 selects the staging variant of the same tile (A/B testing)
     d.staging = tile / 10;
     d.splitk = splitk;
-    const bool fast = !force_generic && conv_fast_path_ok(d);
+    d.debug = force_generic >= 2 ? force_generic - 1 : 0;   // 2: loads only, 3: compute only (ablation)
+    if (d.debug & 4) d.prof = sc.dev<long long>(8);
+    const bool fast = force_generic != 1 && conv_fast_path_ok(d);
     ConvWorkspace ws;
     if (fast) {
       ws.partial_bytes = conv_workspace_bytes(d);
@@ -302,6 +304,12 @@ int sd_op_conv2d(const void* x, const void* w, const float* bias, const void* re
       else
         launch_conv_generic(d, 0, sc.stream);
     });
+    if (d.prof) {
+      long long t[8];
+      SD_HIP(hipMemcpy(t, d.prof, sizeof(t), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[sd prof] block0: prologue %lld, k-loop %lld, epilogue %lld shader cycles; total %lld cycles = %lld ticks of the 100 MHz wall clock\n",
+              t[1] - t[0], t[2] - t[1], t[3] - t[2], t[3] - t[0], t[4]);
+    }
     std::vector<half_t> ot(on);
     SD_HIP(hipMemcpy(ot.data(), dout, on * 2, hipMemcpyDeviceToHost));
     nhwc_to_nchw(ot.data(), reinterpret_cast<half_t*>(out), B, Cout, Ho, Wo);

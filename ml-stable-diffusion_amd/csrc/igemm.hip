@@ -39,12 +39,12 @@ struct IgemmArgs {
   int temb_stride;
   int nk_total, nk_per_split, splitk;
   int out_mode, ldT;
+  int debug;   // ablation (microbench only): bits 0-1: 1 = loads+barriers only, 2 = compute only; bit 2: timestamps
+  long long* prof;
+  const half_t* zeros;   // >= 16 B of zeros: source of padding / out-of-range rows
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-
-// 16 bytes of zeros: source of every out-of-image (padding) / out-of-range lane of the LDS-DMA loader
-__device__ __attribute__((aligned(16))) half_t g_zero_chunk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 // One 256-thread workgroup = 4 wavefronts laid out WGM x WGN over a BM x BN tile.
 // GLDS = true: tiles go HBM -> LDS directly (global_load_lds_dwordx4, no VGPR round trip and no
@@ -52,7 +52,7 @@ __device__ __attribute__((aligned(16))) half_t g_zero_chunk[8] = {0, 0, 0, 0, 0,
 // The DMA writes lane-linear 1-KiB pieces (8 rows x 128 B), so the bank swizzle lives on the
 // per-lane SOURCE address: physical 16-B chunk p of row r holds logical chunk p ^ ((r >> 1) & 7),
 // and fragment reads apply the same XOR (conflict-free ds_read_b128, cdna guide rule 21).
-template <int BM, int BN, int WGM, int WGN, bool TRANS_OUT, bool GLDS, int NST>
+template <int BM, int BN, int WGM, int WGN, bool TRANS_OUT, bool GLDS, int NST, int DBG = 0>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   static_assert(WGM * WGN == 4, "4 waves");
   constexpr int TM = BM / WGM / 32;   // 32x32 MFMA tiles per wave along m
@@ -61,6 +61,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   constexpr int WR = BN / 32;
   constexpr int ROW = GLDS ? BK : LDS_ROW;   // LDS row stride in halves
 
+  // DBG (compile-time, microbench-only instantiations): bits 0-1: 1 = loads+barriers only, 2 = compute only;
+  // bit 2: phase timestamps; bit 3: no LDS reads; bit 4: no MFMAs.  Production kernels have DBG == 0.
+  const bool prof = (DBG & 4) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
+  long long prof_t[4];
+  long long prof_w0 = 0;
+  if (prof) { prof_t[0] = clock64(); prof_w0 = wall_clock64(); }
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half_t* Xs = reinterpret_cast<half_t*>(smem);                 // [NST][BM][ROW]
   half_t* Ws = Xs + NST * BM * ROW;                             // [NST][BN][ROW]
@@ -117,70 +123,81 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   const int chunk = GLDS ? (pchunk ^ ((lrow >> 1) & 7)) : pchunk;
 
   half8 xr[GLDS ? 1 : XR], wr[GLDS ? 1 : WR];
-  const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-  // K-tile iterator: tiles are visited in order, so (tap, channel offset) advance incrementally and
-  // the per-row source pixel (the expensive part of the im2col address) is recomputed only when
-  // the 3x3 tap changes (every Ctot/64 tiles), not every tile.
+  // K-tile iterator.  Tiles are visited in order, so every staged row just walks a pointer:
+  // per K step the loader is one 64-bit add per row.  The im2col source (3x3 tap shift, zero
+  // padding, nearest-x2 upsample, which of the two concat sources) is re-derived only when the
+  // tap or the source changes (every Ctot/64 or C0/64 steps) - a wave-uniform, rarely taken branch.
   int it_tap = (kt_begin * BK) / a.Ctot;
   int it_cc = kt_begin * BK - it_tap * a.Ctot;
-  int pix_tap = -1;
-  int x_src_pix[XR];                // source pixel index of row i for tap pix_tap, -1 = zero padding
-  const half_t* wrow[WR];           // this thread's weight rows (nullptr past N)
+  bool retarget = true;
+  const half_t* const zeros = a.zeros;
+  const half_t* xp[XR];             // where this thread's 16 bytes of row i come from for the next tile
+  int xstep[XR];                    // halves to advance per K step: BK, or 0 while the row reads zeros
+  const half_t* wp[WR];
+  int wstep[WR];
 #pragma unroll
   for (int i = 0; i < WR; ++i) {
     int n = n_blk + lrow + 32 * i;
-    wrow[i] = (n < a.N) ? a.w + (size_t)n * a.K + chunk * 8 : nullptr;
+    wp[i] = (n < a.N) ? a.w + (size_t)n * a.K + (size_t)kt_begin * BK + chunk * 8 : zeros;
+    wstep[i] = (n < a.N) ? BK : 0;
   }
 
-  auto load_tile = [&](int kt, int stage) {
-    const int k0 = kt * BK;
-    if (it_tap != pix_tap) {          // wave-uniform
-      pix_tap = it_tap;
+  auto load_tile = [&](int stage) {
+    if constexpr ((DBG & 3) == 2) return;
+    if (retarget) {                   // wave-uniform
       const int ky = (a.ksize == 3) ? it_tap / 3 : 0;
       const int kx = (a.ksize == 3) ? it_tap - ky * 3 : 0;
+      int cc = it_cc;
+      const half_t* src = a.x0;
+      int Csrc = a.C0;
+      if (cc >= a.C0) {
+        src = a.x1;
+        cc -= a.C0;
+        Csrc = a.C1;
+      }
+      src += cc + chunk * 8;
 #pragma unroll
       for (int i = 0; i < XR; ++i) {
         int iy = x_iy0[i] + ky, ix = x_ix0[i] + kx;
         bool ok = (x_pix[i] >= 0) && (iy >= 0) && (iy < Hup) && (ix >= 0) && (ix < Wup);
-        x_src_pix[i] = ok ? x_pix[i] + (iy >> upshift) * a.Wi + (ix >> upshift) : -1;
+        int pix = x_pix[i] + (iy >> upshift) * a.Wi + (ix >> upshift);
+        xp[i] = ok ? src + (size_t)pix * Csrc : zeros;
+        xstep[i] = ok ? BK : 0;
       }
     }
-    int cc = it_cc;
-    const half_t* src = a.x0;
-    int Csrc = a.C0;
-    if (cc >= a.C0) {
-      src = a.x1;
-      cc -= a.C0;
-      Csrc = a.C1;
-    }
-    src += cc + chunk * 8;
     it_cc += BK;                      // advance the iterator for the next call
     if (it_cc >= a.Ctot) {
       it_cc = 0;
       ++it_tap;
     }
+    retarget = (it_cc == 0) || (it_cc == a.C0);
     if constexpr (GLDS) {
       char* xs = reinterpret_cast<char*>(Xs + stage * BM * ROW) + wave * 1024;   // wave-uniform piece base
       char* ws = reinterpret_cast<char*>(Ws + stage * BN * ROW) + wave * 1024;
 #pragma unroll
       for (int i = 0; i < XR; ++i) {
-        const half_t* p = (x_src_pix[i] >= 0) ? src + (size_t)x_src_pix[i] * Csrc : g_zero_chunk;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)xp[i],
                                          (__attribute__((address_space(3))) void*)(xs + i * 4096), 16, 0, 0);
+        xp[i] += xstep[i];
       }
 #pragma unroll
       for (int i = 0; i < WR; ++i) {
-        const half_t* p = wrow[i] ? wrow[i] + k0 : g_zero_chunk;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wp[i],
                                          (__attribute__((address_space(3))) void*)(ws + i * 4096), 16, 0, 0);
+        wp[i] += wstep[i];
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < XR; ++i)
-        xr[i] = (x_src_pix[i] >= 0) ? *reinterpret_cast<const half8*>(src + (size_t)x_src_pix[i] * Csrc) : zero8;
+      for (int i = 0; i < XR; ++i) {
+        xr[i] = *reinterpret_cast<const half8*>(xp[i]);
+        xp[i] += xstep[i];
+      }
 #pragma unroll
-      for (int i = 0; i < WR; ++i) wr[i] = wrow[i] ? *reinterpret_cast<const half8*>(wrow[i] + k0) : zero8;
+      for (int i = 0; i < WR; ++i) {
+        wr[i] = *reinterpret_cast<const half8*>(wp[i]);
+        wp[i] += wstep[i];
+      }
     }
   };
   auto store_tile = [&](int buf) {   // register-staged variant only
@@ -208,72 +225,110 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   const int fk = (lane >> 5) * 8;       // k offset of this half-wave inside a 16-deep MFMA step
   const int fsw = (frow >> 1) & 7;      // GLDS: swizzle of this lane's fragment rows (tile bases are multiples of 32)
 
-  auto compute = [&](int buf) {
+  // K-step body, split so the next tile's address math + DMA issue can sit in the shadow of the MFMAs:
+  //   read_frags(buf)  - all 16 ds_read_b128 of the step up front (with one wave per SIMD a
+  //                      read->wait->4 MFMA chain exposes the LDS latency four times per step)
+  //   [load_tile(next)] - scheduled by the compiler between / behind the MFMAs
+  //   mfma_step()      - 16 back-to-back MFMAs
+  half8 xf[BK / 16][TM] = {}, wf[BK / 16][TN] = {};
+  auto read_frags = [&](int buf) {
+    if constexpr ((DBG & 3) == 1) return;
+    if constexpr ((DBG & 8) != 0) {   // ablation: no LDS reads (fragments = loop-invariant garbage kept live)
+#pragma unroll
+      for (int kk = 0; kk < BK / 16; ++kk) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(xf[kk][i]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(wf[kk][j]));
+      }
+      return;
+    }
     const half_t* xs = Xs + buf * BM * ROW + (wm * TM * 32 + frow) * ROW;
     const half_t* ws = Ws + buf * BN * ROW + (wn * TN * 32 + frow) * ROW;
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
       const int koff = GLDS ? (((kk * 2 + (lane >> 5)) ^ fsw) * 8) : (kk * 16 + fk);
-      half8 xf[TM], wf[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const half8*>(xs + i * 32 * ROW + koff);
+      for (int i = 0; i < TM; ++i) xf[kk][i] = *reinterpret_cast<const half8*>(xs + i * 32 * ROW + koff);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const half8*>(ws + j * 32 * ROW + koff);
+      for (int j = 0; j < TN; ++j) wf[kk][j] = *reinterpret_cast<const half8*>(ws + j * 32 * ROW + koff);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead (the scheduler would sink them back to their uses)
+  };
+  auto mfma_step = [&]() {
+    if constexpr ((DBG & 3) == 1) return;
+    if constexpr ((DBG & 16) != 0) {  // ablation: no MFMAs (fragments consumed so the reads stay)
+#pragma unroll
+      for (int kk = 0; kk < BK / 16; ++kk) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(xf[kk][i]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(wf[kk][j]));
+      }
+      return;
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           if constexpr (TRANS_OUT)   // rows = m, cols = n
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[i], wf[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[kk][i], wf[kk][j], acc[i][j], 0, 0, 0);
           else                       // rows = n, cols = m
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kk][j], xf[kk][i], acc[i][j], 0, 0, 0);
         }
     }
   };
 
+  if (prof) prof_t[1] = clock64();
   if constexpr (GLDS && NST == 3) {
     // 3-stage ring: the DMA of tile kt+2 is issued while tile kt is computed and tile kt+1 is
     // still in flight.  Raw s_barrier + COUNTED vmcnt (a __syncthreads() would drain vmcnt(0) and
     // serialise the ring, cdna guide section 5 "Pipelining across barriers"); wait + barrier sit in
     // one asm statement with a memory clobber so no LDS access is scheduled across them.
     constexpr int PER_TILE = XR + WR;    // LDS-DMA instructions per wave per tile
-    if (kt_begin < kt_end) load_tile(kt_begin, 0);
-    if (kt_begin + 1 < kt_end) load_tile(kt_begin + 1, 1);
+    if (kt_begin < kt_end) load_tile(0);
+    if (kt_begin + 1 < kt_end) load_tile(1);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       const int rel = kt - kt_begin;
       if (kt + 1 < kt_end)
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PER_TILE) : "memory");
       else
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-      if (kt + 2 < kt_end) load_tile(kt + 2, (rel + 2) % 3);
-      compute(rel % 3);
+      read_frags(rel % 3);
+      if (kt + 2 < kt_end) load_tile((rel + 2) % 3);
+      mfma_step();
     }
   } else if constexpr (GLDS) {
-    if (kt_begin < kt_end) load_tile(kt_begin, 0);
+    if (kt_begin < kt_end) load_tile(0);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       const int buf = (kt - kt_begin) & 1;
       // vmcnt(0) + barrier: this tile's DMA has landed for every wave, and every wave is done
       // reading the other stage, which the next DMA may now overwrite
       __syncthreads();
-      if (kt + 1 < kt_end) load_tile(kt + 1, buf ^ 1);
-      compute(buf);
+      read_frags(buf);
+      if (kt + 1 < kt_end) load_tile(buf ^ 1);
+      mfma_step();
     }
   } else {
     if (kt_begin < kt_end) {
-      load_tile(kt_begin, 0);
+      load_tile(0);
       store_tile(0);
     }
     __syncthreads();
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       const int buf = (kt - kt_begin) & 1;
       const bool more = (kt + 1) < kt_end;
-      if (more) load_tile(kt + 1, 0);     // HBM/L2 latency hides under this tile's MFMAs
-      compute(buf);
+      read_frags(buf);
+      if (more) load_tile(0);     // HBM/L2 latency hides under this tile's MFMAs
+      mfma_step();
       if (more) store_tile(buf ^ 1);
       __syncthreads();
     }
   }
 
+  if (prof) prof_t[2] = clock64();
   // ---------------------------------- epilogue ----------------------------------
   const int hi = lane >> 5;
   if constexpr (TRANS_OUT) {
@@ -381,6 +436,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
           }
         }
     }
+  }
+  if (prof) {
+    prof_t[3] = clock64();
+    a.prof[0] = prof_t[0];
+    a.prof[1] = prof_t[1];
+    a.prof[2] = prof_t[2];
+    a.prof[3] = prof_t[3];
+    a.prof[4] = wall_clock64() - prof_w0;
   }
 }
 
@@ -556,6 +619,16 @@ __global__ __launch_bounds__(256) void conv_small_n_kernel(IgemmArgs a, float* o
   }
 }
 
+const half_t* device_zero_chunk() {   // allocated on first use (always outside graph capture: eager warm-up run)
+  static half_t* p = nullptr;
+  if (!p) {
+    SD_HIP(hipMalloc(reinterpret_cast<void**>(&p), 256));
+    SD_HIP(hipMemset(p, 0, 256));
+    SD_HIP(hipDeviceSynchronize());
+  }
+  return p;
+}
+
 IgemmArgs make_args(const ConvDesc& d) {
   IgemmArgs a{};
   a.x0 = d.x0;
@@ -588,6 +661,9 @@ IgemmArgs make_args(const ConvDesc& d) {
   a.splitk = 1;
   a.out_mode = d.out_mode;
   a.ldT = d.ldT;
+  a.debug = d.debug;
+  a.prof = d.prof;
+  a.zeros = device_zero_chunk();
   return a;
 }
 
@@ -678,6 +754,27 @@ void launch_variant(const IgemmArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
 }
 
+template <int BM, int BN, int DBG>
+void launch_debug(const IgemmArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(half_t);
+  dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), a.splitk);
+  auto k = igemm_kernel<BM, BN, 2, 2, false, true, 2, DBG>;
+  SD_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+}
+template <int BM, int BN>
+bool launch_debug_mode(const IgemmArgs& a, int dbg, hipStream_t s) {
+  switch (dbg) {
+    case 4: launch_debug<BM, BN, 4>(a, s); return true;
+    case 5: launch_debug<BM, BN, 5>(a, s); return true;
+    case 6: launch_debug<BM, BN, 6>(a, s); return true;
+    case 14: launch_debug<BM, BN, 14>(a, s); return true;
+    case 22: launch_debug<BM, BN, 22>(a, s); return true;
+    case 30: launch_debug<BM, BN, 30>(a, s); return true;
+    default: return false;
+  }
+}
+
 // staging: 0 = LDS-DMA 2 stages, 1 = register staging (A/B reference), 2 = LDS-DMA 3-stage ring
 template <int BM, int BN, int WGM, int WGN>
 void launch_tile(const IgemmArgs& a, bool trans, int staging, hipStream_t s) {
@@ -727,6 +824,11 @@ void launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
   }
   const bool trans = d.out_mode == kOutHalfT;
   const int st = d.staging;
+  if (d.debug) {   // ablation builds exist for two tiles only (tools/prof_conv.py)
+    const bool ok = p.tile == 1 ? launch_debug_mode<128, 128>(a, d.debug, s) : launch_debug_mode<64, 64>(a, d.debug, s);
+    SD_REQUIRE(ok && !trans, kInvalidArgument, "no ablation kernel for debug mode %d", d.debug);
+    return;
+  }
   switch (p.tile) {
     case 1: launch_tile<128, 128, 2, 2>(a, trans, st, s); break;
     case 2: launch_tile<128, 64, 2, 2>(a, trans, st, s); break;

@@ -35,6 +35,8 @@ struct ConvDesc {
   // tuning overrides (0 = heuristic)
   int tile = 0;                 // 1: 128x128  2: 128x64  3: 64x64 4: 64x128
   int splitk = 0;
+  long long* prof = nullptr;    // debug bit 2: device buffer of 8 timestamps
+  int debug = 0;                // ablation hooks for tools/microbench (results are garbage when != 0)
   int staging = 0;              // 0: LDS-DMA 2-stage, 1: HBM->VGPR->LDS (A/B reference), 2: LDS-DMA 3-stage ring
 };
 

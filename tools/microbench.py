@@ -56,7 +56,7 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     res[f"t{tile}_k{sk}"] = str(e)
         _, ms_auto = _lib.conv2d(x, wt, bias, None, stride=s, upsample=bool(up), iters=10)
-        good = {kk: v for kk, v in res.items() if isinstance(v, float)}
+        good = {kk: v for kk, v in res.items() if isinstance(v, float) and kk[2] == "_"}   # 2-stage variants only
         best = min(good, key=good.get)
         out["conv"].append(dict(k=k, stride=s, cin=cin, cout=cout, h=h, w=w, up=up, count=count, M=m, gflop=flop / 1e9,
                                 auto_ms=ms_auto, auto_tflops=flop / ms_auto / 1e9, best=best, best_ms=good[best],
