@@ -90,6 +90,7 @@ typedef struct sd_unet_config {
   int32_t num_time_ids;          /* SDXL base 6, refiner 5                                           */
   int32_t support_controlnet;    /* UNet: consume additional_residual_0..N (unet.py:1009-1022)       */
   int32_t is_controlnet;         /* build controlnet.py:49-250 instead of the UNet                   */
+  int32_t is_vae_decoder;        /* build the AutoencoderKL decoder (sd_vae_decoder_create)          */
   int32_t attention_impl;        /* sd_attention_impl                                                */
   int32_t use_graph;             /* 1: capture the forward into a HIP graph and replay it            */
 } sd_unet_config;
@@ -139,6 +140,16 @@ int sd_unet_time_forward(sd_unet* u, int warmup, int iters, float* ms_per_iter);
 int sd_unet_denoise_loop(sd_unet* u, const sd_unet_io* io, float* latents, int n_images, int n_steps,
                          const float* timesteps, const float* coef, int history, float guidance_scale,
                          float* ms_per_step);
+
+/* ------------------------------------------------------------------------------------------
+ * VAE decoder: image = decoder(post_quant_conv(z)) in [-1, 1] (torch2coreml.py:584-594; call
+ * site pipeline.py:313-320 `vae_decoder(z=latents / 0.18215)["image"]`; Decoder.swift).  The
+ * config reuses sd_unet_config: block_out_channels = the VAE's (128,256,512,512), layers_per_block
+ * = 2, in_channels = 4, out_channels = 3, height/width = latent size, norm_num_groups = 32.
+ * z: (B, 4, h, w) f16 or f32 (z_dtype); image: (B, 3, 8h, 8w) f32.
+ * ------------------------------------------------------------------------------------------ */
+int sd_vae_decoder_create(const sd_unet_config* cfg, const sd_weights* w, int device, sd_unet** out);
+int sd_vae_decode(sd_unet* vae, const void* z, sd_dtype z_dtype, float* image, int flags);
 
 /* ------------------------------------------------------------------------------------------
  * Operator-level entry points (what the parity tests and micro-benchmarks bind).  Host

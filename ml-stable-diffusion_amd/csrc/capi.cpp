@@ -175,6 +175,25 @@ int sd_unet_denoise_loop(sd_unet* u, const sd_unet_io* io, float* latents, int n
   });
 }
 
+int sd_vae_decoder_create(const sd_unet_config* cfg, const sd_weights* w, int device, sd_unet** out) {
+  return guarded([&] {
+    SD_REQUIRE(cfg && w && out, kInvalidArgument, "NULL argument");
+    require_device();
+    sd_unet_config c = *cfg;
+    c.is_vae_decoder = 1;
+    c.is_controlnet = 0;
+    auto h = std::make_unique<sd_unet>();
+    h->impl = std::make_unique<UNet>(c, w->store, device);
+    *out = h.release();
+  });
+}
+int sd_vae_decode(sd_unet* vae, const void* z, sd_dtype z_dtype, float* image, int flags) {
+  return guarded([&] {
+    SD_REQUIRE(vae && z && image, kInvalidArgument, "NULL argument");
+    vae->impl->vae_decode(z, z_dtype == SD_F32, image, flags);
+  });
+}
+
 // ------------------------------- operator-level entry points -------------------------------
 
 int sd_op_attention(int impl, const void* q, const void* k, const void* v, void* out, int B, int heads, int d,

@@ -89,6 +89,9 @@ size_t groupnorm_scratch_floats(int B, int HW, int G);
 void launch_groupnorm(const half_t* x0, int C0, const half_t* x1, int C1, float* partial, const float* gamma,
                       const float* beta, half_t* y, int B, int HW, int G, float eps, int silu, hipStream_t s);
 
+// in-place softmax(scale * x) over each row of a [rows][cols] fp16 matrix (VAE single-head attention)
+void launch_row_softmax(half_t* x, int rows, int cols, float scale, hipStream_t s);
+
 // ---------------------------------------------------------------------------------------------
 // K8/K9 + boundary helpers (misc.hip)
 // ---------------------------------------------------------------------------------------------

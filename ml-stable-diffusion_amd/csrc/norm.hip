@@ -249,7 +249,67 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const half_t* __re
   }
 }
 
+// One workgroup per row: row kept in registers (cols <= 256 threads * 4 chunks * 8), fp32 max / sum
+// with wave shuffles + LDS across the four waves.
+__global__ __launch_bounds__(256) void row_softmax_kernel(half_t* __restrict__ x, int cols, float scale_log2) {
+  __shared__ float red[8];
+  half_t* row = x + (size_t)blockIdx.x * cols;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int nchunk = cols >> 3;
+  float v[4][8];
+  float mx = -1e30f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ch = t + 256 * i;
+    if (ch < nchunk) {
+      const half8 h = *reinterpret_cast<const half8*>(row + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[i][e] = (float)h[e] * scale_log2;
+        mx = fmaxf(mx, v[i][e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ch = t + 256 * i;
+    if (ch < nchunk) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[i][e] = __builtin_amdgcn_exp2f(v[i][e] - mx);
+        sum += v[i][e];
+      }
+    }
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ch = t + 256 * i;
+    if (ch < nchunk) {
+      half8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (half_t)(v[i][e] * inv);
+      *reinterpret_cast<half8*>(row + ch * 8) = o;
+    }
+  }
+}
+
 }  // namespace
+
+void launch_row_softmax(half_t* x, int rows, int cols, float scale, hipStream_t s) {
+  SD_REQUIRE(cols % 8 == 0 && cols <= 256 * 4 * 8, kUnsupported, "row_softmax: cols=%d (need cols %% 8 == 0, <= 8192)", cols);
+  hipLaunchKernelGGL(row_softmax_kernel, dim3(rows), dim3(256), 0, s, x, cols, scale * 1.4426950408889634f);
+  SD_HIP(hipGetLastError());
+}
 
 void launch_layernorm(const half_t* x, const float* w, const float* b, half_t* y, int M, int C, float eps,
                       hipStream_t s) {

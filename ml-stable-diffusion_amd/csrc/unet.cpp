@@ -35,7 +35,10 @@ UNet::UNet(const sd_unet_config& cfg, const WeightStore& ws, int device) : cfg_(
   SD_REQUIRE(device >= 0 && device < ndev, kInvalidArgument, "device %d out of range (%d visible)", device, ndev);
   SD_HIP(hipSetDevice(device));
   SD_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-  build_unet();
+  if (cfg_.is_vae_decoder)
+    build_vae_decoder();
+  else
+    build_unet();
   ws_ = nullptr;
   SD_HIP(hipStreamSynchronize(stream_));
 }
@@ -192,10 +195,11 @@ const float* UNet::register_temb(const std::string& name, int cout) {
 }
 
 // unet.py:470-489
-Tensor UNet::resnet(std::vector<Op>& ops, const std::string& p, const Tensor& x, const Tensor* x2, int cout) {
+Tensor UNet::resnet(std::vector<Op>& ops, const std::string& p, const Tensor& x, const Tensor* x2, int cout,
+                    bool has_temb) {
   const int cin = x.C + (x2 ? x2->C : 0);
   Tensor t0 = group_norm(ops, p + ".norm1", x, x2, cfg_.norm_eps, true);
-  const float* temb = register_temb(p + ".time_emb_proj", cout);
+  const float* temb = has_temb ? register_temb(p + ".time_emb_proj", cout) : nullptr;
   Tensor h = conv(ops, p + ".conv1", t0, nullptr, cout, 3, 1, 1, true, temb, nullptr);
   Tensor t1 = group_norm(ops, p + ".norm2", h, nullptr, cfg_.norm_eps, true);
   const half_t* shortcut;
@@ -524,6 +528,127 @@ void UNet::build_unet() {
   // loop state (allocated lazily on first denoise_loop)
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// VAE decoder (diffusers AutoencoderKL.decode, wrapped by the reference in
+// torch2coreml.py:584-594: image = decoder(post_quant_conv(z)); called from pipeline.py:313-320).
+// Third-party arithmetic restated from the public architecture:
+//   post_quant_conv 1x1 -> conv_in 3x3 -> mid [ResNet, 1-head self-attention, ResNet]
+//   -> up blocks (3 ResNets each, nearest-x2 + conv3x3 after all but the last)
+//   -> GroupNorm(32, 1e-6) -> SiLU -> conv_out 3x3.   All GroupNorm eps = 1e-6, no time embedding.
+// Reuses the UNet config struct: block_out_channels = decoder channels in ENCODER order
+// (SD: 128,256,512,512), layers_per_block = 2 (decoder uses +1), in_channels = latent channels,
+// out_channels = 3, height/width = latent size.
+// ---------------------------------------------------------------------------------------------
+void UNet::build_vae_decoder() {
+  const int B = cfg_.batch, H = cfg_.height, W = cfg_.width, n = cfg_.n_levels;
+  const int Cz = cfg_.in_channels;
+  cfg_.norm_eps = 1e-6f;
+  in_z_ = arena_.alloc_n<float>((size_t)B * Cz * H * W);
+  Tensor z = new_tensor(B, H, W, Cz);
+  {
+    float* src = in_z_;
+    main_ops_.push_back([=](hipStream_t s) { launch_nchw_to_nhwc(src, 1, z.p, B, Cz, H, W, s); });
+  }
+  Tensor h = conv(main_ops_, "post_quant_conv", z, nullptr, Cz, 1, 1, 1, true, nullptr, nullptr);
+  const int Ctop = cfg_.block_out_channels[n - 1];
+  h = conv(main_ops_, "decoder.conv_in", h, nullptr, Ctop, 3, 1, 1, true, nullptr, nullptr);
+  h = resnet(main_ops_, "decoder.mid_block.resnets.0", h, nullptr, Ctop, false);
+  {  // single-head self-attention over H*W tokens, d = C (too wide for the streaming kernel's
+     // register budget): scores and P are materialised per image (S x S fp16) through the GEMM kernel.
+    const std::string p = "decoder.mid_block.attentions.0";
+    const int C = Ctop, S = H * W;
+    Tensor t0 = group_norm(main_ops_, p + ".group_norm", h, nullptr, 1e-6f, false);
+    Tensor q = conv(main_ops_, p + ".to_q", t0, nullptr, C, 1, 1, 1, true, nullptr, nullptr);
+    Tensor k = conv(main_ops_, p + ".to_k", t0, nullptr, C, 1, 1, 1, true, nullptr, nullptr);
+    const int ldv = round_up(S, 8);
+    Tensor vt = conv(main_ops_, p + ".to_v", t0, nullptr, C, 1, 1, 1, true, nullptr, nullptr, kOutHalfT, ldv);
+    SD_REQUIRE(C % 64 == 0 && S % 64 == 0, kUnsupported, "VAE attention needs C %% 64 == 0 and H*W %% 64 == 0");
+    half_t* scores = arena_.alloc_n<half_t>((size_t)S * S);
+    Tensor a = new_tensor(B, H, W, C);
+    const float scale = 1.0f / std::sqrt((float)C);
+    ws_need_ = std::max<size_t>(ws_need_, 0);
+    for (int b = 0; b < B; ++b) {
+      ConvDesc d1;   // scores[q][k] = sum_c Q[q][c] K[k][c]   (K tokens play the role of the weight matrix)
+      d1.x0 = q.p + (size_t)b * S * C; d1.C0 = C; d1.w = k.p + (size_t)b * S * C;
+      d1.out = scores; d1.B = 1; d1.Hi = 1; d1.Wi = S; d1.Ho = 1; d1.Wo = S; d1.N = S;
+      ConvDesc d2;   // out[q][c] = sum_k P[q][k] V^T[c][k]
+      d2.x0 = scores; d2.C0 = S; d2.w = vt.p + (size_t)b * C * ldv;
+      d2.out = a.p + (size_t)b * S * C; d2.B = 1; d2.Hi = 1; d2.Wi = S; d2.Ho = 1; d2.Wo = S; d2.N = C;
+      SD_REQUIRE(ldv == S, kUnsupported, "VAE attention needs H*W %% 8 == 0");
+      ws_need_ = std::max(ws_need_, std::max(conv_workspace_bytes(d1), conv_workspace_bytes(d2)));
+      main_ops_.push_back([this, d1, d2, scores, S, scale](hipStream_t s) {
+        launch_conv(d1, ws_conv_, s);
+        launch_row_softmax(scores, S, S, scale, s);
+        launch_conv(d2, ws_conv_, s);
+      });
+    }
+    h = conv(main_ops_, p + ".to_out.0", a, nullptr, C, 1, 1, 1, true, nullptr, h.p);
+  }
+  h = resnet(main_ops_, "decoder.mid_block.resnets.1", h, nullptr, Ctop, false);
+  for (int i = 0; i < n; ++i) {
+    const int cout = cfg_.block_out_channels[n - 1 - i];
+    const std::string p = "decoder.up_blocks." + std::to_string(i);
+    for (int j = 0; j < cfg_.layers_per_block + 1; ++j)
+      h = resnet(main_ops_, p + ".resnets." + std::to_string(j), h, nullptr, cout, false);
+    if (i != n - 1) h = conv(main_ops_, p + ".upsamplers.0.conv", h, nullptr, cout, 3, 1, 2, true, nullptr, nullptr);
+  }
+  Tensor t = group_norm(main_ops_, "decoder.conv_norm_out", h, nullptr, 1e-6f, true);
+  {  // conv_out 3x3 -> 3 channels: one wavefront per pixel, written straight as fp32 NCHW
+    SD_REQUIRE(cfg_.out_channels <= 8 && t.C % 8 == 0, kUnsupported, "VAE conv_out: %d -> %d channels", t.C,
+               cfg_.out_channels);
+    image_elems_ = (size_t)t.B * cfg_.out_channels * t.H * t.W;
+    image_ = arena_.alloc_n<float>(image_elems_);
+    ConvDesc d;
+    d.x0 = t.p;
+    d.C0 = t.C;
+    d.w = upload_conv_weight("decoder.conv_out", cfg_.out_channels, t.C, 3, false);
+    d.bias = upload_vec("decoder.conv_out.bias", cfg_.out_channels);
+    d.B = t.B; d.Hi = t.H; d.Wi = t.W; d.Ho = t.H; d.Wo = t.W;
+    d.ksize = 3; d.stride = 1; d.up = 1; d.N = cfg_.out_channels;
+    float* dst = image_;
+    main_ops_.push_back([=](hipStream_t s) { launch_conv_small_n(d, dst, s); });
+  }
+  if (ws_need_ > 0) {
+    ws_conv_.partial = reinterpret_cast<float*>(arena_.alloc(ws_need_));
+    ws_conv_.partial_bytes = ws_need_;
+  }
+}
+
+// pipeline.py:313-320 hands z = latents / scaling_factor (fp16 or fp32); returns image in [-1, 1]
+void UNet::vae_decode(const void* z, int z_is_f32, float* image, int flags) {
+  SD_HIP(hipSetDevice(device_));
+  SD_REQUIRE(cfg_.is_vae_decoder, kInvalidArgument, "handle is not a VAE decoder");
+  const bool dev = (flags & SD_FLAG_DEVICE_PTRS) != 0;
+  const size_t n = (size_t)cfg_.batch * cfg_.in_channels * cfg_.height * cfg_.width;
+  if (z_is_f32) {
+    SD_HIP(hipMemcpyAsync(in_z_, z, n * 4, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream_));
+  } else {
+    if (!z_half_) z_half_ = arena_.alloc_n<half_t>(n);
+    SD_HIP(hipMemcpyAsync(z_half_, z, n * 2, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream_));
+    launch_half_to_float(z_half_, in_z_, n, stream_);
+  }
+  if (cfg_.use_graph) {
+    if (!graph_) {
+      run_ops(main_ops_);
+      SD_HIP(hipStreamSynchronize(stream_));
+      hipGraph_t g = nullptr;
+      SD_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+      run_ops(main_ops_);
+      SD_HIP(hipStreamEndCapture(stream_, &g));
+      SD_HIP(hipGraphInstantiate(&graph_, g, nullptr, nullptr, 0));
+      SD_HIP(hipGraphDestroy(g));
+    }
+    SD_HIP(hipGraphLaunch(graph_, stream_));
+  } else {
+    run_ops(main_ops_);
+  }
+  SD_HIP(hipMemcpyAsync(image, image_, image_elems_ * sizeof(float),
+                        dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream_));
+  SD_HIP(hipStreamSynchronize(stream_));
+  have_inputs_ = true;
+}
+
 void UNet::set_attention(int impl) {
   SD_REQUIRE(impl >= 0 && impl <= 2, kInvalidArgument, "attention impl %d", impl);
   if (impl != cfg_.attention_impl) {
@@ -616,6 +741,7 @@ void UNet::ensure_graph() {
 
 void UNet::forward(const sd_unet_io& io) {
   SD_HIP(hipSetDevice(device_));
+  SD_REQUIRE(!cfg_.is_vae_decoder, kInvalidArgument, "handle is a VAE decoder: use sd_vae_decode");
   upload_inputs(io, false);
   if (cfg_.use_graph) {
     ensure_graph();

@@ -28,6 +28,7 @@ class UNet {
   void denoise_loop(const sd_unet_io& io, float* latents, int n_images, int n_steps, const float* timesteps,
                     const float* coef, int history, float guidance, float* ms_per_step);
   void set_attention(int impl);
+  void vae_decode(const void* z, int z_is_f32, float* image, int flags);
   int num_residuals() const { return (int)res_shapes_.size(); }
   size_t device_bytes() const { return arena_.bytes(); }
   const sd_unet_config& config() const { return cfg_; }
@@ -35,6 +36,7 @@ class UNet {
  private:
   // ---- build ----
   void build_unet();
+  void build_vae_decoder();
   Tensor new_tensor(int B, int H, int W, int C);
   half_t* upload_conv_weight(const std::string& name, int cout, int cin, int k, bool geglu);
   float* upload_vec(const std::string& name, int n, bool geglu = false);
@@ -44,7 +46,8 @@ class UNet {
   Tensor group_norm(std::vector<Op>& ops, const std::string& name, const Tensor& x, const Tensor* x2, float eps,
                     bool silu);
   Tensor layer_norm(std::vector<Op>& ops, const std::string& name, const Tensor& x);
-  Tensor resnet(std::vector<Op>& ops, const std::string& p, const Tensor& x, const Tensor* x2, int cout);
+  Tensor resnet(std::vector<Op>& ops, const std::string& p, const Tensor& x, const Tensor* x2, int cout,
+                bool has_temb = true);
   Tensor transformer(std::vector<Op>& ops, const std::string& p, const Tensor& x, int heads, int depth);
   Tensor transformer_block(std::vector<Op>& ops, const std::string& b, const Tensor& h, int heads);
   Tensor attention(std::vector<Op>& ops, const Tensor& q, const half_t* k, const half_t* vt, int heads, int Sq,
@@ -73,6 +76,10 @@ class UNet {
   std::vector<Tensor> res_nhwc_;       // ... converted to NHWC
   std::vector<std::vector<int>> res_shapes_;   // (B,C,H,W) of each residual
   float* noise_pred_ = nullptr;     // NCHW f32
+  float* in_z_ = nullptr;           // VAE: latent input NCHW f32
+  half_t* z_half_ = nullptr;
+  float* image_ = nullptr;          // VAE: decoded image NCHW f32
+  size_t image_elems_ = 0;
   std::vector<float*> res_out_;     // ControlNet outputs NCHW f32
   std::vector<Tensor> cn_out_;      // ControlNet outputs NHWC f16
 

@@ -38,6 +38,7 @@ class UNetConfig(C.Structure):
         ("flip_sin_to_cos", C.c_int32), ("freq_shift", C.c_float),
         ("addition_time_embed_dim", C.c_int32), ("projection_class_embeddings_input_dim", C.c_int32),
         ("num_time_ids", C.c_int32), ("support_controlnet", C.c_int32), ("is_controlnet", C.c_int32),
+        ("is_vae_decoder", C.c_int32),
         ("attention_impl", C.c_int32), ("use_graph", C.c_int32),
     ]
 
@@ -73,6 +74,8 @@ SYMBOLS = [
     ("sd_unet_forward", _I, [_P, C.POINTER(UNetIO)]),
     ("sd_unet_time_forward", _I, [_P, _I, _I, _FP]),
     ("sd_unet_denoise_loop", _I, [_P, C.POINTER(UNetIO), _FP, _I, _I, _FP, _FP, _I, _F, _FP]),
+    ("sd_vae_decoder_create", _I, [C.POINTER(UNetConfig), _P, _I, C.POINTER(_P)]),
+    ("sd_vae_decode", _I, [_P, _P, _I, _FP, _I]),
     ("sd_op_attention", _I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _FP]),
     ("sd_op_layernorm", _I, [_P, _FP, _FP, _P, _I, _I, _I, _F, _I, _FP]),
     ("sd_op_groupnorm", _I, [_P, _FP, _FP, _P, _I, _I, _I, _I, _I, _F, _I, _I, _FP]),

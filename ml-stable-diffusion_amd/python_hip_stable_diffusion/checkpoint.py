@@ -126,6 +126,41 @@ def controlnet_param_shapes(cfg, cond_channels=(16, 32, 96, 256)):
     return sh
 
 
+def vae_decoder_param_shapes(cfg):
+    """AutoencoderKL decoder + post_quant_conv (diffusers >= 0.15 key names)."""
+    sh = OrderedDict()
+    boc = tuple(cfg["block_out_channels"])
+    cz, top = cfg["latent_channels"], boc[-1]
+
+    def resnet(p, cin, cout):
+        _norm(sh, p + ".norm1", cin)
+        _conv(sh, p + ".conv1", cin, cout, 3)
+        _norm(sh, p + ".norm2", cout)
+        _conv(sh, p + ".conv2", cout, cout, 3)
+        if cin != cout:
+            _conv(sh, p + ".conv_shortcut", cin, cout, 1)
+
+    _conv(sh, "post_quant_conv", cz, cz, 1)
+    _conv(sh, "decoder.conv_in", cz, top, 3)
+    resnet("decoder.mid_block.resnets.0", top, top)
+    a = "decoder.mid_block.attentions.0"
+    _norm(sh, a + ".group_norm", top)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        sh[f"{a}.{n}.weight"] = (top, top)
+        sh[f"{a}.{n}.bias"] = (top,)
+    resnet("decoder.mid_block.resnets.1", top, top)
+    cin = top
+    for i, cout in enumerate(reversed(boc)):
+        for j in range(cfg["layers_per_block"] + 1):
+            resnet(f"decoder.up_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout)
+        if i != len(boc) - 1:
+            _conv(sh, f"decoder.up_blocks.{i}.upsamplers.0.conv", cout, cout, 3)
+        cin = cout
+    _norm(sh, "decoder.conv_norm_out", boc[0])
+    _conv(sh, "decoder.conv_out", boc[0], cfg["out_channels"], 3)
+    return sh
+
+
 def validate_checkpoint(tensors, shapes):
     """Strict key/shape check (Linear weights may be stored 2-D, unet.py:121-127)."""
     missing = [k for k in shapes if k not in tensors]

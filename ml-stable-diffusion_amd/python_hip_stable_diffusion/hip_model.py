@@ -314,3 +314,76 @@ class HipModel:
             self.close()
         except Exception:
             pass
+
+
+VAE_CONFIGS = {   # public AutoencoderKL config of SD 1.x / 2.x (decoder side)
+    "stabilityai/stable-diffusion-2-1-base": dict(latent_channels=4, out_channels=3,
+                                                   block_out_channels=(128, 256, 512, 512), layers_per_block=2),
+}
+VAE_CONFIGS["runwayml/stable-diffusion-v1-5"] = VAE_CONFIGS["stabilityai/stable-diffusion-2-1-base"]
+
+
+class HipVaeDecoder:
+    """``vae_decoder`` model runner: ``decoder(post_quant_conv(z))`` (torch2coreml.py:584-594) behind
+    the CoreMLModel interface: ``expected_inputs["z"]`` (pipeline.py:315) and
+    ``model(z=...)["image"]`` in [-1, 1] (pipeline.py:316), NCHW fp32."""
+
+    def __init__(self, config, weights, batch=1, latent_height=64, latent_width=64, device=0, use_graph=True,
+                 dtype=np.float16):
+        if isinstance(config, str):
+            if config not in VAE_CONFIGS:
+                raise ValueError(f"unknown VAE config {config!r}")
+            config = VAE_CONFIGS[config]
+        self.config = dict(config)
+        boc = tuple(config["block_out_channels"])
+        c = _lib.UNetConfig()
+        c.batch, c.in_channels, c.out_channels = batch, config["latent_channels"], config["out_channels"]
+        c.height, c.width, c.n_levels = latent_height, latent_width, len(boc)
+        _fill(c.block_out_channels, boc)
+        c.layers_per_block = config["layers_per_block"]
+        c.norm_num_groups, c.norm_eps = 32, 1e-6
+        c.use_graph = int(use_graph)
+        own = not isinstance(weights, Weights)
+        wstore = weights if not own else (Weights(safetensors_path=weights) if isinstance(weights, (str, bytes))
+                                          else Weights(tensors=weights))
+        self._h = C.c_void_p()
+        try:
+            _lib.check(_lib.lib().sd_vae_decoder_create(C.byref(c), wstore._h, device, C.byref(self._h)))
+        finally:
+            if own:
+                wstore.close()
+        self.batch, self.latent_height, self.latent_width = batch, latent_height, latent_width
+        up = 2 ** (len(boc) - 1)
+        self.image_shape = (batch, config["out_channels"], latent_height * up, latent_width * up)
+        self.expected_inputs = {"z": {"shape": (batch, config["latent_channels"], latent_height, latent_width),
+                                      "dtype": np.dtype(dtype)}}
+
+    _verify_inputs = HipModel._verify_inputs
+
+    def __call__(self, **kwargs):
+        self._verify_inputs(**kwargs)
+        z = np.ascontiguousarray(kwargs["z"])
+        image = np.empty(self.image_shape, np.float32)
+        _lib.check(_lib.lib().sd_vae_decode(self._h, _lib.ptr(z), 1 if z.dtype == np.float32 else 0,
+                                            _lib.fptr(image), 0))
+        return {"image": image}
+
+    def time_forward(self, warmup=1, iters=5):
+        ms = C.c_float(0)
+        _lib.check(_lib.lib().sd_unet_time_forward(self._h, warmup, iters, C.byref(ms)))
+        return ms.value
+
+    @property
+    def device_bytes(self):
+        return _lib.lib().sd_unet_device_bytes(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().sd_unet_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,107 @@
+"""Oracle (test infrastructure): AutoencoderKL decoder (SD 1.x / 2.x VAE), torch-CPU fp32.
+
+Third-party arithmetic: the reference wraps diffusers' ``AutoencoderKL`` as
+``decoder(post_quant_conv(z))`` (python_coreml_stable_diffusion/torch2coreml.py:584-594) and
+calls it from pipeline.py:313-320.  diffusers is not available offline and the reference pins the
+decoder only by a live PSNR >= 35 dB check against diffusers (torch2coreml.py:631-639), so this
+restatement of the public architecture is **PARITY UNPINNED**:
+  post_quant_conv 1x1 -> conv_in 3x3 -> mid [ResNet, 1-head self-attention (group_norm 32,
+  eps 1e-6, Linear q/k/v/out with bias, residual), ResNet] -> up blocks (layers_per_block+1
+  ResNets, nearest-x2 + conv3x3 after all but the last; ResNet eps 1e-6, no time embedding,
+  conv_shortcut 1x1 when channels change) -> GroupNorm(32, 1e-6) -> SiLU -> conv_out 3x3.
+Key names follow diffusers >= 0.15 (``decoder.mid_block.attentions.0.to_q`` ...).
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+VAE_CONFIGS = {
+    "sd": dict(latent_channels=4, out_channels=3, block_out_channels=(128, 256, 512, 512), layers_per_block=2),
+    "mini": dict(latent_channels=4, out_channels=3, block_out_channels=(64, 64, 128, 128), layers_per_block=1),
+}
+
+
+def vae_decoder_param_shapes(cfg):
+    sh = OrderedDict()
+
+    def conv(name, cin, cout, k):
+        sh[name + ".weight"] = (cout, cin, k, k)
+        sh[name + ".bias"] = (cout,)
+
+    def norm(name, c):
+        sh[name + ".weight"] = (c,)
+        sh[name + ".bias"] = (c,)
+
+    def resnet(p, cin, cout):
+        norm(p + ".norm1", cin)
+        conv(p + ".conv1", cin, cout, 3)
+        norm(p + ".norm2", cout)
+        conv(p + ".conv2", cout, cout, 3)
+        if cin != cout:
+            conv(p + ".conv_shortcut", cin, cout, 1)
+
+    boc = cfg["block_out_channels"]
+    cz, top = cfg["latent_channels"], boc[-1]
+    conv("post_quant_conv", cz, cz, 1)
+    conv("decoder.conv_in", cz, top, 3)
+    resnet("decoder.mid_block.resnets.0", top, top)
+    a = "decoder.mid_block.attentions.0"
+    norm(a + ".group_norm", top)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        sh[f"{a}.{n}.weight"] = (top, top)
+        sh[f"{a}.{n}.bias"] = (top,)
+    resnet("decoder.mid_block.resnets.1", top, top)
+    cin = top
+    for i, cout in enumerate(reversed(boc)):
+        for j in range(cfg["layers_per_block"] + 1):
+            resnet(f"decoder.up_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout)
+        if i != len(boc) - 1:
+            conv(f"decoder.up_blocks.{i}.upsamplers.0.conv", cout, cout, 3)
+        cin = cout
+    norm("decoder.conv_norm_out", boc[0])
+    conv("decoder.conv_out", boc[0], cfg["out_channels"], 3)
+    return sh
+
+
+def _conv(sd, name, x, padding=0):
+    return F.conv2d(x, sd[name + ".weight"], sd[name + ".bias"], padding=padding)
+
+
+def _gn(sd, name, x):
+    return F.group_norm(x, 32, sd[name + ".weight"], sd[name + ".bias"], 1e-6)
+
+
+def _resnet(sd, p, x):
+    h = _conv(sd, p + ".conv1", F.silu(_gn(sd, p + ".norm1", x)), 1)
+    h = _conv(sd, p + ".conv2", F.silu(_gn(sd, p + ".norm2", h)), 1)
+    if p + ".conv_shortcut.weight" in sd:
+        x = _conv(sd, p + ".conv_shortcut", x)
+    return x + h
+
+
+@torch.no_grad()
+def vae_decode(sd, cfg, z):
+    """z (B, 4, h, w) = latents / scaling_factor -> image (B, 3, 8h, 8w) in [-1, 1]."""
+    x = _conv(sd, "post_quant_conv", z.float())
+    x = _conv(sd, "decoder.conv_in", x, 1)
+    x = _resnet(sd, "decoder.mid_block.resnets.0", x)
+    a = "decoder.mid_block.attentions.0"
+    b, c, h, w = x.shape
+    t = _gn(sd, a + ".group_norm", x).reshape(b, c, h * w).transpose(1, 2)          # (B, S, C)
+    q = F.linear(t, sd[a + ".to_q.weight"], sd[a + ".to_q.bias"])
+    k = F.linear(t, sd[a + ".to_k.weight"], sd[a + ".to_k.bias"])
+    v = F.linear(t, sd[a + ".to_v.weight"], sd[a + ".to_v.bias"])
+    p = torch.softmax(q @ k.transpose(1, 2) * c ** -0.5, dim=-1)
+    o = F.linear(p @ v, sd[a + ".to_out.0.weight"], sd[a + ".to_out.0.bias"])
+    x = x + o.transpose(1, 2).reshape(b, c, h, w)
+    x = _resnet(sd, "decoder.mid_block.resnets.1", x)
+    n = len(cfg["block_out_channels"])
+    for i in range(n):
+        for j in range(cfg["layers_per_block"] + 1):
+            x = _resnet(sd, f"decoder.up_blocks.{i}.resnets.{j}", x)
+        if i != n - 1:
+            x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+            x = _conv(sd, f"decoder.up_blocks.{i}.upsamplers.0.conv", x, 1)
+    x = F.silu(_gn(sd, "decoder.conv_norm_out", x))
+    return _conv(sd, "decoder.conv_out", x, 1)

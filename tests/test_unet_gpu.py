@@ -176,3 +176,25 @@ def test_full_sd21_base_matches_reference_golden():
         p = psnr.compute_psnr(y, g["noise_pred"])
         assert p >= 60.0, f"sd21-base {impl}: PSNR {p:.1f} dB vs reference golden"
     model.close()
+
+
+@pytest.mark.parametrize("name,hw", [("mini", 8), ("sd", 16)])
+def test_vae_decoder_matches_oracle(name, hw):
+    """decoder(post_quant_conv(z)) (torch2coreml.py:584-594).  The oracle restates diffusers'
+    AutoencoderKL from the public architecture (PARITY UNPINNED: no golden exists offline)."""
+    from oracle import vae_ref
+    from python_hip_stable_diffusion import HipVaeDecoder
+    cfg = vae_ref.VAE_CONFIGS[name]
+    shapes = vae_ref.vae_decoder_param_shapes(cfg)
+    sd16 = weights.make_state_dict(shapes, seed=61, dtype=np.float16, gain=1.6)
+    sd = weights.to_torch({k: v.astype(np.float32) for k, v in sd16.items()})
+    vae = HipVaeDecoder(cfg, sd16, batch=1, latent_height=hw, latent_width=hw)
+    z = (weights.seeded_normal((1, 4, hw, hw), 62) / 0.18215).astype(np.float16)     # pipeline.py:314
+    out = vae(z=z)["image"]
+    ref = vae_ref.vae_decode(sd, cfg, torch.from_numpy(z.astype(np.float32))).numpy()
+    assert out.shape == ref.shape == (1, 3, hw * 8, hw * 8)
+    p = psnr.compute_psnr(out, ref)
+    assert p >= 50.0, f"VAE decoder {name}: PSNR {p:.1f} dB"
+    with pytest.raises(TypeError):
+        vae(z=z.astype(np.float32))
+    vae.close()
