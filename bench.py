@@ -145,11 +145,41 @@ def main():
         "e2e": {"model_build_s": round(build_s, 1), "final_latents_finite": True,
                 "gathered_latents": list(all_final.shape), "hbm_bytes": int(model.device_bytes)},
     }
+    if world == 1:   # end-to-end latency of one generation: 20 DDIM steps + VAE decode (pipeline.py:500-589)
+        out["e2e"].update(e2e_latency(model, checkpoint, my_ehs[[0, ppg]], latents[:1], args.guidance_scale,
+                                      local_rank))
     if world == 1 and args.cpu_steps > 0:
         out["cpu_baseline"] = cpu_baseline(ckpt, my_ehs[[0, ppg]], latents[:1], args.cpu_steps, args.guidance_scale)
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def e2e_latency(model, checkpoint, ehs, latents, guidance, device):
+    """Median of 3 back-to-back generations (README.md:79-91 methodology): 20 steps + VAE decode."""
+    from python_hip_stable_diffusion import HipVaeDecoder, VAE_CONFIGS, schedulers
+    if model.batch != 2:
+        return {}
+    vcfg = VAE_CONFIGS[MODEL]
+    vae = HipVaeDecoder(vcfg, checkpoint.random_checkpoint(checkpoint.vae_decoder_param_shapes(vcfg), seed=1),
+                        batch=1, latent_height=64, latent_width=64, device=device)
+    sch = schedulers.DDIMScheduler()
+    sch.set_timesteps(20)
+    ts, coef, hist = sch.device_tables()
+    times, vae_ms = [], []
+    for i in range(4):
+        t0 = time.perf_counter()
+        lat, _ = model.denoise_loop(latents, ts, coef, guidance, history=hist, encoder_hidden_states=ehs)
+        t1 = time.perf_counter()
+        img = vae(z=(lat / 0.18215).astype(np.float16))["image"]
+        t2 = time.perf_counter()
+        if i:
+            times.append(t2 - t0)
+            vae_ms.append((t2 - t1) * 1e3)
+    assert np.isfinite(img).all()
+    vae.close()
+    return {"latency_20_steps_plus_vae_s": round(float(np.median(times)), 4), "vae_decode_ms": round(float(np.median(vae_ms)), 2),
+            "note": "prompt embedding given; 20 DDIM steps device-resident + fp16 VAE decode to 512x512, host wall clock"}
 
 
 def cpu_baseline(ckpt, ehs, latents, n_steps, guidance):

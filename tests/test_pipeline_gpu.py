@@ -1,0 +1,97 @@
+"""End-to-end pipeline (prompt -> latents -> image) through HipStableDiffusionPipeline with the
+reference's call surface (pipeline.py:403-589), against the same loop driven by the oracle UNet /
+oracle VAE.  The CLIP text encoder is third-party and not part of the hot path: a deterministic
+stand-in with the CoreMLModel interface supplies `last_hidden_state`."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import psnr, scheduler_ref, unet_ref, vae_ref, weights
+from python_hip_stable_diffusion import HipModel, HipVaeDecoder, schedulers
+from python_hip_stable_diffusion.pipeline import HipStableDiffusionPipeline
+
+pytestmark = pytest.mark.gpu
+
+
+class StubTokenizer:
+    model_max_length = 77
+
+    def __call__(self, text, padding=None, max_length=None, truncation=None, return_tensors=None):
+        ids = np.zeros((1, 77), np.int64)
+        for i, ch in enumerate(text.encode()[:75]):
+            ids[0, i + 1] = ch
+        return type("Enc", (), {"input_ids": ids})()
+
+
+class StubTextEncoder:
+    def __init__(self, dim):
+        self.dim = dim
+        self.expected_inputs = {"input_ids": {"shape": (1, 77), "dtype": np.dtype(np.float32)}}
+
+    def __call__(self, input_ids):
+        assert input_ids.dtype == np.float32                       # pipeline.py:173
+        rs = np.random.RandomState(int(input_ids.sum()) % (2 ** 31))
+        return {"last_hidden_state": rs.randn(1, 77, self.dim).astype(np.float32)}
+
+
+def build(cfg_name="mini"):
+    cfg = unet_ref.CONFIGS[cfg_name]
+    sd16 = weights.make_state_dict(unet_ref.unet_param_shapes(cfg), seed=21, dtype=np.float16)
+    vcfg = vae_ref.VAE_CONFIGS["mini"]
+    vsd16 = weights.make_state_dict(vae_ref.vae_decoder_param_shapes(vcfg), seed=61, dtype=np.float16, gain=1.6)
+    hw = cfg["sample_size"]
+    unet = HipModel(cfg, sd16, batch=2, attention_implementation="SPLIT_EINSUM")
+    vae = HipVaeDecoder(vcfg, vsd16, batch=1, latent_height=hw, latent_width=hw)
+    pipe = HipStableDiffusionPipeline(StubTextEncoder(cfg["cross_attention_dim"]), unet, vae, schedulers.DDIMScheduler(),
+                                      StubTokenizer(), force_zeros_for_empty_prompt=False)
+    return pipe, cfg, sd16, vcfg, vsd16
+
+
+def test_prompt_to_image_matches_oracle_pipeline():
+    pipe, cfg, sd16, vcfg, vsd16 = build()
+    prompt, seed, steps, g = "a high quality photo of an astronaut riding a horse in space", 93, 5, 7.5
+    out = pipe(prompt, num_inference_steps=steps, guidance_scale=g, seed=seed)
+    hw = cfg["sample_size"]
+    assert out.images.shape == (1, hw * 8, hw * 8, 3) and out.images.min() >= 0 and out.images.max() <= 1
+    assert out.step_ms is not None and len(out.step_ms) == steps          # device-resident loop was used
+    # oracle pipeline on the same (prompt, seed, scheduler)
+    sd = weights.to_torch({k: v.astype(np.float32) for k, v in sd16.items()})
+    vsd = weights.to_torch({k: v.astype(np.float32) for k, v in vsd16.items()})
+    emb, _ = pipe._encode_prompt(prompt, None, True, None, None)
+    np.random.seed(seed)
+    lat0 = np.random.randn(1, 4, hw, hw).astype(np.float16)                # pipeline.py:331, :726
+
+    def unet(x, t, e):
+        return unet_ref.unet_forward(sd, cfg, torch.from_numpy(x.astype(np.float32)), torch.from_numpy(t.astype(np.float32)),
+                                     torch.from_numpy(e.astype(np.float32))).numpy()
+
+    lat = scheduler_ref.denoise_loop(unet, scheduler_ref.DDIM(), lat0.astype(np.float32), emb, steps, g)
+    img = vae_ref.vae_decode(vsd, vcfg, torch.from_numpy(lat / 0.18215)).numpy()
+    img = np.clip(img / 2 + 0.5, 0, 1).transpose(0, 2, 3, 1)               # pipeline.py:317-318
+    assert psnr.compute_psnr(out.latents, lat) >= 35.0
+    assert psnr.compute_psnr(out.images, img) >= 35.0                      # tests/test_stable_diffusion.py:33
+
+
+def test_callback_path_steps_through_the_boundary_and_agrees_with_device_loop():
+    pipe, cfg, *_ = build()
+    seen = []
+    a = pipe("a prompt", num_inference_steps=4, guidance_scale=7.5, seed=1, output_type="latent",
+             callback=lambda i, t, lat: seen.append((i, int(t), lat.copy())))
+    b = pipe("a prompt", num_inference_steps=4, guidance_scale=7.5, seed=1, output_type="latent")
+    assert [s[0] for s in seen] == [0, 1, 2, 3] and a.step_ms is None and b.step_ms is not None
+    assert psnr.compute_psnr(a.images, b.images) >= 60.0
+    assert np.array_equal(seen[-1][2], a.images)
+    c = pipe("a prompt", num_inference_steps=4, guidance_scale=7.5, seed=2, output_type="latent")
+    assert not np.array_equal(b.images, c.images)                           # the seed matters
+    d = pipe("a prompt", num_inference_steps=4, guidance_scale=7.5, seed=1, output_type="latent")
+    assert np.array_equal(b.images, d.images)                               # ... and is reproducible
+
+
+def test_pipeline_argument_checks_mirror_the_reference():
+    pipe, *_ = build()
+    with pytest.raises(NotImplementedError):          # pipeline.py:434-438
+        pipe(["a", "b"], num_inference_steps=2)
+    with pytest.raises(ValueError):                   # pipeline.py:359-382
+        pipe("a", num_inference_steps=2, callback_steps=0)
+    with pytest.raises(ValueError):
+        pipe(3, num_inference_steps=2)
