@@ -366,12 +366,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     return;
   } else {
     // acc[i][j][r]: n = n0 + (r&3) + 8*(r>>2) + 4*hi ; m = m0 + (lane&31)
+    if (a.splitk > 1) {   // fp32 partial slabs; bias/temb/residual are applied by splitk_reduce_kernel
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int m = m_blk + (wm * TM + i) * 32 + frow;
-      if (m >= a.M) continue;
-      const int b = m / a.HoWo;
-      if (a.splitk > 1) {
+      for (int i = 0; i < TM; ++i) {
+        const int m = m_blk + (wm * TM + i) * 32 + frow;
+        if (m >= a.M) continue;
         float* prow = a.partial + ((size_t)split * a.M + m) * a.N;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -383,58 +382,90 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
               *reinterpret_cast<floatx4*>(prow + n) = v;
             }
           }
-        continue;
       }
-      if (a.out_mode == kOutGeglu) {
-        if constexpr (TN % 2 == 0) {
-          const int NO = a.N >> 1;
+    } else {
+      // Stage the finished tile through LDS (free after the K loop) so that the global stores - and
+      // the residual loads - are whole 16-B-per-lane row segments instead of 32 scattered 16-B pieces
+      // per instruction (the scattered form cost ~11k cycles per 128x128 tile, prof_conv).
+      const bool geglu = a.out_mode == kOutGeglu;
+      constexpr int OW = BN;                 // staged tile width in halves (GEGLU uses the first BN/2)
+      constexpr int OROW = OW + 8;           // +16 B pad: conflict-free 16-B reads
+      half_t* ot = reinterpret_cast<half_t*>(smem);   // [BM][OROW]  (<= the K-loop buffers)
+      __syncthreads();                       // every wave is done with its last fragment reads
 #pragma unroll
-          for (int j = 0; j < TN; j += 2)
+      for (int i = 0; i < TM; ++i) {
+        const int ml = (wm * TM + i) * 32 + frow;
+        const int m = m_blk + ml;
+        const int b = (m < a.M) ? m / a.HoWo : 0;
+        if (geglu) {
+          if constexpr (TN % 2 == 0) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int nv = n_blk + (wn * TN + j) * 32 + 8 * q + 4 * hi;      // value rows (interleaved W)
-              const int ng = nv + 32;                                            // gate rows
-              if (ng < a.N) {
-                const int no = (n_blk + (wn * TN + j) * 32) / 2 + 8 * q + 4 * hi;
+            for (int j = 0; j < TN; j += 2)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int nl = (wn * TN + j) * 32 + 8 * q + 4 * hi;          // value rows (interleaved W)
+                const int nv = n_blk + nl, ng = nv + 32;
                 half4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                  float v = acc[i][j][4 * q + e] + (a.bias ? a.bias[nv + e] : 0.f);
-                  float g = acc[i][j + 1][4 * q + e] + (a.bias ? a.bias[ng + e] : 0.f);
+                  float v = acc[i][j][4 * q + e] + ((a.bias && ng < a.N) ? a.bias[nv + e] : 0.f);
+                  float g = acc[i][j + 1][4 * q + e] + ((a.bias && ng < a.N) ? a.bias[ng + e] : 0.f);
                   o[e] = (half_t)(v * gelu_erf(g));
                 }
-                *reinterpret_cast<half4*>(a.out + (size_t)m * NO + no) = o;
+                *reinterpret_cast<half4*>(ot + ml * OROW + (wn * TN + j) * 16 + 8 * q + 4 * hi) = o;
               }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int nl = (wn * TN + j) * 32 + 8 * q + 4 * hi;
+              const int n = n_blk + nl;
+              float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+              if (n < a.N) {
+                if (a.bias) {
+                  floatx4 bb = *reinterpret_cast<const floatx4*>(a.bias + n);
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) v[e] += bb[e];
+                }
+                if (a.temb) {
+                  floatx4 tt = *reinterpret_cast<const floatx4*>(a.temb + (size_t)b * a.temb_stride + n);
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) v[e] += tt[e];
+                }
+              }
+              if (a.res) {   // keep fp32 until the residual is added in the write-out pass
+                // (residual added below from a coalesced load; stage the fp32->fp16 value only when no residual)
+              }
+              half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+              *reinterpret_cast<half4*>(ot + ml * OROW + nl) = o;
             }
         }
-        continue;
       }
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = n_blk + (wn * TN + j) * 32 + 8 * q + 4 * hi;
-          if (n < a.N) {
-            float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-            if (a.bias) {
-              floatx4 bb = *reinterpret_cast<const floatx4*>(a.bias + n);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += bb[e];
-            }
-            if (a.temb) {
-              floatx4 tt = *reinterpret_cast<const floatx4*>(a.temb + (size_t)b * a.temb_stride + n);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += tt[e];
-            }
+      __syncthreads();
+      const int NO = geglu ? (a.N >> 1) : a.N;              // output row length
+      const int nb0 = geglu ? (n_blk >> 1) : n_blk;         // first output column of this tile
+      constexpr int OWC = OW / 8;                           // 16-B chunks per staged row (GEGLU: first half used)
+      const int wc = geglu ? OWC / 2 : OWC;
+      for (int idx = tid; idx < BM * wc; idx += 256) {
+        const int r = idx / wc, c = idx - r * wc;
+        const int m = m_blk + r, n = nb0 + c * 8;
+        if (m < a.M && n < NO) {
+          half8 v = *reinterpret_cast<const half8*>(ot + r * OROW + c * 8);
+          half_t* dst = a.out + (size_t)m * NO + n;
+          if (n + 8 <= NO) {
             if (a.res) {
-              half4 rr = *reinterpret_cast<const half4*>(a.res + (size_t)m * a.N + n);
+              const half8 rr = *reinterpret_cast<const half8*>(a.res + (size_t)m * NO + n);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+              for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
             }
-            half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-            *reinterpret_cast<half4*>(a.out + (size_t)m * a.N + n) = o;
+            *reinterpret_cast<half8*>(dst) = v;
+          } else {   // ragged last chunk (N % 8 == 4)
+            for (int e = 0; e < NO - n; ++e) dst[e] = a.res ? (half_t)((float)v[e] + (float)a.res[(size_t)m * NO + n + e]) : v[e];
           }
         }
+      }
     }
   }
   if (prof) {

@@ -112,6 +112,30 @@ Tensor UNet::conv(std::vector<Op>& ops, const std::string& name, const Tensor& x
                   bool silu_out) {
   const int cin = x.C + (x2 ? x2->C : 0);
   const bool geglu = out_mode == kOutGeglu;
+  const half_t* w = upload_conv_weight(name, cout, cin, k, geglu);
+  const float* b = bias ? upload_vec(name + ".bias", cout, geglu) : nullptr;
+  return conv_w(ops, name, w, b, x, x2, cout, k, stride, up, temb, res, out_mode, ldT, silu_out);
+}
+
+// Several bias-free 1x1 projections of the same input as ONE GEMM: weights stacked along Cout
+// (attn1.to_q | attn1.to_k, unet.py:93-95): fewer launches, bigger N, same arithmetic.
+Tensor UNet::conv_stacked(std::vector<Op>& ops, const std::vector<std::string>& names, const Tensor& x, int cout_each) {
+  const int cin = x.C, n = (int)names.size();
+  std::vector<half_t> host((size_t)n * cout_each * cin);
+  for (int i = 0; i < n; ++i) {
+    const HostTensor& t = ws_->get(names[i] + ".weight");
+    SD_REQUIRE(t.numel() == (size_t)cout_each * cin, kInvalidArgument, "%s.weight: bad shape", names[i].c_str());
+    for (size_t j = 0; j < t.numel(); ++j) host[(size_t)i * cout_each * cin + j] = (half_t)t.data[j];
+  }
+  half_t* d = arena_.alloc_n<half_t>(host.size());
+  SD_HIP(hipMemcpy(d, host.data(), host.size() * sizeof(half_t), hipMemcpyHostToDevice));
+  return conv_w(ops, names[0], d, nullptr, x, nullptr, n * cout_each, 1, 1, 1, nullptr, nullptr, kOutHalf, 0, false);
+}
+
+Tensor UNet::conv_w(std::vector<Op>& ops, const std::string& name, const half_t* w, const float* bias, const Tensor& x,
+                    const Tensor* x2, int cout, int k, int stride, int up, const float* temb, const half_t* res,
+                    int out_mode, int ldT, bool silu_out) {
+  const bool geglu = out_mode == kOutGeglu;
   ConvDesc d;
   d.x0 = x.p;
   d.C0 = x.C;
@@ -120,8 +144,8 @@ Tensor UNet::conv(std::vector<Op>& ops, const std::string& name, const Tensor& x
     d.x1 = x2->p;
     d.C1 = x2->C;
   }
-  d.w = upload_conv_weight(name, cout, cin, k, geglu);
-  d.bias = bias ? upload_vec(name + ".bias", cout, geglu) : nullptr;
+  d.w = w;
+  d.bias = bias;
   d.temb = temb;
   d.temb_stride = kTembCap;
   d.res = res;
@@ -214,7 +238,7 @@ Tensor UNet::resnet(std::vector<Op>& ops, const std::string& p, const Tensor& x,
 }
 
 Tensor UNet::attention(std::vector<Op>& ops, const Tensor& q, const half_t* k, const half_t* vt, int heads, int Sq,
-                       int Sk, int ldk, int ldv) {
+                       int Sk, int ldk, int ldv, int ldq) {
   Tensor o = new_tensor(q.B, q.H, q.W, q.C);
   AttnDesc d;
   d.q = q.p;
@@ -226,7 +250,7 @@ Tensor UNet::attention(std::vector<Op>& ops, const Tensor& q, const half_t* k, c
   d.d = q.C / heads;
   d.Sq = Sq;
   d.Sk = Sk;
-  d.ldq = q.C;
+  d.ldq = ldq;
   d.ldk = ldk;
   d.ldv = ldv;
   d.ldo = q.C;
@@ -244,11 +268,12 @@ Tensor UNet::transformer_block(std::vector<Op>& ops, const std::string& b, const
   const int C = h.C, S = h.H * h.W, L = cfg_.context_len;
   // --- self attention
   Tensor n1 = layer_norm(ops, b + ".norm1", h);
-  Tensor q = conv(ops, b + ".attn1.to_q", n1, nullptr, C, 1, 1, 1, false, nullptr, nullptr);
-  Tensor k = conv(ops, b + ".attn1.to_k", n1, nullptr, C, 1, 1, 1, false, nullptr, nullptr);
+  Tensor qk = conv_stacked(ops, {b + ".attn1.to_q", b + ".attn1.to_k"}, n1, C);   // [M][2C]: q | k
   const int ldv = round_up(S, 8);
   Tensor vt = conv(ops, b + ".attn1.to_v", n1, nullptr, C, 1, 1, 1, false, nullptr, nullptr, kOutHalfT, ldv);
-  Tensor a1 = attention(ops, q, k.p, vt.p, heads, S, S, C, ldv);
+  Tensor q = qk;
+  q.C = C;   // logical width of q; rows are 2C apart
+  Tensor a1 = attention(ops, q, qk.p + C, vt.p, heads, S, S, 2 * C, ldv, 2 * C);
   Tensor h1 = conv(ops, b + ".attn1.to_out.0", a1, nullptr, C, 1, 1, 1, true, nullptr, h.p);
   // --- cross attention: K / V^T of the prompt are computed by ctx_ops_ when the prompt changes
   Tensor n2 = layer_norm(ops, b + ".norm2", h1);
@@ -256,7 +281,7 @@ Tensor UNet::transformer_block(std::vector<Op>& ops, const std::string& b, const
   const int ldvc = round_up(L, 8);
   Tensor k2 = conv(ctx_ops_, b + ".attn2.to_k", ctx_, nullptr, C, 1, 1, 1, false, nullptr, nullptr);
   Tensor vt2 = conv(ctx_ops_, b + ".attn2.to_v", ctx_, nullptr, C, 1, 1, 1, false, nullptr, nullptr, kOutHalfT, ldvc);
-  Tensor a2 = attention(ops, q2, k2.p, vt2.p, heads, S, L, C, ldvc);
+  Tensor a2 = attention(ops, q2, k2.p, vt2.p, heads, S, L, C, ldvc, C);
   Tensor h2 = conv(ops, b + ".attn2.to_out.0", a2, nullptr, C, 1, 1, 1, true, nullptr, h1.p);
   // --- GEGLU feed-forward
   Tensor n3 = layer_norm(ops, b + ".norm3", h2);

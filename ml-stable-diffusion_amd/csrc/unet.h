@@ -43,6 +43,10 @@ class UNet {
   Tensor conv(std::vector<Op>& ops, const std::string& name, const Tensor& x, const Tensor* x2, int cout, int k,
               int stride, int up, bool bias, const float* temb, const half_t* res, int out_mode = kOutHalf,
               int ldT = 0, bool silu_out = false);
+  Tensor conv_w(std::vector<Op>& ops, const std::string& name, const half_t* w, const float* bias, const Tensor& x,
+                const Tensor* x2, int cout, int k, int stride, int up, const float* temb, const half_t* res,
+                int out_mode, int ldT, bool silu_out);
+  Tensor conv_stacked(std::vector<Op>& ops, const std::vector<std::string>& names, const Tensor& x, int cout_each);
   Tensor group_norm(std::vector<Op>& ops, const std::string& name, const Tensor& x, const Tensor* x2, float eps,
                     bool silu);
   Tensor layer_norm(std::vector<Op>& ops, const std::string& name, const Tensor& x);
@@ -51,7 +55,7 @@ class UNet {
   Tensor transformer(std::vector<Op>& ops, const std::string& p, const Tensor& x, int heads, int depth);
   Tensor transformer_block(std::vector<Op>& ops, const std::string& b, const Tensor& h, int heads);
   Tensor attention(std::vector<Op>& ops, const Tensor& q, const half_t* k, const half_t* vt, int heads, int Sq,
-                   int Sk, int ldk, int ldv);
+                   int Sk, int ldk, int ldv, int ldq);
   void down_and_mid(std::vector<Op>& ops, Tensor& h, std::vector<Tensor>& skips);
   const float* register_temb(const std::string& name, int cout);
   void finalize_temb();
