@@ -14,6 +14,8 @@
 // The tile is computed TRANSPOSED (rows = n, cols = m) so each lane owns 4 consecutive output
 // channels of one pixel: bias / timestep-embedding / residual adds and the fp16 store are 8-byte
 // vector accesses with no cross-lane traffic.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace sd {
@@ -855,6 +857,10 @@ void launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
   }
   const bool trans = d.out_mode == kOutHalfT;
   const int st = d.staging;
+  static const bool log_plans = getenv("SD_LOG_CONVS") != nullptr;
+  if (log_plans)
+    fprintf(stderr, "[sd conv] k%d s%d up%d C0=%d C1=%d M=%d N=%d K=%d mode=%d tile=%d splitk=%d\n", a.ksize, a.stride, a.up,
+            a.C0, a.C1, a.M, a.N, a.K, d.out_mode, p.tile, a.splitk);
   if (d.debug) {   // ablation builds exist for two tiles only (tools/prof_conv.py)
     const bool ok = p.tile == 1 ? launch_debug_mode<128, 128>(a, d.debug, s) : launch_debug_mode<64, 64>(a, d.debug, s);
     SD_REQUIRE(ok && !trans, kInvalidArgument, "no ablation kernel for debug mode %d", d.debug);

@@ -26,45 +26,58 @@ __global__ void timestep_embedding_kernel(const float* __restrict__ t, const flo
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
 
-// out[b][n] (+)= act_out( sum_k W[n][k] * act_in(x[b][k]) + bias[n] ).  One wavefront per output
-// row n: the weight row is streamed once with 16-B loads (HBM-bound: this is the M<=8 regime where
-// an LDS round trip would be pure overhead), x stays in L1/L2.  B <= 8.
-template <int BMAX>
+// out[b][n] (+)= act_out( sum_k W[n][k] * act_in(x[b][k]) + bias[n] ), B <= BMAX rows of x.
+// Weight-streaming (HBM-bound, M <= 8: an LDS round trip would be pure overhead).  Each wavefront owns
+// GEMV_ROWS output rows: its slice of x (with the optional SiLU applied ONCE) lives in registers, weight
+// rows stream through with 16-B loads, two rows in flight, shuffle reduction per row.
+constexpr int GEMV_ROWS = 8;
+template <int BMAX, int GEMV_KITERS>   // K <= 64 lanes * 8 halves * GEMV_KITERS
 __global__ __launch_bounds__(256) void gemv_kernel(const half_t* __restrict__ w, const float* __restrict__ bias,
                                                    const float* __restrict__ x, int ldx, float* __restrict__ out,
                                                    int ldo, int B, int N, int K, int silu_in, int silu_out,
                                                    int accumulate) {
   const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= N) return;
-  float acc[BMAX];
+  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * GEMV_ROWS;
+  if (n0 >= N) return;
+  float xr[BMAX][GEMV_KITERS][8];
 #pragma unroll
-  for (int b = 0; b < BMAX; ++b) acc[b] = 0.f;
-  const half_t* wr = w + (size_t)n * K;
-  for (int k = lane * 8; k < K; k += 64 * 8) {
-    const half8 wv = *reinterpret_cast<const half8*>(wr + k);
+  for (int b = 0; b < BMAX; ++b)
 #pragma unroll
-    for (int b = 0; b < BMAX; ++b) {
-      if (b < B) {
+    for (int i = 0; i < GEMV_KITERS; ++i) {
+      const int k = (lane + 64 * i) * 8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float xv = x[(size_t)b * ldx + k + e];
-          if (silu_in) xv = silu_f(xv);
-          acc[b] += (float)wv[e] * xv;
-        }
+      for (int e = 0; e < 8; ++e) {
+        float v = (b < B && k < K) ? x[(size_t)b * ldx + k + e] : 0.f;
+        if (silu_in) v = silu_f(v);
+        xr[b][i][e] = v;
       }
     }
-  }
+  for (int r = 0; r < GEMV_ROWS; ++r) {
+    const int n = n0 + r;
+    if (n >= N) break;   // wave-uniform
+    const half_t* wr = w + (size_t)n * K;
+    half8 wv[GEMV_KITERS];
 #pragma unroll
-  for (int b = 0; b < BMAX; ++b) {
-    float v = acc[b];
+    for (int i = 0; i < GEMV_KITERS; ++i) {
+      const int k = (lane + 64 * i) * 8;
+      wv[i] = (k < K) ? *reinterpret_cast<const half8*>(wr + k) : half8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if (lane == 0 && b < B) {
-      v += bias ? bias[n] : 0.f;
-      if (silu_out) v = silu_f(v);
-      float* dst = out + (size_t)b * ldo + n;
-      *dst = accumulate ? (*dst + v) : v;
+    for (int b = 0; b < BMAX; ++b) {
+      if (b >= B) break;
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < GEMV_KITERS; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += (float)wv[i][e] * xr[b][i][e];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+      if (lane == 0) {
+        acc += bias ? bias[n] : 0.f;
+        if (silu_out) acc = silu_f(acc);
+        float* dst = out + (size_t)b * ldo + n;
+        *dst = accumulate ? (*dst + acc) : acc;
+      }
     }
   }
 }
@@ -194,11 +207,16 @@ void launch_timestep_embedding(const float* t, const float* freq, float* out, in
 
 void launch_gemv(const half_t* w, const float* bias, const float* x, int ldx, float* out, int ldo, int B, int N,
                  int K, int silu_in, int silu_out, int accumulate, hipStream_t s) {
-  SD_REQUIRE(K % 8 == 0, kUnsupported, "gemv: K=%d must be a multiple of 8", K);
-  for (int b0 = 0; b0 < B; b0 += 8) {
-    const int nb = std::min(8, B - b0);
-    hipLaunchKernelGGL(gemv_kernel<8>, dim3(cdiv(N, 4)), dim3(256), 0, s, w, bias, x + (size_t)b0 * ldx, ldx,
-                       out + (size_t)b0 * ldo, ldo, nb, N, K, silu_in, silu_out, accumulate);
+  SD_REQUIRE(K % 8 == 0 && K <= 64 * 8 * 6, kUnsupported, "gemv: K=%d must be a multiple of 8 and <= 3072", K);
+  const int blocks = cdiv(N, 4 * GEMV_ROWS);
+  for (int b0 = 0; b0 < B; b0 += 4) {   // 4 x-rows per pass keeps the register footprint at 4*6*8 floats
+    const int nb = std::min(4, B - b0);
+    if (K <= 64 * 8 * 3)
+      hipLaunchKernelGGL((gemv_kernel<4, 3>), dim3(blocks), dim3(256), 0, s, w, bias, x + (size_t)b0 * ldx, ldx,
+                         out + (size_t)b0 * ldo, ldo, nb, N, K, silu_in, silu_out, accumulate);
+    else
+      hipLaunchKernelGGL((gemv_kernel<4, 6>), dim3(blocks), dim3(256), 0, s, w, bias, x + (size_t)b0 * ldx, ldx,
+                         out + (size_t)b0 * ldo, ldo, nb, N, K, silu_in, silu_out, accumulate);
   }
   SD_HIP(hipGetLastError());
 }

@@ -13,6 +13,8 @@
 //               bitwise reproducible.  The apply pass folds the slabs in its prologue and fuses the
 //               affine, the optional SiLU (unet.py:473,481) and the channel concat of the up-block
 //               inputs (unet.py:213-216) into a single read-modify-write.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace sd {
@@ -249,6 +251,73 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const half_t* __re
   }
 }
 
+// Single-launch GroupNorm for the UNet-sized tensors (<= 128K elements per (sample, group)): one
+// workgroup per (group, sample) reads its strided channel slice twice (second pass from L2): fixed-order
+// reduction, then affine (+SiLU) and the concatenated store.  Replaces the two dependent launches of
+// the slab version - a UNet step is launch-latency-bound on its ~60 GroupNorms (~4 us per dependent
+// launch), not bandwidth-bound.  VW = halves per vector access (alignment of the group's channel run).
+template <int VW>
+__global__ __launch_bounds__(256) void groupnorm_fused_kernel(const half_t* __restrict__ x0, int C0,
+                                                              const half_t* __restrict__ x1, int C1,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, half_t* __restrict__ y,
+                                                              int HW, int G, float eps, int silu) {
+  typedef _Float16 vec_t __attribute__((ext_vector_type(VW)));
+  __shared__ float red[16];
+  __shared__ float s_sc[128], s_sh[128];
+  const int C = C0 + C1;
+  const int cpg = C / G;
+  const int g = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+  const int c0 = g * cpg;
+  const int nv = cpg / VW;                       // vectors per pixel
+  const int items = HW * nv;
+  float s = 0.f, q = 0.f;
+  for (int it = t; it < items; it += 256) {
+    const int p = it / nv, v = it - p * nv;
+    const int c = c0 + v * VW;
+    const half_t* src = (c < C0) ? x0 + ((size_t)b * HW + p) * C0 + c : x1 + ((size_t)b * HW + p) * C1 + (c - C0);
+    const vec_t h = *reinterpret_cast<const vec_t*>(src);
+#pragma unroll
+    for (int e = 0; e < VW; ++e) {
+      const float f = (float)h[e];
+      s += f;
+      q += f * f;
+    }
+  }
+  s = wave_sum(s);
+  q = wave_sum(q);
+  if ((t & 63) == 0) {
+    red[t >> 6] = s;
+    red[4 + (t >> 6)] = q;
+  }
+  __syncthreads();
+  s = (red[0] + red[1]) + (red[2] + red[3]);
+  q = (red[4] + red[5]) + (red[6] + red[7]);
+  const float inv_n = 1.0f / ((float)cpg * (float)HW);
+  const float mean = s * inv_n;
+  const float rstd = rsqrtf(fmaxf(q * inv_n - mean * mean, 0.f) + eps);
+  if (t < cpg) {
+    const float sc = rstd * gamma[c0 + t];
+    s_sc[t] = sc;
+    s_sh[t] = beta[c0 + t] - mean * sc;
+  }
+  __syncthreads();
+  for (int it = t; it < items; it += 256) {
+    const int p = it / nv, v = it - p * nv;
+    const int c = c0 + v * VW;
+    const half_t* src = (c < C0) ? x0 + ((size_t)b * HW + p) * C0 + c : x1 + ((size_t)b * HW + p) * C1 + (c - C0);
+    const vec_t h = *reinterpret_cast<const vec_t*>(src);
+    vec_t o;
+#pragma unroll
+    for (int e = 0; e < VW; ++e) {
+      float f = (float)h[e] * s_sc[v * VW + e] + s_sh[v * VW + e];
+      if (silu) f = f * __builtin_amdgcn_rcpf(1.0f + __expf(-f));
+      o[e] = (half_t)f;
+    }
+    *reinterpret_cast<vec_t*>(y + ((size_t)b * HW + p) * C + c) = o;
+  }
+}
+
 // One workgroup per row: row kept in registers (cols <= 256 threads * 4 chunks * 8), fp32 max / sum
 // with wave shuffles + LDS across the four waves.
 __global__ __launch_bounds__(256) void row_softmax_kernel(half_t* __restrict__ x, int cols, float scale_log2) {
@@ -331,6 +400,21 @@ void launch_groupnorm(const half_t* x0, int C0, const half_t* x1, int C1, float*
   if (!x1) C1 = 0;
   const int C = C0 + C1;
   SD_REQUIRE(C % G == 0 && C0 % 8 == 0 && C1 % 8 == 0 && G <= 64, kUnsupported, "groupnorm: C0=%d C1=%d G=%d", C0, C1, G);
+  const int cpg = C / G;
+  // measured crossover (tools/gn_sweep.py): the single launch wins for HW <= 256 (3.5-11 us vs 10-23 us), the
+  // slab pair wins at 32x32 and above (8-16 us vs 13-208 us).  SD_GN_FUSED_MAX_HW overrides for tuning.
+  static const long fused_max_hw = getenv("SD_GN_FUSED_MAX_HW") ? atol(getenv("SD_GN_FUSED_MAX_HW")) : 256;
+  if (HW <= fused_max_hw && cpg <= 128 && cpg % 2 == 0) {
+    dim3 grid(G, B);
+    if (cpg % 8 == 0)
+      hipLaunchKernelGGL(groupnorm_fused_kernel<8>, grid, dim3(256), 0, s, x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu);
+    else if (cpg % 4 == 0)
+      hipLaunchKernelGGL(groupnorm_fused_kernel<4>, grid, dim3(256), 0, s, x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu);
+    else
+      hipLaunchKernelGGL(groupnorm_fused_kernel<2>, grid, dim3(256), 0, s, x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu);
+    SD_HIP(hipGetLastError());
+    return;
+  }
   int slabs = groupnorm_num_slabs(B, HW);
   const int ppb = cdiv(HW, slabs);
   slabs = cdiv(HW, ppb);   // <= groupnorm_num_slabs

@@ -94,6 +94,8 @@ def _maxdiff(a, b):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also write the full SD2.1-base golden")
+    ap.add_argument("--xl", action="store_true", help="also write the SDXL-base 768x768 golden (2.6 B params)")
+    ap.add_argument("--control", action="store_true", help="also write the SD1.5 control-UNet golden")
     args = ap.parse_args()
     os.makedirs(GOLDEN, exist_ok=True)
     torch.set_grad_enabled(False)
@@ -152,7 +154,7 @@ def main():
     np.savez_compressed(os.path.join(GOLDEN, "timestep_golden.npz"), t=t.numpy(), out=ref)
 
     # ---- 4. UNets: oracle == reference on seeded synthetic checkpoints; golden outputs ----------
-    def run_unet(name, seed, impl_enum, full=False):
+    def run_unet(name, seed, impl_enum, full=False, hw=None):
         cfg = unet_ref.CONFIGS[name]
         xl = cfg["addition_embed_type"] == "text_time"
         shapes = unet_ref.unet_param_shapes(cfg)
@@ -165,7 +167,7 @@ def main():
         for k_, v_ in model.state_dict().items():
             assert tuple(v_.shape) == tuple(shapes[k_]), (k_, v_.shape, shapes[k_])
         model.load_state_dict({k_: v_.clone() for k_, v_ in sd.items()})
-        hw = cfg["sample_size"]
+        hw = hw or cfg["sample_size"]
         bsz = 2
         sample = weights.seeded_normal((bsz, 4, hw, hw), seed + 1)
         ehs = weights.seeded_normal((bsz, cfg["cross_attention_dim"], 1, 77), seed + 2)
@@ -186,7 +188,7 @@ def main():
         res = None
         if cfg["support_controlnet"]:
             res = [0.1 * weights.seeded_normal(s_, seed + 10 + i).astype(np.float16).astype(np.float32)
-                   for i, s_ in enumerate(unet_ref.residual_shapes(cfg, bsz))]
+                   for i, s_ in enumerate(unet_ref.residual_shapes(cfg, bsz, hw, hw))]
             extra_t += [torch.from_numpy(r) for r in res]
         out = {}
         for impl in ("ORIGINAL", "SPLIT_EINSUM", "SPLIT_EINSUM_V2"):
@@ -212,8 +214,11 @@ def main():
         for k_, v_ in extra.items():
             g[k_] = v_
         if res is not None:
-            for i, r in enumerate(res):
-                g[f"additional_residual_{i}"] = r.astype(np.float16)
+            if full:   # full-size residuals are regenerated from their seeds by the test (keeps the fixture small)
+                g["residuals_from_seed"] = np.array(1)
+            else:
+                for i, r in enumerate(res):
+                    g[f"additional_residual_{i}"] = r.astype(np.float16)
         np.savez_compressed(os.path.join(GOLDEN, f"unet_{name}_golden.npz"), **g)
         return nparams
 
@@ -224,6 +229,12 @@ def main():
         n = run_unet("sd21-base", 0, None, full=True)
         assert n == 865_910_724, n            # 865.91 M parameters
         report.append(f"  sd21-base: {n / 1e6:.2f} M params")
+    if args.xl:                               # BASELINE config 4: SDXL-base at 768x768 (96x96 latents)
+        n = run_unet("sdxl-base", 5, None, full=True, hw=96)
+        report.append(f"  sdxl-base @96x96: {n / 1e6:.2f} M params")
+    if args.control:                          # BASELINE config 5: SD1.5 control-UNet (heads 8 -> d_head 40/80/160)
+        n = run_unet("sd15-control", 7, None, full=True)
+        report.append(f"  sd15-control: {n / 1e6:.2f} M params")
 
     # ---- 5. ControlNet ---------------------------------------------------------------------------
     cfg = unet_ref.CONFIGS["mini-control"]
@@ -258,6 +269,34 @@ def main():
     for i, r in enumerate(ref):
         g[f"additional_residual_{i}"] = r.astype(np.float32)
     np.savez_compressed(os.path.join(GOLDEN, "controlnet_mini_golden.npz"), **g)
+
+    if args.control:
+        cfgc = unet_ref.CONFIGS["sd15-control"]
+        shapes = unet_ref.controlnet_param_shapes(cfgc)
+        sd = weights.to_torch(weights.round_to_fp16(weights.make_state_dict(shapes, seed=71)))
+        kwc = {k_: cfgc[k_] for k_ in ("in_channels", "block_out_channels", "down_block_types", "layers_per_block",
+                                        "attention_head_dim", "cross_attention_dim", "transformer_layers_per_block",
+                                        "norm_num_groups", "norm_eps", "flip_sin_to_cos", "freq_shift")}
+        modelc = cn.ControlNetModel(**kwc).eval()
+        modelc.load_state_dict({k_: v_.clone() for k_, v_ in sd.items()})
+        hwc = 64
+        samplec = weights.seeded_normal((2, 4, hwc, hwc), 72).astype(np.float16).astype(np.float32)
+        ehsc = weights.seeded_normal((2, 768, 1, 77), 73).astype(np.float16).astype(np.float32)
+        condc = np.random.RandomState(74).rand(2, 3, 512, 512).astype(np.float16).astype(np.float32)
+        downc, midc = modelc(torch.from_numpy(samplec).clone(), torch.from_numpy(ts), torch.from_numpy(ehsc),
+                             torch.from_numpy(condc))
+        refc = [r.numpy() for r in downc] + [midc.numpy()]
+        minec = unet_ref.controlnet_forward(sd, cfgc, torch.from_numpy(samplec), torch.from_numpy(ts),
+                                            torch.from_numpy(ehsc), torch.from_numpy(condc))
+        worst = max(_maxdiff(a_, b_.numpy()) for a_, b_ in zip(refc, minec))
+        assert worst < 5e-5, worst
+        report.append(f"controlnet sd15 (361.3 M params): 13 residuals, max|oracle-ref| {worst:.2e}")
+        # fixture: inputs are regenerated from seeds by the test; store only the (strided) outputs
+        gc = dict(seed=np.array(71), stride=np.array(16))
+        for i, r in enumerate(refc):
+            gc[f"additional_residual_{i}"] = r[:, ::16].astype(np.float16)    # every 16th channel: keeps the fixture small
+        np.savez_compressed(os.path.join(GOLDEN, "controlnet_sd15_golden.npz"), **gc)
+        del modelc, sd
 
     # ---- 6. numpy legacy RNG golden (StableDiffusionTests.swift:52-62) ---------------------------
     r = rng_ref.NumpyLegacyRandom(rng_ref.GOLDEN_SEED).randn(rng_ref.GOLDEN_COUNT)

@@ -198,3 +198,59 @@ def test_vae_decoder_matches_oracle(name, hw):
     with pytest.raises(TypeError):
         vae(z=z.astype(np.float32))
     vae.close()
+
+
+def test_full_sdxl_base_768_matches_reference_golden():
+    """BASELINE config 4 (UNet part): SDXL-base, 96x96 latents (768x768), text_time add-embedding,
+    transformer depth (1,2,10), 2.57 B parameters.  S_q = 9216 / 2304 are not multiples of 512,
+    so SPLIT_EINSUM_V2 is rejected loudly instead of dropping the tail like attention.py:86."""
+    g = load_golden("unet_sdxl-base_golden.npz")
+    cfg = unet_ref.CONFIGS["sdxl-base"]
+    sd = synthetic_checkpoint(unet_ref.unet_param_shapes(cfg), int(g["seed"]))
+    model = HipModel("stabilityai/stable-diffusion-xl-base-1.0", sd, batch=2, latent_height=96, latent_width=96,
+                     attention_implementation="ORIGINAL")
+    del sd
+    assert model.expected_inputs["time_ids"]["shape"] == (2, 6) and model.expected_inputs["text_embeds"]["shape"] == (2, 1280)
+    kw = golden_inputs(g, model)
+    for impl in ("ORIGINAL", "SPLIT_EINSUM"):
+        model.set_attention_implementation(impl)
+        y = model(**kw)["noise_pred"]
+        p = psnr.compute_psnr(y, g["noise_pred"])
+        assert p >= 60.0, f"sdxl-base {impl}: PSNR {p:.1f} dB vs reference golden"
+    model.set_attention_implementation("SPLIT_EINSUM_V2")
+    with pytest.raises(ValueError, match="512"):
+        model(**kw)
+    model.close()
+
+
+def test_full_sd15_control_unet_and_controlnet_match_reference_golden():
+    """BASELINE config 5: SD1.5 (8 heads -> head dims 40/80/160) control-UNet consuming 13 residuals,
+    and the SD1.5 ControlNet producing them (controlnet.py:199-250)."""
+    g = load_golden("unet_sd15-control_golden.npz")
+    cfg = unet_ref.CONFIGS["sd15-control"]
+    seed = int(g["seed"])
+    sd = synthetic_checkpoint(unet_ref.unet_param_shapes(cfg), seed)
+    model = HipModel(cfg, sd, batch=2, attention_implementation="SPLIT_EINSUM")
+    del sd
+    kw = dict(sample=g["sample"].astype(np.float16), timestep=g["timestep"].astype(np.float16),
+              encoder_hidden_states=g["encoder_hidden_states"].astype(np.float16))
+    for i, s_ in enumerate(unet_ref.residual_shapes(cfg, 2)):
+        kw[f"additional_residual_{i}"] = (0.1 * weights.seeded_normal(s_, seed + 10 + i)).astype(np.float16)
+    assert set(kw) == set(model.expected_inputs)
+    y = model(**kw)["noise_pred"]
+    p = psnr.compute_psnr(y, g["noise_pred"])
+    assert p >= 60.0, f"sd15 control-UNet: PSNR {p:.1f} dB vs reference golden"
+    model.close()
+
+    gc = load_golden("controlnet_sd15_golden.npz")
+    cn = HipModel(cfg, synthetic_checkpoint(unet_ref.controlnet_param_shapes(cfg), int(gc["seed"])), kind="controlnet",
+                  batch=2, attention_implementation="ORIGINAL")
+    out = cn(sample=weights.seeded_normal((2, 4, 64, 64), 72).astype(np.float16), timestep=np.array([981, 981], np.float16),
+             encoder_hidden_states=weights.seeded_normal((2, 768, 1, 77), 73).astype(np.float16),
+             controlnet_cond=np.random.RandomState(74).rand(2, 3, 512, 512).astype(np.float16))
+    stride = int(gc["stride"])
+    for i in range(13):
+        ref = gc[f"additional_residual_{i}"].astype(np.float32)
+        p = psnr.compute_psnr(out[f"additional_residual_{i}"][:, ::stride], ref)
+        assert p >= 50.0, f"sd15 ControlNet residual {i}: PSNR {p:.1f} dB"
+    cn.close()
