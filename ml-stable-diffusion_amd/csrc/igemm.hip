@@ -44,6 +44,7 @@ struct IgemmArgs {
   int debug;   // ablation (microbench only): bits 0-1: 1 = loads+barriers only, 2 = compute only; bit 2: timestamps
   long long* prof;
   const half_t* zeros;   // >= 16 B of zeros: source of padding / out-of-range rows
+  int tiles_x, tiles_y;  // halo kernel: 8x16-pixel output tiles per image
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
@@ -480,6 +481,241 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 3x3 / stride 1 convolution with an LDS-resident input HALO tile (resnet convs, unet.py:435-456).
+// The im2col kernel above re-fetches the activation tile once per tap (9x); its K step moves
+// 32 KB into LDS for 2 MFLOP, and the measured LDS fill rate (~40 GB/s per CU, tools/prof_conv.py) -
+// not the MFMA pipe - bounds it.  Here a workgroup owns an 8x16-pixel output tile: per 64-channel
+// chunk it stages the 10x18 halo ONCE (23 KB, reused by all nine taps) plus one 16-KB weight tile
+// per tap -> 167 KB instead of 288 KB per nine K steps.  The tap is a shift of the fragment's LDS
+// row; swizzle, MFMA tiling and the LDS-staged epilogue are those of igemm_kernel.  The next chunk's
+// halo streams in as one 1-KB DMA piece per wave per tap.
+// ---------------------------------------------------------------------------------------------
+constexpr int HALO_W = 18, HALO_ROWS = 180, HALO_PIECES = 23, HALO_LDS_ROWS = 184, HALO_PPW = 6;
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(IgemmArgs a) {
+  constexpr int BM = 128, TM = 2, TN = BN / 64, WR = BN / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* Xh = reinterpret_cast<half_t*>(smem);                  // [2][HALO_LDS_ROWS][BK]
+  half_t* Ws = Xh + 2 * HALO_LDS_ROWS * BK;                      // [2][BN][BK]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int H = a.Hi, W = a.Wi;
+
+  const int n_tiles = (a.N + BN - 1) / BN;
+  const int m_tiles = a.B * a.tiles_y * a.tiles_x;
+  const int nwg = m_tiles * n_tiles;
+  int bid = blockIdx.x;
+  {
+    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    bid = base + idx;
+  }
+  const int bn_idx = bid / m_tiles, mt = bid % m_tiles;
+  const int b = mt / (a.tiles_y * a.tiles_x);
+  const int trem = mt - b * (a.tiles_y * a.tiles_x);
+  const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+  const int y0 = ty * 8, x0 = tx * 16;
+  const int n_blk = bn_idx * BN;
+
+  const int nch = a.Ctot / BK;
+  const int split = blockIdx.y;
+  const int ch_begin = split * a.nk_per_split;          // split-K over channel chunks
+  int ch_end = ch_begin + a.nk_per_split;
+  if (ch_end > nch) ch_end = nch;
+
+  const half_t* const zeros = a.zeros;
+  // this wave's halo pieces p = wave + 4j (8 halo rows = 1 KiB each); lane -> (row, 16-B slot)
+  int hpix[HALO_PPW], hchunk[HALO_PPW];
+#pragma unroll
+  for (int j = 0; j < HALO_PPW; ++j) {
+    const int p = wave + 4 * j;
+    const int hr = 8 * p + (lane >> 3);
+    const int hy = hr / HALO_W, hx = hr - hy * HALO_W;
+    const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+    const bool ok = (hr < HALO_ROWS) && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    hpix[j] = ok ? (b * H + iy) * W + ix : -1;
+    hchunk[j] = (lane & 7) ^ ((hr >> 1) & 7);
+  }
+  const int pchunk = tid & 7, lrow = tid >> 3;
+  const int wchunk = pchunk ^ ((lrow >> 1) & 7);
+  const half_t* wrow[WR];
+#pragma unroll
+  for (int i = 0; i < WR; ++i) {
+    const int n = n_blk + lrow + 32 * i;
+    wrow[i] = (n < a.N) ? a.w + (size_t)n * a.K + wchunk * 8 : nullptr;
+  }
+
+  auto issue_x_piece = [&](int j, int ch, int xstage) {
+    const int p = wave + 4 * j;
+    if (p >= HALO_PIECES) return;                       // wave-uniform
+    int cc = ch * BK;
+    const half_t* src = a.x0;
+    int Csrc = a.C0;
+    if (cc >= a.C0) {
+      src = a.x1;
+      cc -= a.C0;
+      Csrc = a.C1;
+    }
+    const half_t* ptr = (hpix[j] >= 0) ? src + (size_t)hpix[j] * Csrc + cc + hchunk[j] * 8 : zeros;
+    char* dst = reinterpret_cast<char*>(Xh + xstage * HALO_LDS_ROWS * BK) + p * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ptr,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  auto issue_w = [&](int ch, int tap, int wstage) {
+    const int koff = tap * a.Ctot + ch * BK;
+    char* ws = reinterpret_cast<char*>(Ws + wstage * BN * BK) + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < WR; ++i) {
+      const half_t* ptr = wrow[i] ? wrow[i] + koff : zeros;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ptr,
+                                       (__attribute__((address_space(3))) void*)(ws + i * 4096), 16, 0, 0);
+    }
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frow = lane & 31, hi = lane >> 5;
+  const int fsw = (frow >> 1) & 7;
+  int hr0[TM];                                          // halo row of this lane's pixel for the (0,0) tap
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int ml = (wm * TM + i) * 32 + frow;
+    hr0[i] = (ml >> 4) * HALO_W + (ml & 15);
+  }
+
+  if (ch_begin < ch_end) {
+#pragma unroll
+    for (int j = 0; j < HALO_PPW; ++j) issue_x_piece(j, ch_begin, 0);
+    issue_w(ch_begin, 0, 0);
+  }
+  int step = 0;
+  for (int ch = ch_begin; ch < ch_end; ++ch) {
+    const int xst = (ch - ch_begin) & 1;
+    const bool next_chunk = ch + 1 < ch_end;
+    const half_t* xs = Xh + xst * HALO_LDS_ROWS * BK;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap, ++step) {
+      const int wst = step & 1;
+      __syncthreads();   // vmcnt(0) + barrier: this step's W tile (and halo pieces issued so far) have landed
+      const half_t* ws = Ws + wst * BN * BK + (wn * TN * 32 + frow) * BK;
+      const int toff = (tap / 3) * HALO_W + (tap % 3);
+      // keep the 72 (tap, k, tile) fragment addresses from being hoisted out of the chunk loop into
+      // registers (they would push the kernel past 256 VGPRs): re-derive them from hr0 at every tap
+#pragma unroll
+      for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(hr0[i]));
+      half8 xf[BK / 16][TM], wf[BK / 16][TN];
+#pragma unroll
+      for (int kk = 0; kk < BK / 16; ++kk) {
+        const int kc = kk * 2 + hi;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int hr = hr0[i] + toff;
+          xf[kk][i] = *reinterpret_cast<const half8*>(xs + hr * BK + ((kc ^ ((hr >> 1) & 7)) * 8));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wf[kk][j] = *reinterpret_cast<const half8*>(ws + j * 32 * BK + ((kc ^ fsw) * 8));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (tap < 8)
+        issue_w(ch, tap + 1, wst ^ 1);
+      else if (next_chunk)
+        issue_w(ch + 1, 0, wst ^ 1);
+      if (tap < HALO_PPW && next_chunk) issue_x_piece(tap, ch + 1, xst ^ 1);
+#pragma unroll
+      for (int kk = 0; kk < BK / 16; ++kk)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kk][j], xf[kk][i], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: acc[i][j][r]: n = n0 + (r&3) + 8*(r>>2) + 4*hi ; pixel = tile-local ml ----
+  if (a.splitk > 1) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int ml = (wm * TM + i) * 32 + frow;
+      const int y = y0 + (ml >> 4), x = x0 + (ml & 15);
+      if (y >= H || x >= W) continue;
+      const int m = (b * H + y) * W + x;
+      float* prow = a.partial + ((size_t)split * a.M + m) * a.N;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n_blk + (wn * TN + j) * 32 + 8 * q + 4 * hi;
+          if (n < a.N) {
+            floatx4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            *reinterpret_cast<floatx4*>(prow + n) = v;
+          }
+        }
+    }
+    return;
+  }
+  constexpr int OROW = BN + 8;
+  half_t* ot = reinterpret_cast<half_t*>(smem);   // [BM][OROW]
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int ml = (wm * TM + i) * 32 + frow;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int nl = (wn * TN + j) * 32 + 8 * q + 4 * hi;
+        const int n = n_blk + nl;
+        float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        if (n < a.N) {
+          if (a.bias) {
+            floatx4 bb = *reinterpret_cast<const floatx4*>(a.bias + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += bb[e];
+          }
+          if (a.temb) {
+            floatx4 tt = *reinterpret_cast<const floatx4*>(a.temb + (size_t)b * a.temb_stride + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += tt[e];
+          }
+        }
+        half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        *reinterpret_cast<half4*>(ot + ml * OROW + nl) = o;
+      }
+  }
+  __syncthreads();
+  constexpr int WC = BN / 8;
+  for (int idx = tid; idx < BM * WC; idx += 256) {
+    const int r = idx / WC, c = idx - r * WC;
+    const int y = y0 + (r >> 4), x = x0 + (r & 15);
+    const int n = n_blk + c * 8;
+    if (y < H && x < W && n < a.N) {
+      const size_t m = (size_t)(b * H + y) * W + x;
+      half8 v = *reinterpret_cast<const half8*>(ot + r * OROW + c * 8);
+      half_t* dst = a.out + m * a.N + n;
+      if (n + 8 <= a.N) {
+        if (a.res) {
+          const half8 rr = *reinterpret_cast<const half8*>(a.res + m * a.N + n);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
+        }
+        *reinterpret_cast<half8*>(dst) = v;
+      } else {
+        for (int e = 0; e < a.N - n; ++e) dst[e] = a.res ? (half_t)((float)v[e] + (float)a.res[m * a.N + n + e]) : v[e];
+      }
+    }
+  }
+}
+
 // split-K combine + the same epilogue (bias, temb broadcast, residual) -> fp16
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmArgs a) {
   const size_t total4 = (size_t)a.M * a.N / 4;
@@ -697,6 +933,8 @@ IgemmArgs make_args(const ConvDesc& d) {
   a.debug = d.debug;
   a.prof = d.prof;
   a.zeros = device_zero_chunk();
+  a.tiles_x = cdiv(d.Wi, 16);
+  a.tiles_y = cdiv(d.Hi, 8);
   return a;
 }
 
@@ -705,8 +943,16 @@ struct Plan {
   int splitk;
 };
 
+bool halo_ok(const ConvDesc& d) {
+  const int c1 = d.x1 ? d.C1 : 0;
+  return d.ksize == 3 && d.stride == 1 && d.up == 1 && d.out_mode == kOutHalf && d.Wi >= 16 && d.Hi >= 8 &&
+         d.C0 % BK == 0 && c1 % BK == 0 && d.N % 4 == 0;
+}
+
 void tile_dims(int tile, int& bm, int& bn) {
   switch (tile) {
+    case 5: bm = 128; bn = 128; break;   // halo kernel, 8x16-pixel tile
+    case 6: bm = 128; bn = 64; break;
     case 1: bm = 128; bn = 128; break;
     case 2: bm = 128; bn = 64; break;
     case 3: bm = 64; bn = 64; break;
@@ -734,14 +980,19 @@ Plan choose_plan(const ConvDesc& d, const IgemmArgs& a) {
   Plan p{d.tile, d.splitk};
   const bool geglu = d.out_mode == kOutGeglu;
   const bool can_split = d.out_mode == kOutHalf;
+  if ((p.tile == 5 || p.tile == 6) && !halo_ok(d)) p.tile = 0;
+  auto is_halo = [](int c) { return c == 5 || c == 6; };
   auto blocks_of = [&](int c) {
     int bm, bn;
     tile_dims(c, bm, bn);
-    return (long)cdiv(a.M, bm) * cdiv(a.N, bn);
+    const long mt = is_halo(c) ? (long)a.B * a.tiles_x * a.tiles_y : cdiv(a.M, bm);
+    return mt * cdiv(a.N, bn);
   };
-  auto max_split = [&]() {
+  auto ksteps = [&](int c) { return is_halo(c) ? a.Ctot / BK : a.nk_total; };   // split-K granularity
+  auto max_split = [&](int c) {
+    const int per_min = is_halo(c) ? 2 : 8;      // halo splits whole 64-channel chunks (9 K steps each)
     int s = 1;
-    while (can_split && s < 16 && a.nk_total / (s * 2) >= 8) s *= 2;
+    while (can_split && s < 16 && ksteps(c) / (s * 2) >= per_min) s *= 2;
     return s;
   };
   if (p.tile == 0 && p.splitk == 0 && can_split) {
@@ -750,28 +1001,45 @@ Plan choose_plan(const ConvDesc& d, const IgemmArgs& a) {
       if (t.ksize == a.ksize && t.stride == a.stride && t.up == a.up && t.ctot == a.Ctot && t.n == a.N && t.m == a.M) {
         p.tile = t.tile;
         p.splitk = t.splitk;
+        if (is_halo(p.tile) && !halo_ok(d)) p.tile = p.splitk = 0;
         break;
       }
     }
   }
   if (p.tile == 0) {
-    const int ms = max_split();
     p.tile = 3;
     for (int c : {1, 2, 4, 3}) {
       if (geglu && c != 1 && c != 4) continue;   // GEGLU value/gate pairs need 64 n-columns per wave
-      if (blocks_of(c) * ms >= 384 || c == 3) { p.tile = c; break; }
+      if (blocks_of(c) * max_split(c) >= 384 || c == 3) { p.tile = c; break; }
     }
     if (geglu && p.tile == 3) p.tile = 4;
   }
   if (geglu && p.tile != 1 && p.tile != 4) p.tile = 4;
   if (p.splitk == 0) {
     p.splitk = 1;
-    const int ms = max_split();
+    const int ms = max_split(p.tile);
     while (blocks_of(p.tile) * p.splitk < 384 && p.splitk < ms) p.splitk *= 2;
   }
   if (!can_split) p.splitk = 1;
-  if (p.splitk > a.nk_total) p.splitk = a.nk_total;
+  if (p.splitk > ksteps(p.tile)) p.splitk = ksteps(p.tile);
   return p;
+}
+
+template <int BN>
+void launch_halo(IgemmArgs a, int splitk, hipStream_t s) {
+  const int nch = a.Ctot / BK;
+  a.nk_total = nch;
+  a.nk_per_split = cdiv(nch, splitk);
+  a.splitk = cdiv(nch, a.nk_per_split);
+  const size_t lds = ((size_t)2 * HALO_LDS_ROWS * BK + (size_t)2 * BN * BK) * sizeof(half_t);
+  auto k = conv3x3_halo_kernel<BN>;
+  static bool attr = false;
+  if (!attr) {
+    SD_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  dim3 grid(a.B * a.tiles_x * a.tiles_y * cdiv(a.N, BN), a.splitk);
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
 }
 
 template <int BM, int BN, int WGM, int WGN, bool TRANS, bool GLDS, int NST>
@@ -838,7 +1106,7 @@ size_t conv_workspace_bytes(const ConvDesc& d) {
   if (!conv_fast_path_ok(d)) return 0;
   IgemmArgs a = make_args(d);
   Plan p = choose_plan(d, a);
-  return p.splitk > 1 ? (size_t)p.splitk * a.M * a.N * sizeof(float) : 0;
+  return p.splitk > 1 ? (size_t)p.splitk * a.M * a.N * sizeof(float) : 0;   // upper bound (launch may use fewer splits)
 }
 
 void launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
@@ -846,9 +1114,16 @@ void launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
              d.C0, d.C1, d.N, d.ksize);
   IgemmArgs a = make_args(d);
   Plan p = choose_plan(d, a);
-  a.splitk = p.splitk;
-  a.nk_per_split = cdiv(a.nk_total, p.splitk);
-  a.splitk = cdiv(a.nk_total, a.nk_per_split);   // no empty splits
+  const bool halo = p.tile == 5 || p.tile == 6;
+  if (halo) {
+    const int nch = a.Ctot / BK;
+    a.nk_per_split = cdiv(nch, p.splitk);
+    a.splitk = cdiv(nch, a.nk_per_split);
+  } else {
+    a.splitk = p.splitk;
+    a.nk_per_split = cdiv(a.nk_total, p.splitk);
+    a.splitk = cdiv(a.nk_total, a.nk_per_split);   // no empty splits
+  }
   if (a.splitk > 1) {
     size_t need = (size_t)a.splitk * a.M * a.N * sizeof(float);
     SD_REQUIRE(ws.partial && ws.partial_bytes >= need, kInternal, "split-K workspace too small (%zu < %zu)",
@@ -861,16 +1136,20 @@ void launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
   if (log_plans)
     fprintf(stderr, "[sd conv] k%d s%d up%d C0=%d C1=%d M=%d N=%d K=%d mode=%d tile=%d splitk=%d\n", a.ksize, a.stride, a.up,
             a.C0, a.C1, a.M, a.N, a.K, d.out_mode, p.tile, a.splitk);
-  if (d.debug) {   // ablation builds exist for two tiles only (tools/prof_conv.py)
+  if (halo) {
+    if (p.tile == 5) launch_halo<128>(a, a.splitk, s);
+    else launch_halo<64>(a, a.splitk, s);
+  } else if (d.debug) {   // ablation builds exist for two tiles only (tools/prof_conv.py)
     const bool ok = p.tile == 1 ? launch_debug_mode<128, 128>(a, d.debug, s) : launch_debug_mode<64, 64>(a, d.debug, s);
     SD_REQUIRE(ok && !trans, kInvalidArgument, "no ablation kernel for debug mode %d", d.debug);
     return;
-  }
-  switch (p.tile) {
-    case 1: launch_tile<128, 128, 2, 2>(a, trans, st, s); break;
-    case 2: launch_tile<128, 64, 2, 2>(a, trans, st, s); break;
-    case 3: launch_tile<64, 64, 2, 2>(a, trans, st, s); break;
-    default: launch_tile<64, 128, 2, 2>(a, trans, st, s); break;
+  } else {
+    switch (p.tile) {
+      case 1: launch_tile<128, 128, 2, 2>(a, trans, st, s); break;
+      case 2: launch_tile<128, 64, 2, 2>(a, trans, st, s); break;
+      case 3: launch_tile<64, 64, 2, 2>(a, trans, st, s); break;
+      default: launch_tile<64, 128, 2, 2>(a, trans, st, s); break;
+    }
   }
   if (a.splitk > 1) {
     size_t total4 = (size_t)a.M * a.N / 4;

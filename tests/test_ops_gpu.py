@@ -200,6 +200,22 @@ def test_conv2d_every_tile_and_splitk(tile, splitk):
     close(gen, conv_ref(x, w, bias, res, 1, False), "generic conv")
 
 
+@pytest.mark.parametrize("tile", [5, 6])
+@pytest.mark.parametrize("splitk", [0, 1, 2, 3])
+@pytest.mark.parametrize("shape", [(2, 128, 16, 16, 128), (1, 64, 24, 40, 96), (2, 320, 32, 32, 320), (1, 192, 9, 17, 68)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_conv3x3_halo_kernel(tile, splitk, shape):
+    """LDS-halo 3x3 kernel: full and ragged 8x16 tiles, ragged N, split over channel chunks."""
+    b, cin, hh, ww, cout = shape
+    rs = np.random.RandomState(cin + ww)
+    x = h16(rs.randn(b, cin, hh, ww))
+    w = h16(rs.randn(cout, cin, 3, 3) / np.sqrt(cin * 9))
+    bias = (0.1 * rs.randn(cout)).astype(np.float32)
+    res = h16(rs.randn(b, cout, hh, ww))
+    out, _ = _lib.conv2d(x, w, bias, res, tile=tile, splitk=splitk)
+    close(out, conv_ref(x, w, bias, res, 1, False), f"halo conv tile {tile} splitk {splitk} {shape}")
+
+
 @pytest.mark.parametrize("m,c", [(512, 320), (77, 64), (128, 1280), (40, 32)])
 def test_geglu_matches_oracle(m, c):
     rs = np.random.RandomState(m + c)

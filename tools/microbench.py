@@ -47,8 +47,8 @@ def main():
         flop = 2.0 * B * ho * ho * cout * cin * k * k
         m = B * ho * ho
         res = {}
-        splitks = [0] if m >= 2048 else [1, 2, 4, 8, 16]
-        for tile in (1, 2, 3, 4, 21, 22, 23, 24):
+        splitks = [0, 1, 2] if m >= 2048 else [1, 2, 4, 8, 16]
+        for tile in ((1, 2, 3, 4, 5, 6) if (k == 3 and s == 1 and not up and w >= 16) else (1, 2, 3, 4)):
             for sk in splitks:
                 try:
                     _, ms = _lib.conv2d(x, wt, bias, None, stride=s, upsample=bool(up), tile=tile, splitk=sk, iters=10)
