@@ -22,6 +22,7 @@
 // operands of P.V are key-contiguous.  K / V^T tiles of 64 keys are staged HBM -> VGPR -> LDS
 // (padded, bank-conflict-free rows) with a register double buffer, one barrier per tile.
 #include "kernels.h"
+#include <type_traits>
 
 namespace sd {
 namespace {
@@ -36,38 +37,66 @@ struct AttnArgs {
   int heads, d, Sq, Sk;
   int ldq, ldk, ldv, ldo;
   float scale_log2;   // d^-0.5 * log2(e)
-  int use_bpermute;
 };
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
 }
-// reductions across the 32 lanes that share (lane >> 5): 4 DPP steps inside each 16-lane row
-// (quad_perm xor1, xor2, row_half_mirror, row_mirror) + one ds_bpermute across the two rows
-__device__ __forceinline__ float half_wave_max(float v, bool bperm) {
-  if (bperm) {
-#pragma unroll
-    for (int o = 1; o < 32; o <<= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-  }
-  v = fmaxf(v, dpp_mov<0xB1>(v));
-  v = fmaxf(v, dpp_mov<0x4E>(v));
-  v = fmaxf(v, dpp_mov<0x141>(v));
-  v = fmaxf(v, dpp_mov<0x140>(v));
-  return fmaxf(v, __shfl_xor(v, 16));
+// gfx950 cross-row exchanges: v_permlane16_swap trades the odd 16-lane rows of one operand with
+// the even rows of the other, v_permlane32_swap the two wave halves; fed the same value twice,
+// the two results are {own, partner} for the xor-16 / xor-32 butterfly step - one VALU op
+// instead of a ds_bpermute round trip through the LDS crossbar.
+__device__ __forceinline__ void swap16(float v, float& x, float& y) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const unsigned r0 = r[0], r1 = r[1];   // scalars first: bit-casting the vector-element lvalue reads lane 0 twice
+  x = __uint_as_float(r0);
+  y = __uint_as_float(r1);
 }
-__device__ __forceinline__ float half_wave_sum(float v, bool bperm) {
-  if (bperm) {
+__device__ __forceinline__ void swap32(float v, float& x, float& y) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const unsigned r0 = r[0], r1 = r[1];   // scalars first: bit-casting the vector-element lvalue reads lane 0 twice
+  x = __uint_as_float(r0);
+  y = __uint_as_float(r1);
+}
+__device__ __forceinline__ float xor32_max(float v) {
+  float x, y;
+  swap32(v, x, y);
+  return fmaxf(x, y);
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+  float x, y;
+  swap32(v, x, y);
+  return x + y;
+}
+// reductions across the 32 lanes that share (lane >> 5): 4 DPP steps inside each 16-lane row
+// (quad_perm xor1, xor2, row_half_mirror, row_mirror) + one permlane16 swap across the two rows
+__device__ __forceinline__ void half_wave_max16(float (&v)[16]) {
 #pragma unroll
-    for (int o = 1; o < 32; o <<= 1) v += __shfl_xor(v, o);
-    return v;
+  for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], dpp_mov<0xB1>(v[r]));
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], dpp_mov<0x4E>(v[r]));
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], dpp_mov<0x141>(v[r]));
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], dpp_mov<0x140>(v[r]));
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float x, y;
+    swap16(v[r], x, y);
+    v[r] = fmaxf(x, y);
   }
+}
+__device__ __forceinline__ float half_wave_sum(float v) {
   v += dpp_mov<0xB1>(v);
   v += dpp_mov<0x4E>(v);
   v += dpp_mov<0x141>(v);
   v += dpp_mov<0x140>(v);
-  return v + __shfl_xor(v, 16);
+  float x, y;
+  swap16(v, x, y);
+  return x + y;
 }
 
 // MODE 0: ORIGINAL ([q][k] tiles), MODE 1: SPLIT_EINSUM ([k][q] tiles).  QT = 32-query tiles per wave.
@@ -183,13 +212,17 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs a) {
   store_tiles(0);
   __syncthreads();
 
-  for (int kt = 0; kt < ntiles; ++kt) {
+  // One key tile.  LAST is a compile-time flag: only the final tile can be ragged (needs the
+  // -inf masking) and has nothing to prefetch, so the steady-state loop carries neither the
+  // per-score compare/select nor the conditional loads (the compiler if-converts a runtime flag).
+  auto tile_step = [&](const int kt, auto last_c) {
+    constexpr bool LAST = decltype(last_c)::value;
     const int buf = kt & 1;
-    const bool more = kt + 1 < ntiles;
-    if (more) load_tiles(kt + 1);
+    constexpr bool more = !LAST;
+    if constexpr (more) load_tiles(kt + 1);
     const half_t* ks = Ks + buf * KT * KROW;
     const half_t* vs = Vs + buf * DCP * VROW;
-    const bool tail = (kt + 1) * KT > a.Sk;   // wave-uniform: only the last tile masks
+    const bool tail = LAST && (kt + 1) * KT > a.Sk;
 
     // ---------------- scores: two 32-key sub-tiles ----------------
     floatx16 sacc[QT][2];
@@ -200,9 +233,9 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[t][sub][r] = 0.f;
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
+    for (int kk = 0; kk < DK16; ++kk)   // kk outer: the two sub-tiles are independent MFMA chains
 #pragma unroll
-      for (int kk = 0; kk < DK16; ++kk) {
+      for (int sub = 0; sub < 2; ++sub) {
         const half8 kf = *reinterpret_cast<const half8*>(ks + (sub * 32 + l31) * KROW + kk * 16 + hi * 8);
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
@@ -215,39 +248,45 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs a) {
 
     if constexpr (MODE == 1) {
       // ======== SPLIT_EINSUM: lane = query column, registers = keys ========
+      // VALU diet (the loop is VALU-, not MFMA-bound): the max runs on RAW scores (scale > 0 commutes
+      // with max), scale and -max fold into ONE fma before the exp2, and the accumulator rescale is
+      // skipped - exactly, alpha == 1 - on the (common) tiles where no lane's running max moved.
 #pragma unroll
       for (int t = 0; t < QT; ++t) {
-        float mx = -1e30f;
+        float mx = -3.0e38f;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            float s = sacc[t][sub][r] * a.scale_log2;
             if (tail) {
               const int key = kt * KT + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-              if (key >= a.Sk) s = -1e30f;
+              if (key >= a.Sk) sacc[t][sub][r] = -3.0e38f;
             }
-            sacc[t][sub][r] = s;
-            mx = fmaxf(mx, s);
+            mx = fmaxf(mx, sacc[t][sub][r]);
           }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));            // the other half-wave holds the other 32 keys
-        const float mnew = fmaxf(mrun[t][0], mx);
-        const float alpha = __builtin_amdgcn_exp2f(mrun[t][0] - mnew);
-        mrun[t][0] = mnew;
-        float psum = 0.f;
+        mx = xor32_max(mx);                            // the other half-wave holds the other 32 keys
+        const float mold = mrun[t][0];
+        const float mnew = fmaxf(mold, mx * a.scale_log2);
+        float ps4[4] = {0.f, 0.f, 0.f, 0.f};           // four short add chains instead of one of 32
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const float p = __builtin_amdgcn_exp2f(sacc[t][sub][r] - mnew);
+            const float p = __builtin_amdgcn_exp2f(fmaf(sacc[t][sub][r], a.scale_log2, -mnew));
             sacc[t][sub][r] = p;
-            psum += p;
+            ps4[r & 3] += p;
           }
-        lrun[t][0] = lrun[t][0] * alpha + psum;        // per-lane partial (own keys); merged at the end
+        const float psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
+        if (__any(mnew > mold)) {                      // wave-uniform
+          const float alpha = __builtin_amdgcn_exp2f(mold - mnew);
+          lrun[t][0] *= alpha;
 #pragma unroll
-        for (int ct = 0; ct < DC32; ++ct)
+          for (int ct = 0; ct < DC32; ++ct)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) oacc[t][ct][r] *= alpha;
+            for (int r = 0; r < 16; ++r) oacc[t][ct][r] *= alpha;
+          mrun[t][0] = mnew;
+        }
+        lrun[t][0] += psum;                            // per-lane partial (own keys); merged at the end
       }
       // P (registers) is already the B operand of O^T += V^T . P^T: k-slot (hi, e) of MFMA step s2
       // holds key  sub*32 + s2*16 + (e&3) + 8*(e>>2) + 4*hi ; V^T is gathered with the same map.
@@ -276,21 +315,39 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs a) {
       half_t* ps = Ps + wave * (QT * 32) * PROW;
 #pragma unroll
       for (int t = 0; t < QT; ++t) {
+        float mnew[16];
+        bool moved = false;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float s0 = sacc[t][0][r] * a.scale_log2, s1 = sacc[t][1][r] * a.scale_log2;
           if (tail) {
-            if (kt * KT + l31 >= a.Sk) s0 = -1e30f;
-            if (kt * KT + 32 + l31 >= a.Sk) s1 = -1e30f;
+            if (kt * KT + l31 >= a.Sk) sacc[t][0][r] = -3.0e38f;
+            if (kt * KT + 32 + l31 >= a.Sk) sacc[t][1][r] = -3.0e38f;
           }
-          const float mx = half_wave_max(fmaxf(s0, s1), a.use_bpermute);
-          const float mnew = fmaxf(mrun[t][r], mx);
-          const float alpha = __builtin_amdgcn_exp2f(mrun[t][r] - mnew);
-          mrun[t][r] = mnew;
-          const float p0 = __builtin_amdgcn_exp2f(s0 - mnew), p1 = __builtin_amdgcn_exp2f(s1 - mnew);
-          lrun[t][r] = lrun[t][r] * alpha + p0 + p1;   // per-lane partial, reduced at the end
+          mnew[r] = fmaxf(sacc[t][0][r], sacc[t][1][r]);   // in-lane over the two 32-key sub-tiles
+        }
+        // row max across the 32 lanes, butterfly step-major over the 16 rows: consecutive DPP ops
+        // are independent, so none of them waits on the VALU->DPP hazard of its predecessor
+        half_wave_max16(mnew);
 #pragma unroll
-          for (int ct = 0; ct < DC32; ++ct) oacc[t][ct][r] *= alpha;
+        for (int r = 0; r < 16; ++r) {
+          mnew[r] = fmaxf(mrun[t][r], mnew[r] * a.scale_log2);
+          moved |= mnew[r] > mrun[t][r];
+        }
+        if (__any(moved)) {                            // wave-uniform: rescale only when some row's max moved
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float alpha = __builtin_amdgcn_exp2f(mrun[t][r] - mnew[r]);
+            lrun[t][r] *= alpha;
+#pragma unroll
+            for (int ct = 0; ct < DC32; ++ct) oacc[t][ct][r] *= alpha;
+            mrun[t][r] = mnew[r];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[t][0][r], a.scale_log2, -mnew[r]));
+          const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[t][1][r], a.scale_log2, -mnew[r]));
+          lrun[t][r] += p0 + p1;                       // per-lane partial, reduced at the end
           const int qrow = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
           ps[qrow * PROW + l31] = (half_t)p0;
           ps[qrow * PROW + 32 + l31] = (half_t)p1;
@@ -314,16 +371,20 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs a) {
       __builtin_amdgcn_wave_barrier();
     }
 
-    if (more) store_tiles(buf ^ 1);
-    __syncthreads();
-  }
+    if constexpr (more) {
+      store_tiles(buf ^ 1);
+      __syncthreads();
+    }
+  };
+  for (int kt = 0; kt + 1 < ntiles; ++kt) tile_step(kt, std::false_type{});
+  tile_step(ntiles - 1, std::true_type{});
 
   // ---------------- normalise + store ----------------
   half_t* obase = a.out + (size_t)b * a.Sq * a.ldo + (size_t)h * a.d;
   if constexpr (MODE == 1) {
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-      const float ltot = lrun[t][0] + __shfl_xor(lrun[t][0], 32);
+      const float ltot = xor32_sum(lrun[t][0]);
       const float inv = 1.0f / ltot;
       const int q = q_wave0 + t * 32 + l31;
       if (q < a.Sq) {
@@ -345,7 +406,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs a) {
     for (int t = 0; t < QT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float inv = 1.0f / half_wave_sum(lrun[t][r], a.use_bpermute);
+        const float inv = 1.0f / half_wave_sum(lrun[t][r]);
         const int q = q_wave0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         if (q < a.Sq) {
 #pragma unroll
@@ -407,7 +468,7 @@ void launch_attention(const AttnDesc& d, hipStream_t s) {
                  "(attention.py:86)", d.Sq);
   }
   AttnArgs a{d.q, d.k, d.vt, d.out, d.heads, d.d, d.Sq, d.Sk, d.ldq, d.ldk, d.ldv, d.ldo,
-             1.4426950408889634f / sqrtf((float)d.d), d.variant & 1};
+             1.4426950408889634f / sqrtf((float)d.d)};
   const int dk16 = cdiv(d.d, 16), dc32 = cdiv(d.d, 32);
   if (dk16 == 1 && dc32 == 1) launch_d<1, 1>(a, d.B, impl, s);
   else if (dk16 == 2 && dc32 == 1) launch_d<2, 1>(a, d.B, impl, s);

@@ -71,7 +71,7 @@ struct AttnDesc {
   int B = 1, heads = 1, d = 64, Sq = 0, Sk = 0;
   int ldq = 0, ldk = 0, ldv = 0, ldo = 0;
   int impl = kAttnOriginal;
-  int variant = 0;   // tuning/testing: bit0 = use ds_bpermute instead of DPP in ORIGINAL
+  int variant = 0;   // reserved for A/B testing of kernel variants (currently unused)
 };
 void launch_attention(const AttnDesc& d, hipStream_t s);
 bool attention_supported(int d);

@@ -96,14 +96,6 @@ def test_attention_running_max_rescale_branch(impl):
     close(out, ref, f"{impl} rescale")
 
 
-def test_attention_original_dpp_and_bpermute_variants_agree():
-    rs = np.random.RandomState(3)
-    q, k, v = (h16(rs.randn(1, 128, 1, n)) for n in (256, 200, 200))
-    a, _ = _lib.attention("ORIGINAL", q, k, v, 2, 64, variant=0)
-    b, _ = _lib.attention("ORIGINAL", q, k, v, 2, 64, variant=1)
-    assert np.array_equal(a, b)
-
-
 def test_three_attention_schedules_agree_with_each_other():
     rs = np.random.RandomState(9)
     q, k, v = (h16(rs.randn(2, 320, 1, n)) for n in (1024, 1024, 1024))
