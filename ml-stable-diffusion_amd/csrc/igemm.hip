@@ -45,9 +45,25 @@ struct IgemmArgs {
   long long* prof;
   const half_t* zeros;   // >= 16 B of zeros: source of padding / out-of-range rows
   int tiles_x, tiles_y;  // halo kernel: 8x16-pixel output tiles per image
+  // LayerNorm folded into a 1x1 GEMM (LNF kernels): w already carries gamma, bias carries W.beta,
+  // colsum[n] = sum_k w[n][k]; the kernel accumulates the row statistics of its A tile on the fly
+  const float* ln_colsum;
+  float ln_eps;
+  // fused q|k|v projection: output columns >= n_trans go, token-transposed, to out_t [B][N-n_trans][ldT]
+  // (the V^T operand of attention); columns below it to out with row length ldo
+  int n_trans, ldo;
+  half_t* out_t;
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// v + (value of lane ^ 32): one v_permlane32_swap instead of a ds_bpermute round trip
+__device__ __forceinline__ float xor32_sum(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const unsigned r0 = r[0], r1 = r[1];   // scalars first: bit-casting the vector-element lvalue reads lane 0 twice
+  return __uint_as_float(r0) + __uint_as_float(r1);
+}
 
 // One 256-thread workgroup = 4 wavefronts laid out WGM x WGN over a BM x BN tile.
 // GLDS = true: tiles go HBM -> LDS directly (global_load_lds_dwordx4, no VGPR round trip and no
@@ -55,9 +71,10 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 // The DMA writes lane-linear 1-KiB pieces (8 rows x 128 B), so the bank swizzle lives on the
 // per-lane SOURCE address: physical 16-B chunk p of row r holds logical chunk p ^ ((r >> 1) & 7),
 // and fragment reads apply the same XOR (conflict-free ds_read_b128, cdna guide rule 21).
-template <int BM, int BN, int WGM, int WGN, bool TRANS_OUT, bool GLDS, int NST, int DBG = 0>
+template <int BM, int BN, int WGM, int WGN, bool TRANS_OUT, bool GLDS, int NST, int DBG = 0, bool LNF = false>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   static_assert(WGM * WGN == 4, "4 waves");
+  static_assert(!(LNF && TRANS_OUT), "LayerNorm fold uses the in-lane row layout of the non-transposed tile");
   constexpr int TM = BM / WGM / 32;   // 32x32 MFMA tiles per wave along m
   constexpr int TN = BN / WGN / 32;
   constexpr int XR = BM / 32;         // 16-B chunks each thread stages per K step (X tile)
@@ -234,6 +251,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   //   [load_tile(next)] - scheduled by the compiler between / behind the MFMAs
   //   mfma_step()      - 16 back-to-back MFMAs
   half8 xf[BK / 16][TM] = {}, wf[BK / 16][TN] = {};
+  // LNF: per-lane partial sum / sum of squares of activation row (lane & 31) of each m-tile, over the
+  // k chunks this half-wave reads (v_dot2_f32_f16: exact fp16 products, fp32 accumulation)
+  float ln_s1[TM] = {}, ln_s2[TM] = {};
   auto read_frags = [&](int buf) {
     if constexpr ((DBG & 3) == 1) return;
     if constexpr ((DBG & 8) != 0) {   // ablation: no LDS reads (fragments = loop-invariant garbage kept live)
@@ -281,6 +301,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
           else                       // rows = n, cols = m
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kk][j], xf[kk][i], acc[i][j], 0, 0, 0);
         }
+      if constexpr (LNF) {           // VALU work that fits the issue slots between the MFMAs
+        const half2v one2 = {(half_t)1.f, (half_t)1.f};
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const half2v p2 = {xf[kk][i][2 * e], xf[kk][i][2 * e + 1]};
+            ln_s2[i] = __builtin_amdgcn_fdot2(p2, p2, ln_s2[i], false);
+            ln_s1[i] = __builtin_amdgcn_fdot2(p2, one2, ln_s1[i], false);
+          }
+      }
     }
   };
 
@@ -334,6 +365,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   if (prof) prof_t[2] = clock64();
   // ---------------------------------- epilogue ----------------------------------
   const int hi = lane >> 5;
+  // LNF: y = rstd*(x.W') - rstd*mean*colsum + bias'  ->  out = acc*ln_a + ln_b*colsum[n] + bias[n]
+  float ln_a[TM] = {}, ln_b[TM] = {};
+  if constexpr (LNF) {
+    const float inv_k = 1.0f / (float)a.K;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const float s1 = xor32_sum(ln_s1[i]), s2 = xor32_sum(ln_s2[i]);   // the two k halves of the wave
+      const float mean = s1 * inv_k;
+      const float var = fmaxf(s2 * inv_k - mean * mean, 0.f);
+      ln_a[i] = rsqrtf(var + a.ln_eps);
+      ln_b[i] = -ln_a[i] * mean;
+    }
+  }
   if constexpr (TRANS_OUT) {
     // acc[i][j][r]: m = m0 + (r&3) + 8*(r>>2) + 4*hi ; n = n0 + (lane&31).  out[b][n][s]
 #pragma unroll
@@ -393,7 +437,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
       const bool geglu = a.out_mode == kOutGeglu;
       constexpr int OW = BN;                 // staged tile width in halves (GEGLU uses the first BN/2)
       constexpr int OROW = OW + 8;           // +16 B pad: conflict-free 16-B reads
-      half_t* ot = reinterpret_cast<half_t*>(smem);   // [BM][OROW]  (<= the K-loop buffers)
+      constexpr int TROW = BM + 8;           // transposed staging (fused q|k|v: the V^T columns), [BN][TROW]
+      half_t* ot = reinterpret_cast<half_t*>(smem);   // [BM][OROW] or [BN][TROW]  (<= the K-loop buffers)
+      const bool tblock = n_blk >= a.n_trans;         // block-uniform
       __syncthreads();                       // every wave is done with its last fragment reads
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -411,8 +457,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
                 half4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                  float v = acc[i][j][4 * q + e] + ((a.bias && ng < a.N) ? a.bias[nv + e] : 0.f);
-                  float g = acc[i][j + 1][4 * q + e] + ((a.bias && ng < a.N) ? a.bias[ng + e] : 0.f);
+                  float v, g;
+                  if constexpr (LNF) {
+                    const bool in = ng < a.N;
+                    v = fmaf(acc[i][j][4 * q + e], ln_a[i], in ? fmaf(ln_b[i], a.ln_colsum[nv + e], a.bias[nv + e]) : 0.f);
+                    g = fmaf(acc[i][j + 1][4 * q + e], ln_a[i], in ? fmaf(ln_b[i], a.ln_colsum[ng + e], a.bias[ng + e]) : 0.f);
+                  } else {
+                    v = acc[i][j][4 * q + e] + ((a.bias && ng < a.N) ? a.bias[nv + e] : 0.f);
+                    g = acc[i][j + 1][4 * q + e] + ((a.bias && ng < a.N) ? a.bias[ng + e] : 0.f);
+                  }
                   o[e] = (half_t)(v * gelu_erf(g));
                 }
                 *reinterpret_cast<half4*>(ot + ml * OROW + (wn * TN + j) * 16 + 8 * q + 4 * hi) = o;
@@ -427,7 +480,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
               const int n = n_blk + nl;
               float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
               if (n < a.N) {
-                if (a.bias) {
+                if constexpr (LNF) {
+                  const floatx4 cs = *reinterpret_cast<const floatx4*>(a.ln_colsum + n);
+                  const floatx4 bb = *reinterpret_cast<const floatx4*>(a.bias + n);
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], ln_a[i], fmaf(ln_b[i], cs[e], bb[e]));
+                } else if (a.bias) {
                   floatx4 bb = *reinterpret_cast<const floatx4*>(a.bias + n);
 #pragma unroll
                   for (int e = 0; e < 4; ++e) v[e] += bb[e];
@@ -438,16 +496,31 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
                   for (int e = 0; e < 4; ++e) v[e] += tt[e];
                 }
               }
-              if (a.res) {   // keep fp32 until the residual is added in the write-out pass
-                // (residual added below from a coalesced load; stage the fp32->fp16 value only when no residual)
-              }
               half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-              *reinterpret_cast<half4*>(ot + ml * OROW + nl) = o;
+              if (tblock) {   // V^T columns: staged [n][m] so the write-out rows are token-contiguous
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ot[(nl + e) * TROW + ml] = o[e];
+              } else {
+                *reinterpret_cast<half4*>(ot + ml * OROW + nl) = o;
+              }
             }
         }
       }
       __syncthreads();
-      const int NO = geglu ? (a.N >> 1) : a.N;              // output row length
+      if (tblock) {   // out_t[b][n - n_trans][s]: 8 consecutive tokens of one image per 16-B store
+        const int NV = a.N - a.n_trans;
+        for (int idx = tid; idx < BN * (BM / 8); idx += 256) {
+          const int r = idx / (BM / 8), c = idx - r * (BM / 8);
+          const int nv = n_blk + r - a.n_trans, m = m_blk + c * 8;
+          if (nv < NV && m < a.M) {
+            const int b = m / a.HoWo, sp = m - b * a.HoWo;
+            *reinterpret_cast<half8*>(a.out_t + ((size_t)b * NV + nv) * a.ldT + sp) =
+                *reinterpret_cast<const half8*>(ot + r * TROW + c * 8);
+          }
+        }
+        return;
+      }
+      const int NO = geglu ? (a.N >> 1) : a.ldo;            // output row length
       const int nb0 = geglu ? (n_blk >> 1) : n_blk;         // first output column of this tile
       constexpr int OWC = OW / 8;                           // 16-B chunks per staged row (GEGLU: first half used)
       const int wc = geglu ? OWC / 2 : OWC;
@@ -935,6 +1008,11 @@ IgemmArgs make_args(const ConvDesc& d) {
   a.zeros = device_zero_chunk();
   a.tiles_x = cdiv(d.Wi, 16);
   a.tiles_y = cdiv(d.Hi, 8);
+  a.ln_colsum = d.ln_colsum;
+  a.ln_eps = d.ln_eps;
+  a.n_trans = d.out_t ? d.n_trans : 0x7fffffff;
+  a.ldo = d.out_t ? d.n_trans : d.N;
+  a.out_t = d.out_t;
   return a;
 }
 
@@ -979,7 +1057,9 @@ static const int kNumTuned = 0;
 Plan choose_plan(const ConvDesc& d, const IgemmArgs& a) {
   Plan p{d.tile, d.splitk};
   const bool geglu = d.out_mode == kOutGeglu;
-  const bool can_split = d.out_mode == kOutHalf;
+  // the LayerNorm fold needs whole rows per workgroup, the fused q|k|v epilogue has no slab path
+  const bool can_split = d.out_mode == kOutHalf && !d.ln_colsum && !d.out_t;
+  if (d.ln_colsum || d.out_t) p.splitk = 1;
   if ((p.tile == 5 || p.tile == 6) && !halo_ok(d)) p.tile = 0;
   auto is_halo = [](int c) { return c == 5 || c == 6; };
   auto blocks_of = [&](int c) {
@@ -1010,6 +1090,9 @@ Plan choose_plan(const ConvDesc& d, const IgemmArgs& a) {
     p.tile = 3;
     for (int c : {1, 2, 4, 3}) {
       if (geglu && c != 1 && c != 4) continue;   // GEGLU value/gate pairs need 64 n-columns per wave
+      int bm, bn;
+      tile_dims(c, bm, bn);
+      if (d.out_t && d.n_trans % bn != 0) continue;   // the q|k / v boundary must be a tile boundary
       if (blocks_of(c) * max_split(c) >= 384 || c == 3) { p.tile = c; break; }
     }
     if (geglu && p.tile == 3) p.tile = 4;
@@ -1042,11 +1125,12 @@ void launch_halo(IgemmArgs a, int splitk, hipStream_t s) {
   hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
 }
 
-template <int BM, int BN, int WGM, int WGN, bool TRANS, bool GLDS, int NST>
+template <int BM, int BN, int WGM, int WGN, bool TRANS, bool GLDS, int NST, bool LNF = false>
 void launch_variant(const IgemmArgs& a, hipStream_t s) {
   const size_t lds = (size_t)NST * (BM + BN) * (GLDS ? BK : LDS_ROW) * sizeof(half_t);
+  static_assert((size_t)BN * (BM + 8) <= (size_t)NST * (BM + BN) * (GLDS ? BK : LDS_ROW), "transposed staging fits");
   dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), a.splitk);
-  auto k = igemm_kernel<BM, BN, WGM, WGN, TRANS, GLDS, NST>;
+  auto k = igemm_kernel<BM, BN, WGM, WGN, TRANS, GLDS, NST, 0, LNF>;
   static bool attr = false;
   if (!attr) {
     SD_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1079,6 +1163,10 @@ bool launch_debug_mode(const IgemmArgs& a, int dbg, hipStream_t s) {
 // staging: 0 = LDS-DMA 2 stages, 1 = register staging (A/B reference), 2 = LDS-DMA 3-stage ring
 template <int BM, int BN, int WGM, int WGN>
 void launch_tile(const IgemmArgs& a, bool trans, int staging, hipStream_t s) {
+  if (a.ln_colsum) {   // LayerNorm-folded 1x1 GEMM: LDS-DMA two-stage kernel only
+    launch_variant<BM, BN, WGM, WGN, false, true, 2, true>(a, s);
+    return;
+  }
   if (trans) {
     if (staging == 1) launch_variant<BM, BN, WGM, WGN, true, false, 2>(a, s);
     else if (staging == 2) launch_variant<BM, BN, WGM, WGN, true, true, 3>(a, s);
@@ -1112,6 +1200,11 @@ size_t conv_workspace_bytes(const ConvDesc& d) {
 void launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
   SD_REQUIRE(conv_fast_path_ok(d), kInvalidArgument, "launch_conv: shape not MFMA-tileable (C0=%d C1=%d N=%d k=%d)",
              d.C0, d.C1, d.N, d.ksize);
+  SD_REQUIRE(!d.ln_colsum || (d.ksize == 1 && !d.x1 && d.bias && d.out_mode != kOutHalfT), kInvalidArgument,
+             "LayerNorm fold needs a 1x1 single-source GEMM with a (folded) bias");
+  SD_REQUIRE(!d.out_t || (d.out_mode == kOutHalf && d.n_trans % 64 == 0 && d.n_trans < d.N && (d.Ho * d.Wo) % 8 == 0 &&
+                          d.ldT % 8 == 0 && !d.res && !d.temb),
+             kInvalidArgument, "fused q|k|v: n_trans %d N %d HoWo %d ldT %d", d.n_trans, d.N, d.Ho * d.Wo, d.ldT);
   IgemmArgs a = make_args(d);
   Plan p = choose_plan(d, a);
   const bool halo = p.tile == 5 || p.tile == 6;

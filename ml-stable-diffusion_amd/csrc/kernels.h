@@ -38,6 +38,14 @@ struct ConvDesc {
   long long* prof = nullptr;    // debug bit 2: device buffer of 8 timestamps
   int debug = 0;                // ablation hooks for tools/microbench (results are garbage when != 0)
   int staging = 0;              // 0: LDS-DMA 2-stage, 1: HBM->VGPR->LDS (A/B reference), 2: LDS-DMA 3-stage ring
+  // LayerNorm folded into this 1x1 GEMM (x is the UN-normalised input): w = W*gamma, bias = b + W.beta,
+  // ln_colsum[n] = sum_k w[n][k]; the kernel derives mean / rstd of each row from its own A tiles
+  const float* ln_colsum = nullptr;
+  float ln_eps = 1e-5f;
+  // fused q|k|v: output columns [n_trans, N) are written token-transposed to out_t [B][N-n_trans][ldT]
+  // (attention's V^T), columns [0, n_trans) to out with row length n_trans.  Needs Ho*Wo % 8 == 0.
+  half_t* out_t = nullptr;
+  int n_trans = 0;
 };
 
 struct ConvWorkspace {

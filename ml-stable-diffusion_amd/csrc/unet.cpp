@@ -15,6 +15,7 @@
 #include "unet.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace sd {
@@ -132,9 +133,67 @@ Tensor UNet::conv_stacked(std::vector<Op>& ops, const std::vector<std::string>& 
   return conv_w(ops, names[0], d, nullptr, x, nullptr, n * cout_each, 1, 1, 1, nullptr, nullptr, kOutHalf, 0, false);
 }
 
+// y = LN(x) . W^T + b  ==  rstd*(x . (W*gamma)^T) - rstd*mean*colsum(W*gamma) + (b + W.beta): the
+// GEMM runs on the raw rows and applies the row statistics in its epilogue (igemm LNF kernels), so
+// the separate LayerNorm launch, its HBM round trip and the fp16 rounding of LN(x) all disappear.
+UNet::LnFold UNet::fold_layernorm(const std::string& ln, const std::vector<std::string>& names, int cin, int cout_each,
+                                  bool geglu) {
+  const HostTensor& g = ws_->get(ln + ".weight");
+  const HostTensor& be = ws_->get(ln + ".bias");
+  SD_REQUIRE((int)g.numel() == cin && (int)be.numel() == cin, kInvalidArgument, "%s: expected %d channels", ln.c_str(),
+             cin);
+  const int n = (int)names.size(), ntot = n * cout_each;
+  SD_REQUIRE(!geglu || n == 1, kInternal, "GEGLU fold takes one projection");
+  std::vector<half_t> w((size_t)ntot * cin);
+  std::vector<float> colsum(ntot), bias(ntot);
+  for (int i = 0; i < n; ++i) {
+    const HostTensor& t = ws_->get(names[i] + ".weight");
+    SD_REQUIRE(t.numel() == (size_t)cout_each * cin, kInvalidArgument, "%s.weight: bad shape", names[i].c_str());
+    const HostTensor* tb = ws_->has(names[i] + ".bias") ? &ws_->get(names[i] + ".bias") : nullptr;
+    SD_REQUIRE(!tb || (int)tb->numel() == cout_each, kInvalidArgument, "%s.bias: bad shape", names[i].c_str());
+    for (int o = 0; o < cout_each; ++o) {
+      int dst = i * cout_each + o;
+      if (geglu) {   // same value/gate interleave as upload_conv_weight
+        const int half_n = cout_each / 2;
+        const bool gate = o >= half_n;
+        const int j = gate ? o - half_n : o;
+        dst = (j / 32) * 64 + (gate ? 32 : 0) + (j % 32);
+      }
+      double cs = 0.0, bb = tb ? (double)tb->data[o] : 0.0;
+      for (int c = 0; c < cin; ++c) {
+        const float wv = t.data[(size_t)o * cin + c];
+        const half_t h = (half_t)(wv * g.data[c]);
+        w[(size_t)dst * cin + c] = h;
+        cs += (double)(float)h;          // column sum of what the MFMA actually multiplies
+        bb += (double)wv * (double)be.data[c];
+      }
+      colsum[dst] = (float)cs;
+      bias[dst] = (float)bb;
+    }
+  }
+  LnFold f;
+  f.w = arena_.alloc_n<half_t>(w.size());
+  f.colsum = arena_.alloc_n<float>(ntot);
+  f.bias = arena_.alloc_n<float>(ntot);
+  SD_HIP(hipMemcpy(f.w, w.data(), w.size() * sizeof(half_t), hipMemcpyHostToDevice));
+  SD_HIP(hipMemcpy(f.colsum, colsum.data(), ntot * sizeof(float), hipMemcpyHostToDevice));
+  SD_HIP(hipMemcpy(f.bias, bias.data(), ntot * sizeof(float), hipMemcpyHostToDevice));
+  return f;
+}
+
+bool UNet::can_fold_ln(const Tensor& x, int cout, bool geglu) const {
+  ConvDesc d;
+  d.C0 = x.C;
+  d.N = cout;
+  d.ksize = 1;
+  d.out_mode = geglu ? kOutGeglu : kOutHalf;
+  static const bool off = getenv("SD_NO_LN_FOLD") != nullptr;   // A/B switch for measurements
+  return !off && conv_fast_path_ok(d);
+}
+
 Tensor UNet::conv_w(std::vector<Op>& ops, const std::string& name, const half_t* w, const float* bias, const Tensor& x,
                     const Tensor* x2, int cout, int k, int stride, int up, const float* temb, const half_t* res,
-                    int out_mode, int ldT, bool silu_out) {
+                    int out_mode, int ldT, bool silu_out, ConvExtra* ex) {
   const bool geglu = out_mode == kOutGeglu;
   ConvDesc d;
   d.x0 = x.p;
@@ -162,13 +221,21 @@ Tensor UNet::conv_w(std::vector<Op>& ops, const std::string& name, const half_t*
   d.out_mode = out_mode;
   d.ldT = ldT;
   Tensor out;
-  if (out_mode == kOutHalfT) {
+  if (ex) d.ln_colsum = ex->ln_colsum;
+  if (ex && ex->n_trans > 0) {   // fused q|k|v: [M][n_trans] row-major + V^T [B][cout - n_trans][ldT]
+    out = new_tensor(x.B, d.Ho, d.Wo, ex->n_trans);
+    ex->vt = arena_.alloc_n<half_t>((size_t)x.B * (cout - ex->n_trans) * ldT);
+    d.out_t = ex->vt;
+    d.n_trans = ex->n_trans;
+  } else if (out_mode == kOutHalfT) {
     out.B = x.B; out.H = 1; out.W = ldT; out.C = cout;   // [B][cout][ldT]
     out.p = arena_.alloc_n<half_t>((size_t)x.B * cout * ldT);
   } else {
     out = new_tensor(x.B, d.Ho, d.Wo, geglu ? cout / 2 : cout);
   }
   d.out = out.p;
+  SD_REQUIRE(!ex || (conv_fast_path_ok(d) && !silu_out), kInternal, "%s: LayerNorm fold / fused q|k|v off the MFMA path",
+             name.c_str());
   if (conv_fast_path_ok(d) && !silu_out) {
     ws_need_ = std::max(ws_need_, conv_workspace_bytes(d));
     ops.push_back([this, d](hipStream_t s) { launch_conv(d, ws_conv_, s); });
@@ -266,26 +333,56 @@ Tensor UNet::attention(std::vector<Op>& ops, const Tensor& q, const half_t* k, c
 // unet.py:586-591 (+ CrossAttention :87-118, FeedForward/GEGLU :594-617)
 Tensor UNet::transformer_block(std::vector<Op>& ops, const std::string& b, const Tensor& h, int heads) {
   const int C = h.C, S = h.H * h.W, L = cfg_.context_len;
-  // --- self attention
-  Tensor n1 = layer_norm(ops, b + ".norm1", h);
-  Tensor qk = conv_stacked(ops, {b + ".attn1.to_q", b + ".attn1.to_k"}, n1, C);   // [M][2C]: q | k
+  // --- self attention.  MFMA-tileable widths: norm1 is folded into ONE fused q|k|v GEMM whose V
+  // columns leave token-transposed (attention's V^T operand); otherwise LN + stacked q|k + V^T GEMMs.
   const int ldv = round_up(S, 8);
-  Tensor vt = conv(ops, b + ".attn1.to_v", n1, nullptr, C, 1, 1, 1, false, nullptr, nullptr, kOutHalfT, ldv);
+  Tensor qk;
+  half_t* vtp;
+  if (can_fold_ln(h, 3 * C, false) && S % 8 == 0 && (2 * C) % 64 == 0) {
+    LnFold f = fold_layernorm(b + ".norm1", {b + ".attn1.to_q", b + ".attn1.to_k", b + ".attn1.to_v"}, C, C, false);
+    ConvExtra ex;
+    ex.ln_colsum = f.colsum;
+    ex.n_trans = 2 * C;
+    qk = conv_w(ops, b + ".attn1.to_qkv", f.w, f.bias, h, nullptr, 3 * C, 1, 1, 1, nullptr, nullptr, kOutHalf, ldv,
+                false, &ex);
+    vtp = ex.vt;
+  } else {
+    Tensor n1 = layer_norm(ops, b + ".norm1", h);
+    qk = conv_stacked(ops, {b + ".attn1.to_q", b + ".attn1.to_k"}, n1, C);   // [M][2C]: q | k
+    vtp = conv(ops, b + ".attn1.to_v", n1, nullptr, C, 1, 1, 1, false, nullptr, nullptr, kOutHalfT, ldv).p;
+  }
   Tensor q = qk;
   q.C = C;   // logical width of q; rows are 2C apart
-  Tensor a1 = attention(ops, q, qk.p + C, vt.p, heads, S, S, 2 * C, ldv, 2 * C);
+  Tensor a1 = attention(ops, q, qk.p + C, vtp, heads, S, S, 2 * C, ldv, 2 * C);
   Tensor h1 = conv(ops, b + ".attn1.to_out.0", a1, nullptr, C, 1, 1, 1, true, nullptr, h.p);
   // --- cross attention: K / V^T of the prompt are computed by ctx_ops_ when the prompt changes
-  Tensor n2 = layer_norm(ops, b + ".norm2", h1);
-  Tensor q2 = conv(ops, b + ".attn2.to_q", n2, nullptr, C, 1, 1, 1, false, nullptr, nullptr);
+  Tensor q2;
+  if (can_fold_ln(h1, C, false)) {
+    LnFold f = fold_layernorm(b + ".norm2", {b + ".attn2.to_q"}, C, C, false);
+    ConvExtra ex;
+    ex.ln_colsum = f.colsum;
+    q2 = conv_w(ops, b + ".attn2.to_q", f.w, f.bias, h1, nullptr, C, 1, 1, 1, nullptr, nullptr, kOutHalf, 0, false, &ex);
+  } else {
+    Tensor n2 = layer_norm(ops, b + ".norm2", h1);
+    q2 = conv(ops, b + ".attn2.to_q", n2, nullptr, C, 1, 1, 1, false, nullptr, nullptr);
+  }
   const int ldvc = round_up(L, 8);
   Tensor k2 = conv(ctx_ops_, b + ".attn2.to_k", ctx_, nullptr, C, 1, 1, 1, false, nullptr, nullptr);
   Tensor vt2 = conv(ctx_ops_, b + ".attn2.to_v", ctx_, nullptr, C, 1, 1, 1, false, nullptr, nullptr, kOutHalfT, ldvc);
   Tensor a2 = attention(ops, q2, k2.p, vt2.p, heads, S, L, C, ldvc, C);
   Tensor h2 = conv(ops, b + ".attn2.to_out.0", a2, nullptr, C, 1, 1, 1, true, nullptr, h1.p);
-  // --- GEGLU feed-forward
-  Tensor n3 = layer_norm(ops, b + ".norm3", h2);
-  Tensor g = conv(ops, b + ".ff.net.0.proj", n3, nullptr, 8 * C, 1, 1, 1, true, nullptr, nullptr, kOutGeglu);
+  // --- GEGLU feed-forward (norm3 folded the same way)
+  Tensor g;
+  if (can_fold_ln(h2, 8 * C, true)) {
+    LnFold f = fold_layernorm(b + ".norm3", {b + ".ff.net.0.proj"}, C, 8 * C, true);
+    ConvExtra ex;
+    ex.ln_colsum = f.colsum;
+    g = conv_w(ops, b + ".ff.net.0.proj", f.w, f.bias, h2, nullptr, 8 * C, 1, 1, 1, nullptr, nullptr, kOutGeglu, 0,
+               false, &ex);
+  } else {
+    Tensor n3 = layer_norm(ops, b + ".norm3", h2);
+    g = conv(ops, b + ".ff.net.0.proj", n3, nullptr, 8 * C, 1, 1, 1, true, nullptr, nullptr, kOutGeglu);
+  }
   return conv(ops, b + ".ff.net.2", g, nullptr, C, 1, 1, 1, true, nullptr, h2.p);
 }
 

@@ -43,9 +43,26 @@ class UNet {
   Tensor conv(std::vector<Op>& ops, const std::string& name, const Tensor& x, const Tensor* x2, int cout, int k,
               int stride, int up, bool bias, const float* temb, const half_t* res, int out_mode = kOutHalf,
               int ldT = 0, bool silu_out = false);
+  // optional extras of conv_w: LayerNorm fold (ln_colsum) and the fused q|k|v split (n_trans > 0:
+  // columns >= n_trans leave token-transposed in *vt, [B][cout - n_trans][ldT])
+  struct ConvExtra {
+    const float* ln_colsum = nullptr;
+    int n_trans = 0;
+    half_t* vt = nullptr;   // out
+  };
   Tensor conv_w(std::vector<Op>& ops, const std::string& name, const half_t* w, const float* bias, const Tensor& x,
                 const Tensor* x2, int cout, int k, int stride, int up, const float* temb, const half_t* res,
-                int out_mode, int ldT, bool silu_out);
+                int out_mode, int ldT, bool silu_out, ConvExtra* ex = nullptr);
+  // LayerNorm `ln` folded into the bias-free/biased 1x1 projections `names` (stacked along Cout) that
+  // consume it: returns w' = W*gamma (fp16), colsum of w', bias' = b + W.beta
+  struct LnFold {
+    half_t* w;
+    float* colsum;
+    float* bias;
+  };
+  LnFold fold_layernorm(const std::string& ln, const std::vector<std::string>& names, int cin, int cout_each,
+                        bool geglu);
+  bool can_fold_ln(const Tensor& x, int cout, bool geglu) const;
   Tensor conv_stacked(std::vector<Op>& ops, const std::vector<std::string>& names, const Tensor& x, int cout_each);
   Tensor group_norm(std::vector<Op>& ops, const std::string& name, const Tensor& x, const Tensor* x2, float eps,
                     bool silu);
