@@ -232,11 +232,28 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs a) {
       for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[t][sub][r] = 0.f;
+    // With one wave per SIMD nothing hides an LDS round trip, and the compiler's just-in-time
+    // ds_read -> s_waitcnt -> MFMA chains expose one per fragment: request every K fragment of the
+    // tile up front (d <= 64: 32 VGPRs), and the V^T fragments right behind the S MFMAs so that
+    // their latency disappears under the softmax VALU work.
+    constexpr bool KPRE = DK16 <= 4;
+    constexpr bool VPRE = DC32 <= 2 && DK16 <= 4;
+    half8 kfr[KPRE ? DK16 : 1][2];
+    if constexpr (KPRE) {
+#pragma unroll
+      for (int kk = 0; kk < DK16; ++kk)
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+          kfr[kk][sub] = *reinterpret_cast<const half8*>(ks + (sub * 32 + l31) * KROW + kk * 16 + hi * 8);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int kk = 0; kk < DK16; ++kk)   // kk outer: the two sub-tiles are independent MFMA chains
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
-        const half8 kf = *reinterpret_cast<const half8*>(ks + (sub * 32 + l31) * KROW + kk * 16 + hi * 8);
+        half8 kf;
+        if constexpr (KPRE) kf = kfr[kk][sub];
+        else kf = *reinterpret_cast<const half8*>(ks + (sub * 32 + l31) * KROW + kk * 16 + hi * 8);
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
           if constexpr (MODE == 0)   // rows = q, cols = key
@@ -245,6 +262,24 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs a) {
             sacc[t][sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[t][kk], sacc[t][sub], 0, 0, 0);
         }
       }
+
+    half8 vfr[VPRE ? 4 : 1][VPRE ? DC32 : 1];     // [16-key step][32-channel tile]
+    if constexpr (VPRE) {
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int ct = 0; ct < DC32; ++ct) {
+          if constexpr (MODE == 1) {   // keys of step s4 in the P-register order (two 4-key groups, 8 apart)
+            const half_t* vp = vs + (ct * 32 + l31) * VROW + s4 * 16 + 4 * hi;
+            const half4 v0 = *reinterpret_cast<const half4*>(vp);
+            const half4 v1 = *reinterpret_cast<const half4*>(vp + 8);
+            vfr[s4][ct] = half8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          } else {
+            vfr[s4][ct] = *reinterpret_cast<const half8*>(vs + (ct * 32 + l31) * VROW + s4 * 16 + hi * 8);
+          }
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
 
     if constexpr (MODE == 1) {
       // ======== SPLIT_EINSUM: lane = query column, registers = keys ========
@@ -301,10 +336,15 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs a) {
             for (int e = 0; e < 8; ++e) pf[t][e] = (half_t)sacc[t][sub][s2 * 8 + e];
 #pragma unroll
           for (int ct = 0; ct < DC32; ++ct) {
-            const half_t* vp = vs + (ct * 32 + l31) * VROW + sub * 32 + s2 * 16 + 4 * hi;
-            const half4 v0 = *reinterpret_cast<const half4*>(vp);
-            const half4 v1 = *reinterpret_cast<const half4*>(vp + 8);
-            const half8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            half8 vf;
+            if constexpr (VPRE) {
+              vf = vfr[sub * 2 + s2][ct];
+            } else {
+              const half_t* vp = vs + (ct * 32 + l31) * VROW + sub * 32 + s2 * 16 + 4 * hi;
+              const half4 v0 = *reinterpret_cast<const half4*>(vp);
+              const half4 v1 = *reinterpret_cast<const half4*>(vp + 8);
+              vf = half8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            }
 #pragma unroll
             for (int t = 0; t < QT; ++t)
               oacc[t][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[t], oacc[t][ct], 0, 0, 0);
@@ -362,7 +402,9 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs a) {
           pf[t] = *reinterpret_cast<const half8*>(ps + (t * 32 + l31) * PROW + s4 * 16 + hi * 8);
 #pragma unroll
         for (int ct = 0; ct < DC32; ++ct) {
-          const half8 vf = *reinterpret_cast<const half8*>(vs + (ct * 32 + l31) * VROW + s4 * 16 + hi * 8);
+          half8 vf;
+          if constexpr (VPRE) vf = vfr[s4][ct];
+          else vf = *reinterpret_cast<const half8*>(vs + (ct * 32 + l31) * VROW + s4 * 16 + hi * 8);
 #pragma unroll
           for (int t = 0; t < QT; ++t)
             oacc[t][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf[t], vf, oacc[t][ct], 0, 0, 0);

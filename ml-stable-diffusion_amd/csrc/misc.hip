@@ -28,17 +28,27 @@ __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v));
 
 // out[b][n] (+)= act_out( sum_k W[n][k] * act_in(x[b][k]) + bias[n] ), B <= BMAX rows of x.
 // Weight-streaming (HBM-bound, M <= 8: an LDS round trip would be pure overhead).  Each wavefront owns
-// GEMV_ROWS output rows: its slice of x (with the optional SiLU applied ONCE) lives in registers, weight
-// rows stream through with 16-B loads, two rows in flight, shuffle reduction per row.
-constexpr int GEMV_ROWS = 8;
-template <int BMAX, int GEMV_KITERS>   // K <= 64 lanes * 8 halves * GEMV_KITERS
+// ROWS output rows: its slice of x (with the optional SiLU applied ONCE) lives in registers and ALL of
+// its weight rows are requested up front (ROWS x KITERS 16-B loads in flight per lane - one exposed
+// HBM round trip per wave instead of one per row), then a shuffle reduction per row.
+template <int BMAX, int GEMV_KITERS, int ROWS>   // K <= 64 lanes * 8 halves * GEMV_KITERS
 __global__ __launch_bounds__(256) void gemv_kernel(const half_t* __restrict__ w, const float* __restrict__ bias,
                                                    const float* __restrict__ x, int ldx, float* __restrict__ out,
                                                    int ldo, int B, int N, int K, int silu_in, int silu_out,
                                                    int accumulate) {
   const int lane = threadIdx.x & 63;
-  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * GEMV_ROWS;
+  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
   if (n0 >= N) return;
+  half8 wv[ROWS][GEMV_KITERS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const half_t* wr = w + (size_t)min(n0 + r, N - 1) * K;   // clamped rows are computed and dropped
+#pragma unroll
+    for (int i = 0; i < GEMV_KITERS; ++i) {
+      const int k = (lane + 64 * i) * 8;
+      wv[r][i] = (k < K) ? *reinterpret_cast<const half8*>(wr + k) : half8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
   float xr[BMAX][GEMV_KITERS][8];
 #pragma unroll
   for (int b = 0; b < BMAX; ++b)
@@ -52,16 +62,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(const half_t* __restrict__ w,
         xr[b][i][e] = v;
       }
     }
-  for (int r = 0; r < GEMV_ROWS; ++r) {
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
     const int n = n0 + r;
     if (n >= N) break;   // wave-uniform
-    const half_t* wr = w + (size_t)n * K;
-    half8 wv[GEMV_KITERS];
-#pragma unroll
-    for (int i = 0; i < GEMV_KITERS; ++i) {
-      const int k = (lane + 64 * i) * 8;
-      wv[i] = (k < K) ? *reinterpret_cast<const half8*>(wr + k) : half8{0, 0, 0, 0, 0, 0, 0, 0};
-    }
 #pragma unroll
     for (int b = 0; b < BMAX; ++b) {
       if (b >= B) break;
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const half_t* __restrict__ w,
 #pragma unroll
       for (int i = 0; i < GEMV_KITERS; ++i)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc += (float)wv[i][e] * xr[b][i][e];
+        for (int e = 0; e < 8; ++e) acc += (float)wv[r][i][e] * xr[b][i][e];
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
       if (lane == 0) {
@@ -208,15 +212,14 @@ void launch_timestep_embedding(const float* t, const float* freq, float* out, in
 void launch_gemv(const half_t* w, const float* bias, const float* x, int ldx, float* out, int ldo, int B, int N,
                  int K, int silu_in, int silu_out, int accumulate, hipStream_t s) {
   SD_REQUIRE(K % 8 == 0 && K <= 64 * 8 * 6, kUnsupported, "gemv: K=%d must be a multiple of 8 and <= 3072", K);
-  const int blocks = cdiv(N, 4 * GEMV_ROWS);
   for (int b0 = 0; b0 < B; b0 += 4) {   // 4 x-rows per pass keeps the register footprint at 4*6*8 floats
     const int nb = std::min(4, B - b0);
-    if (K <= 64 * 8 * 3)
-      hipLaunchKernelGGL((gemv_kernel<4, 3>), dim3(blocks), dim3(256), 0, s, w, bias, x + (size_t)b0 * ldx, ldx,
-                         out + (size_t)b0 * ldo, ldo, nb, N, K, silu_in, silu_out, accumulate);
+    if (K <= 64 * 8 * 3)   // 8 rows x 3 chunks = 96 weight VGPRs in flight
+      hipLaunchKernelGGL((gemv_kernel<4, 3, 8>), dim3(cdiv(N, 4 * 8)), dim3(256), 0, s, w, bias, x + (size_t)b0 * ldx,
+                         ldx, out + (size_t)b0 * ldo, ldo, nb, N, K, silu_in, silu_out, accumulate);
     else
-      hipLaunchKernelGGL((gemv_kernel<4, 6>), dim3(blocks), dim3(256), 0, s, w, bias, x + (size_t)b0 * ldx, ldx,
-                         out + (size_t)b0 * ldo, ldo, nb, N, K, silu_in, silu_out, accumulate);
+      hipLaunchKernelGGL((gemv_kernel<4, 6, 4>), dim3(cdiv(N, 4 * 4)), dim3(256), 0, s, w, bias, x + (size_t)b0 * ldx,
+                         ldx, out + (size_t)b0 * ldo, ldo, nb, N, K, silu_in, silu_out, accumulate);
   }
   SD_HIP(hipGetLastError());
 }
