@@ -316,22 +316,29 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   };
 
   if (prof) prof_t[1] = clock64();
-  if constexpr (GLDS && NST == 3) {
-    // 3-stage ring: the DMA of tile kt+2 is issued while tile kt is computed and tile kt+1 is
-    // still in flight.  Raw s_barrier + COUNTED vmcnt (a __syncthreads() would drain vmcnt(0) and
-    // serialise the ring, cdna guide section 5 "Pipelining across barriers"); wait + barrier sit in
-    // one asm statement with a memory clobber so no LDS access is scheduled across them.
+  if constexpr (GLDS && NST >= 3) {
+    // NST-stage ring: the DMA of tile kt+NST-1 is issued while tile kt is computed and tiles
+    // kt+1 .. kt+NST-2 are still in flight (weight-streaming layers need the bytes in flight: at the
+    // 8x8 / 16x16 levels every K step of a two-stage loop is one exposed HBM round trip).
+    // Raw s_barrier + COUNTED vmcnt (a __syncthreads() would drain vmcnt(0) and serialise the ring,
+    // cdna guide section 5 "Pipelining across barriers"); wait + barrier sit in one asm statement
+    // with a memory clobber so no LDS access is scheduled across them.
     constexpr int PER_TILE = XR + WR;    // LDS-DMA instructions per wave per tile
-    if (kt_begin < kt_end) load_tile(0);
-    if (kt_begin + 1 < kt_end) load_tile(1);
+    static_assert((NST - 2) * PER_TILE <= 63, "vmcnt range");
+#pragma unroll
+    for (int p = 0; p < NST - 1; ++p)
+      if (kt_begin + p < kt_end) load_tile(p);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       const int rel = kt - kt_begin;
-      if (kt + 1 < kt_end)
+      const int ahead = kt_end - 1 - kt;   // tiles after this one that are already issued (capped below)
+      if (NST >= 4 && ahead >= 2)
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * PER_TILE) : "memory");
+      else if (ahead >= 1)
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PER_TILE) : "memory");
       else
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-      read_frags(rel % 3);
-      if (kt + 2 < kt_end) load_tile((rel + 2) % 3);
+      read_frags(rel % NST);
+      if (kt + NST - 1 < kt_end) load_tile((rel + NST - 1) % NST);
       mfma_step();
     }
   } else if constexpr (GLDS) {
@@ -1019,6 +1026,7 @@ IgemmArgs make_args(const ConvDesc& d) {
 struct Plan {
   int tile;     // 1: 128x128, 2: 128x64, 3: 64x64, 4: 64x128
   int splitk;
+  int staging = 0;   // from the tuned table (tile / 10): 0 two-stage LDS-DMA, 2 / 3 = 3- / 4-stage ring
 };
 
 bool halo_ok(const ConvDesc& d) {
@@ -1079,7 +1087,8 @@ Plan choose_plan(const ConvDesc& d, const IgemmArgs& a) {
     for (int i = 0; i < kNumTuned; ++i) {
       const TunedConv& t = kTuned[i];
       if (t.ksize == a.ksize && t.stride == a.stride && t.up == a.up && t.ctot == a.Ctot && t.n == a.N && t.m == a.M) {
-        p.tile = t.tile;
+        p.tile = t.tile % 10;
+        p.staging = t.tile / 10;
         p.splitk = t.splitk;
         if (is_halo(p.tile) && !halo_ok(d)) p.tile = p.splitk = 0;
         break;
@@ -1160,7 +1169,7 @@ bool launch_debug_mode(const IgemmArgs& a, int dbg, hipStream_t s) {
   }
 }
 
-// staging: 0 = LDS-DMA 2 stages, 1 = register staging (A/B reference), 2 = LDS-DMA 3-stage ring
+// staging: 0 = LDS-DMA 2 stages, 1 = register staging (A/B reference), 2 / 3 = LDS-DMA 3- / 4-stage ring
 template <int BM, int BN, int WGM, int WGN>
 void launch_tile(const IgemmArgs& a, bool trans, int staging, hipStream_t s) {
   if (a.ln_colsum) {   // LayerNorm-folded 1x1 GEMM: LDS-DMA two-stage kernel only
@@ -1174,6 +1183,7 @@ void launch_tile(const IgemmArgs& a, bool trans, int staging, hipStream_t s) {
   } else {
     if (staging == 1) launch_variant<BM, BN, WGM, WGN, false, false, 2>(a, s);
     else if (staging == 2) launch_variant<BM, BN, WGM, WGN, false, true, 3>(a, s);
+    else if (staging == 3) launch_variant<BM, BN, WGM, WGN, false, true, 4>(a, s);
     else launch_variant<BM, BN, WGM, WGN, false, true, 2>(a, s);
   }
 }
@@ -1224,7 +1234,7 @@ void launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
     a.partial = ws.partial;
   }
   const bool trans = d.out_mode == kOutHalfT;
-  const int st = d.staging;
+  const int st = d.staging ? d.staging : p.staging;
   static const bool log_plans = getenv("SD_LOG_CONVS") != nullptr;
   if (log_plans)
     fprintf(stderr, "[sd conv] k%d s%d up%d C0=%d C1=%d M=%d N=%d K=%d mode=%d tile=%d splitk=%d\n", a.ksize, a.stride, a.up,

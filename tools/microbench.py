@@ -48,7 +48,10 @@ def main():
         m = B * ho * ho
         res = {}
         splitks = [0, 1, 2] if m >= 2048 else [1, 2, 4, 8, 16]
-        for tile in ((1, 2, 3, 4, 5, 6) if (k == 3 and s == 1 and not up and w >= 16) else (1, 2, 3, 4)):
+        tiles = (1, 2, 3, 4, 5, 6) if (k == 3 and s == 1 and not up and w >= 16) else (1, 2, 3, 4)
+        if m <= 2048 and k == 3:
+            tiles = tiles + (21, 23, 24, 33)      # LDS-DMA rings (3 / 4 stages) for the weight-streaming levels
+        for tile in tiles:
             for sk in splitks:
                 try:
                     _, ms = _lib.conv2d(x, wt, bias, None, stride=s, upsample=bool(up), tile=tile, splitk=sk, iters=10)
@@ -56,7 +59,7 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     res[f"t{tile}_k{sk}"] = str(e)
         _, ms_auto = _lib.conv2d(x, wt, bias, None, stride=s, upsample=bool(up), iters=10)
-        good = {kk: v for kk, v in res.items() if isinstance(v, float) and kk[2] == "_"}   # 2-stage variants only
+        good = {kk: v for kk, v in res.items() if isinstance(v, float)}
         best = min(good, key=good.get)
         out["conv"].append(dict(k=k, stride=s, cin=cin, cout=cout, h=h, w=w, up=up, count=count, M=m, gflop=flop / 1e9,
                                 auto_ms=ms_auto, auto_tflops=flop / ms_auto / 1e9, best=best, best_ms=good[best],
@@ -80,8 +83,6 @@ def main():
             _, ms = _lib.attention(impl, q, kk, v, heads, 64, iters=10)
             row[impl] = ms
             row[impl + "_tflops"] = flop / ms / 1e9
-        _, ms = _lib.attention("ORIGINAL", q, kk, v, heads, 64, variant=1, iters=10)
-        row["ORIGINAL_bpermute"] = ms
         out["attention"].append(row)
         print(f"attn h{heads} {sq}x{sk}: " + " ".join(f"{i} {row[i]:.4f} ms ({row[i + '_tflops']:.0f} TF)"
                                                       for i in ("ORIGINAL", "SPLIT_EINSUM", "SPLIT_EINSUM_V2")), flush=True)
