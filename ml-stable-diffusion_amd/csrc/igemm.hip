@@ -1063,7 +1063,7 @@ void tile_dims(int tile, int& bm, int& bn) {
 }
 
 // Heuristic (overridden per shape by the measured table in tuned_convs.inc when present):
-// prefer the biggest tile whose grid, multiplied by the split-K it can afford (>= 8 K-tiles per
+// prefer the biggest tile whose grid, multiplied by the split-K it can afford (>= 16 K-tiles per
 // split), still gives every CU work (>= ~1.5 workgroups per CU); deep-K small-M layers (8x8 /
 // 16x16 levels stream weights: SURVEY.md 7.3(1)) end up split, shallow 1x1 GEMMs end up on the
 // small tile with many workgroups.
@@ -1094,7 +1094,9 @@ Plan choose_plan(const ConvDesc& d, const IgemmArgs& a) {
   };
   auto ksteps = [&](int c) { return is_halo(c) ? a.Ctot / BK : a.nk_total; };   // split-K granularity
   auto max_split = [&](int c) {
-    const int per_min = is_halo(c) ? 2 : 8;      // halo splits whole 64-channel chunks (9 K steps each)
+    // a split costs a dependent reduce launch (~6 us): worth it only while each split still runs >= 16 K
+    // steps (measured: 20-step 1x1 GEMMs lose 2.5 us when split in two, 180-step 3x3 convs peak at 8 splits)
+    const int per_min = is_halo(c) ? 2 : 16;     // halo splits whole 64-channel chunks (9 K steps each)
     int s = 1;
     while (can_split && s < 16 && ksteps(c) / (s * 2) >= per_min) s *= 2;
     return s;
