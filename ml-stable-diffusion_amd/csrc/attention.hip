@@ -9,9 +9,11 @@
 //                    column and reduces over keys IN REGISTERS - no cross-lane traffic except one
 //                    half-wave exchange; P feeds the P.V MFMA straight from registers.
 //   SPLIT_EINSUM_V2  attention.py:77-144   SPLIT_EINSUM with the query axis cut into 512-query
-//                    workgroup chunks (CHUNK_SIZE attention.py:75): 8 waves x 64 queries.  Falls
-//                    back to SPLIT_EINSUM when S_q < 512 (attention.py:88-92) and rejects
-//                    S_q % 512 != 0 instead of silently dropping the tail (attention.py:86).
+//                    chunks (CHUNK_SIZE attention.py:75): one 8-wave workgroup x 64 queries per
+//                    wave per chunk, or 2 / 4 smaller workgroups per chunk when the launch has too
+//                    few chunks to fill the chip.  Falls back to SPLIT_EINSUM when S_q < 512
+//                    (attention.py:88-92) and rejects S_q % 512 != 0 instead of silently dropping
+//                    the tail (attention.py:86).
 //
 // All three: scores never touch HBM (the reference materialises attn_weights, 335 MB at
 // S=4096), scale d^-0.5 applied to the scores (attention.py:49,123,159) folded with log2(e) so
@@ -479,14 +481,27 @@ void launch_one(const AttnArgs& a, int B, hipStream_t s) {
 
 template <int DK16, int DC32>
 void launch_d(const AttnArgs& a, int B, int impl, hipStream_t s) {
-  if (impl == kAttnOriginal)
+  if (impl == kAttnOriginal) {
     launch_one<DK16, DC32, 0, 4, 1>(a, B, s);
-  else if (impl == kAttnSplitEinsum)
+  } else if (impl == kAttnSplitEinsum) {
     launch_one<DK16, DC32, 1, 4, 1>(a, B, s);
-  else if constexpr (DC32 <= 2)
-    launch_one<DK16, DC32, 1, 8, 2>(a, B, s);   // one 512-query chunk per workgroup (8 waves x 64 queries)
-  else
-    launch_one<DK16, DC32, 1, 8, 1>(a, B, s);   // d > 64: register budget -> two 256-query workgroups per chunk
+  } else {
+    // SPLIT_EINSUM_V2: the query axis is cut into 512-query chunks (attention.py:75-86).  A chunk is
+    // one 8-wave workgroup (64 queries per wave) when the launch has enough chunks to fill the 256
+    // CUs; with few chunks (CFG batch 2 at 64x64: 80) each chunk is split over two 256-query or four
+    // 128-query workgroups instead - same chunk arithmetic, more workgroups in flight.
+    const long chunks = (long)B * a.heads * cdiv(a.Sq, 512);
+    if constexpr (DC32 <= 2) {
+      if (chunks >= 192) {
+        launch_one<DK16, DC32, 1, 8, 2>(a, B, s);
+        return;
+      }
+    }
+    if (chunks * 2 >= 192)
+      launch_one<DK16, DC32, 1, 8, 1>(a, B, s);   // also: d > 64 (register budget of two query tiles per wave)
+    else
+      launch_one<DK16, DC32, 1, 4, 1>(a, B, s);
+  }
 }
 
 }  // namespace

@@ -97,10 +97,11 @@ def lib():
         raise LibraryNotBuilt(
             f"{LIB_PATH} is missing - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             f"or `make -C ml-stable-diffusion_amd/csrc`. There is no CPU fallback.")
-    try:
-        import torch  # noqa: F401  (plumbing only: shares libamdhip64 / RCCL with torch.distributed)
-    except Exception:  # pragma: no cover - torch is optional for the library itself
-        pass
+    if not os.environ.get("SD_MI355X_NO_TORCH"):
+        try:
+            import torch  # noqa: F401  (plumbing only: shares libamdhip64 / RCCL with torch.distributed)
+        except Exception:  # pragma: no cover - torch is optional for the library itself
+            pass
     handle = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, restype, argtypes in SYMBOLS:
         fn = getattr(handle, name)   # AttributeError here == header/library mismatch
