@@ -239,6 +239,10 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs a) {
     // tile up front (d <= 64: 32 VGPRs), and the V^T fragments right behind the S MFMAs so that
     // their latency disappears under the softmax VALU work.
     constexpr bool KPRE = DK16 <= 4;
+    // Key row that lane l31 of sub-tile `sub` multiplies.  ORIGINAL interleaves the two sub-tiles
+    // (keys 2*l31 and 2*l31+1) so that a lane's two probabilities of a query row are ADJACENT keys:
+    // one packed 32-bit P write per row instead of two 16-bit ones, P and V^T stay in key order.
+    auto krow = [&](int sub) { return MODE == 0 ? 2 * l31 + sub : sub * 32 + l31; };
     constexpr bool VPRE = DC32 <= 2 && DK16 <= 4;
     half8 kfr[KPRE ? DK16 : 1][2];
     if constexpr (KPRE) {
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs a) {
       for (int kk = 0; kk < DK16; ++kk)
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
-          kfr[kk][sub] = *reinterpret_cast<const half8*>(ks + (sub * 32 + l31) * KROW + kk * 16 + hi * 8);
+          kfr[kk][sub] = *reinterpret_cast<const half8*>(ks + krow(sub) * KROW + kk * 16 + hi * 8);
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs a) {
       for (int sub = 0; sub < 2; ++sub) {
         half8 kf;
         if constexpr (KPRE) kf = kfr[kk][sub];
-        else kf = *reinterpret_cast<const half8*>(ks + (sub * 32 + l31) * KROW + kk * 16 + hi * 8);
+        else kf = *reinterpret_cast<const half8*>(ks + krow(sub) * KROW + kk * 16 + hi * 8);
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
           if constexpr (MODE == 0)   // rows = q, cols = key
@@ -362,8 +366,8 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           if (tail) {
-            if (kt * KT + l31 >= a.Sk) sacc[t][0][r] = -3.0e38f;
-            if (kt * KT + 32 + l31 >= a.Sk) sacc[t][1][r] = -3.0e38f;
+            if (kt * KT + 2 * l31 >= a.Sk) sacc[t][0][r] = -3.0e38f;
+            if (kt * KT + 2 * l31 + 1 >= a.Sk) sacc[t][1][r] = -3.0e38f;
           }
           mnew[r] = fmaxf(sacc[t][0][r], sacc[t][1][r]);   // in-lane over the two 32-key sub-tiles
         }
@@ -382,17 +386,17 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs a) {
             lrun[t][r] *= alpha;
 #pragma unroll
             for (int ct = 0; ct < DC32; ++ct) oacc[t][ct][r] *= alpha;
-            mrun[t][r] = mnew[r];
           }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+          mrun[t][r] = mnew[r];                        // == the old value on rows that did not move
           const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[t][0][r], a.scale_log2, -mnew[r]));
           const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[t][1][r], a.scale_log2, -mnew[r]));
           lrun[t][r] += p0 + p1;                       // per-lane partial, reduced at the end
           const int qrow = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          ps[qrow * PROW + l31] = (half_t)p0;
-          ps[qrow * PROW + 32 + l31] = (half_t)p1;
+          const half2v pp = {(half_t)p0, (half_t)p1};  // keys 2*l31, 2*l31+1
+          *reinterpret_cast<half2v*>(ps + qrow * PROW + 2 * l31) = pp;
         }
       }
       __builtin_amdgcn_wave_barrier();   // P tile is wave-private; LDS ops of one wave complete in order
