@@ -24,14 +24,39 @@ __global__ void timestep_embedding_kernel(const float* __restrict__ t, const flo
   out[(size_t)row * dim + half + i] = sinf(arg);
 }
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
+__device__ __forceinline__ float silu_f(float v) {   // v * sigmoid(v) on the native exp2 / rcp units
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+// sum over the 64 lanes, result in every lane: 4 DPP steps inside each 16-lane row, then the
+// gfx950 v_permlane16_swap / v_permlane32_swap exchanges across rows and wave halves
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const unsigned r0 = r[0], r1 = r[1];   // scalars first (bit-casting a vector-element lvalue reads lane 0 twice)
+  v = __uint_as_float(r0) + __uint_as_float(r1);
+  const unsigned u2 = __float_as_uint(v);
+  const auto q = __builtin_amdgcn_permlane32_swap(u2, u2, false, false);
+  const unsigned q0 = q[0], q1 = q[1];
+  return __uint_as_float(q0) + __uint_as_float(q1);
+}
 
 // out[b][n] (+)= act_out( sum_k W[n][k] * act_in(x[b][k]) + bias[n] ), B <= BMAX rows of x.
 // Weight-streaming (HBM-bound, M <= 8: an LDS round trip would be pure overhead).  Each wavefront owns
-// ROWS output rows: its slice of x (with the optional SiLU applied ONCE) lives in registers and ALL of
-// its weight rows are requested up front (ROWS x KITERS 16-B loads in flight per lane - one exposed
-// HBM round trip per wave instead of one per row), then a shuffle reduction per row.
-template <int BMAX, int GEMV_KITERS, int ROWS>   // K <= 64 lanes * 8 halves * GEMV_KITERS
+// ROWS output rows: ALL of its weight rows are requested up front (ROWS x KITERS 16-B loads in flight
+// per lane - one exposed HBM round trip per wave), its slice of x arrives by unconditional 16-B loads
+// (row / column indices clamped, out-of-range values zeroed by select - a per-element branchy load
+// costs a dependent memory round trip each) with the optional SiLU applied once, then one wave
+// reduction per (row, batch) pair.
+template <int BMAX, int GEMV_KITERS, int ROWS>   // K <= 64 lanes * 8 halves * GEMV_KITERS, K % 8 == 0
 __global__ __launch_bounds__(256) void gemv_kernel(const half_t* __restrict__ w, const float* __restrict__ bias,
                                                    const float* __restrict__ x, int ldx, float* __restrict__ out,
                                                    int ldo, int B, int N, int K, int silu_in, int silu_out,
@@ -46,43 +71,55 @@ __global__ __launch_bounds__(256) void gemv_kernel(const half_t* __restrict__ w,
 #pragma unroll
     for (int i = 0; i < GEMV_KITERS; ++i) {
       const int k = (lane + 64 * i) * 8;
-      wv[r][i] = (k < K) ? *reinterpret_cast<const half8*>(wr + k) : half8{0, 0, 0, 0, 0, 0, 0, 0};
+      wv[r][i] = *reinterpret_cast<const half8*>(wr + min(k, K - 8));
     }
   }
   float xr[BMAX][GEMV_KITERS][8];
 #pragma unroll
-  for (int b = 0; b < BMAX; ++b)
+  for (int b = 0; b < BMAX; ++b) {
+    const float* xb = x + (size_t)min(b, B - 1) * ldx;
 #pragma unroll
     for (int i = 0; i < GEMV_KITERS; ++i) {
       const int k = (lane + 64 * i) * 8;
+      const bool in = k < K;                      // out-of-range chunks contribute x = 0
+      const floatx4 lo = *reinterpret_cast<const floatx4*>(xb + min(k, K - 8));
+      const floatx4 hi = *reinterpret_cast<const floatx4*>(xb + min(k, K - 8) + 4);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float v = (b < B && k < K) ? x[(size_t)b * ldx + k + e] : 0.f;
+        float v = e < 4 ? lo[e] : hi[e - 4];
         if (silu_in) v = silu_f(v);
-        xr[b][i][e] = v;
+        xr[b][i][e] = in ? v : 0.f;
       }
     }
+  }
+  float acc[ROWS][BMAX];
 #pragma unroll
-  for (int r = 0; r < ROWS; ++r) {
-    const int n = n0 + r;
-    if (n >= N) break;   // wave-uniform
+  for (int r = 0; r < ROWS; ++r)
 #pragma unroll
     for (int b = 0; b < BMAX; ++b) {
-      if (b >= B) break;
-      float acc = 0.f;
+      float s = 0.f;
 #pragma unroll
       for (int i = 0; i < GEMV_KITERS; ++i)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc += (float)wv[r][i][e] * xr[b][i][e];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-      if (lane == 0) {
-        acc += bias ? bias[n] : 0.f;
-        if (silu_out) acc = silu_f(acc);
-        float* dst = out + (size_t)b * ldo + n;
-        *dst = accumulate ? (*dst + acc) : acc;
-      }
+        for (int e = 0; e < 8; ++e) s = fmaf((float)wv[r][i][e], xr[b][i][e], s);
+      acc[r][b] = s;
     }
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int b = 0; b < BMAX; ++b) acc[r][b] = wave_sum(acc[r][b]);
+  // every lane now holds every sum: lane r*BMAX+b keeps result (r, b) and runs the one epilogue
+  float mine = 0.f;
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int b = 0; b < BMAX; ++b) mine = (lane == r * BMAX + b) ? acc[r][b] : mine;
+  const int n = n0 + lane / BMAX, b = lane % BMAX;
+  if (lane < ROWS * BMAX && n < N && b < B) {
+    float v = mine + (bias ? bias[n] : 0.f);
+    if (silu_out) v = silu_f(v);
+    float* dst = out + (size_t)b * ldo + n;
+    *dst = accumulate ? (*dst + v) : v;
   }
 }
 
@@ -212,14 +249,22 @@ void launch_timestep_embedding(const float* t, const float* freq, float* out, in
 void launch_gemv(const half_t* w, const float* bias, const float* x, int ldx, float* out, int ldo, int B, int N,
                  int K, int silu_in, int silu_out, int accumulate, hipStream_t s) {
   SD_REQUIRE(K % 8 == 0 && K <= 64 * 8 * 6, kUnsupported, "gemv: K=%d must be a multiple of 8 and <= 3072", K);
-  for (int b0 = 0; b0 < B; b0 += 4) {   // 4 x-rows per pass keeps the register footprint at 4*6*8 floats
+  // up to 4 x-rows per pass (register footprint); the CFG batch of 2 gets its own instantiation
+  for (int b0 = 0; b0 < B; b0 += 4) {
     const int nb = std::min(4, B - b0);
-    if (K <= 64 * 8 * 3)   // 8 rows x 3 chunks = 96 weight VGPRs in flight
-      hipLaunchKernelGGL((gemv_kernel<4, 3, 8>), dim3(cdiv(N, 4 * 8)), dim3(256), 0, s, w, bias, x + (size_t)b0 * ldx,
-                         ldx, out + (size_t)b0 * ldo, ldo, nb, N, K, silu_in, silu_out, accumulate);
-    else
-      hipLaunchKernelGGL((gemv_kernel<4, 6, 4>), dim3(cdiv(N, 4 * 4)), dim3(256), 0, s, w, bias, x + (size_t)b0 * ldx,
-                         ldx, out + (size_t)b0 * ldo, ldo, nb, N, K, silu_in, silu_out, accumulate);
+    const float* xp = x + (size_t)b0 * ldx;
+    float* op = out + (size_t)b0 * ldo;
+    if (K <= 64 * 8 * 3) {   // 8 rows x 3 chunks = 96 weight VGPRs in flight
+      if (nb <= 2)
+        hipLaunchKernelGGL((gemv_kernel<2, 3, 8>), dim3(cdiv(N, 4 * 8)), dim3(256), 0, s, w, bias, xp, ldx, op, ldo, nb, N, K,
+                           silu_in, silu_out, accumulate);
+      else
+        hipLaunchKernelGGL((gemv_kernel<4, 3, 8>), dim3(cdiv(N, 4 * 8)), dim3(256), 0, s, w, bias, xp, ldx, op, ldo, nb, N, K,
+                           silu_in, silu_out, accumulate);
+    } else {
+      hipLaunchKernelGGL((gemv_kernel<4, 6, 4>), dim3(cdiv(N, 4 * 4)), dim3(256), 0, s, w, bias, xp, ldx, op, ldo, nb, N, K,
+                         silu_in, silu_out, accumulate);
+    }
   }
   SD_HIP(hipGetLastError());
 }
