@@ -217,7 +217,8 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs a) {
   // One key tile.  LAST is a compile-time flag: only the final tile can be ragged (needs the
   // -inf masking) and has nothing to prefetch, so the steady-state loop carries neither the
   // per-score compare/select nor the conditional loads (the compiler if-converts a runtime flag).
-  auto tile_step = [&](const int kt, auto last_c) {
+  auto tile_step = [&](const int kt, auto first_c, auto last_c) {
+    constexpr bool FIRST = decltype(first_c)::value;   // ORIGINAL: the first tile seeds the running max exactly
     constexpr bool LAST = decltype(last_c)::value;
     const int buf = kt & 1;
     constexpr bool more = !LAST;
@@ -361,38 +362,64 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs a) {
       half_t* ps = Ps + wave * (QT * 32) * PROW;
 #pragma unroll
       for (int t = 0; t < QT; ++t) {
-        float mnew[16];
-        bool moved = false;
+        // Lazy running max.  The first tile seeds the running max exactly.  Every later tile forms
+        // its exponent arguments against the OLD running max (in place of the scores) and takes the
+        // exact row max - 16 rows x 5 cross-lane butterfly steps, the bulk of this schedule's VALU
+        // work - only when some argument exceeds 2^kLazyBits; then the maxima move up by exactly
+        // that excess and O, l are rescaled.  Softmax is invariant to the stabiliser; P stays
+        // <= 2^kLazyBits (fp16-safe) and never underflows earlier than with the exact max of the
+        // tiles seen so far would allow by more than that factor.
+        constexpr float kLazyBits = 8.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           if (tail) {
             if (kt * KT + 2 * l31 >= a.Sk) sacc[t][0][r] = -3.0e38f;
             if (kt * KT + 2 * l31 + 1 >= a.Sk) sacc[t][1][r] = -3.0e38f;
           }
-          mnew[r] = fmaxf(sacc[t][0][r], sacc[t][1][r]);   // in-lane over the two 32-key sub-tiles
         }
-        // row max across the 32 lanes, butterfly step-major over the 16 rows: consecutive DPP ops
-        // are independent, so none of them waits on the VALU->DPP hazard of its predecessor
-        half_wave_max16(mnew);
+        if constexpr (FIRST) {
+          float mnew[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          mnew[r] = fmaxf(mrun[t][r], mnew[r] * a.scale_log2);
-          moved |= mnew[r] > mrun[t][r];
-        }
-        if (__any(moved)) {                            // wave-uniform: rescale only when some row's max moved
+          for (int r = 0; r < 16; ++r) mnew[r] = fmaxf(sacc[t][0][r], sacc[t][1][r]);
+          // row max across the 32 lanes, butterfly step-major over the 16 rows: consecutive DPP ops
+          // are independent, so none of them waits on the VALU->DPP hazard of its predecessor
+          half_wave_max16(mnew);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const float alpha = __builtin_amdgcn_exp2f(mrun[t][r] - mnew[r]);
-            lrun[t][r] *= alpha;
+            mrun[t][r] = mnew[r] * a.scale_log2;
+            sacc[t][0][r] = fmaf(sacc[t][0][r], a.scale_log2, -mrun[t][r]);
+            sacc[t][1][r] = fmaf(sacc[t][1][r], a.scale_log2, -mrun[t][r]);
+          }
+        } else {
+          float amax = -3.0e38f;
 #pragma unroll
-            for (int ct = 0; ct < DC32; ++ct) oacc[t][ct][r] *= alpha;
+          for (int r = 0; r < 16; ++r) {
+            sacc[t][0][r] = fmaf(sacc[t][0][r], a.scale_log2, -mrun[t][r]);
+            sacc[t][1][r] = fmaf(sacc[t][1][r], a.scale_log2, -mrun[t][r]);
+            amax = fmaxf(amax, fmaxf(sacc[t][0][r], sacc[t][1][r]));
+          }
+          if (__any(amax > kLazyBits)) {               // wave-uniform, rare after the first tiles
+            float up[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) up[r] = fmaxf(sacc[t][0][r], sacc[t][1][r]);
+            half_wave_max16(up);                       // how far each row's max moved above the old one
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float d = fmaxf(up[r], 0.f);
+              const float alpha = __builtin_amdgcn_exp2f(-d);
+              mrun[t][r] += d;
+              lrun[t][r] *= alpha;
+#pragma unroll
+              for (int ct = 0; ct < DC32; ++ct) oacc[t][ct][r] *= alpha;
+              sacc[t][0][r] -= d;
+              sacc[t][1][r] -= d;
+            }
           }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          mrun[t][r] = mnew[r];                        // == the old value on rows that did not move
-          const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[t][0][r], a.scale_log2, -mnew[r]));
-          const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[t][1][r], a.scale_log2, -mnew[r]));
+          const float p0 = __builtin_amdgcn_exp2f(sacc[t][0][r]);
+          const float p1 = __builtin_amdgcn_exp2f(sacc[t][1][r]);
           lrun[t][r] += p0 + p1;                       // per-lane partial, reduced at the end
           const int qrow = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
           const half2v pp = {(half_t)p0, (half_t)p1};  // keys 2*l31, 2*l31+1
@@ -424,8 +451,18 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs a) {
       __syncthreads();
     }
   };
-  for (int kt = 0; kt + 1 < ntiles; ++kt) tile_step(kt, std::false_type{});
-  tile_step(ntiles - 1, std::true_type{});
+  if constexpr (MODE == 0) {
+    if (ntiles == 1) {
+      tile_step(0, std::true_type{}, std::true_type{});
+    } else {
+      tile_step(0, std::true_type{}, std::false_type{});
+      for (int kt = 1; kt + 1 < ntiles; ++kt) tile_step(kt, std::false_type{}, std::false_type{});
+      tile_step(ntiles - 1, std::false_type{}, std::true_type{});
+    }
+  } else {
+    for (int kt = 0; kt + 1 < ntiles; ++kt) tile_step(kt, std::false_type{}, std::false_type{});
+    tile_step(ntiles - 1, std::false_type{}, std::true_type{});
+  }
 
   // ---------------- normalise + store ----------------
   half_t* obase = a.out + (size_t)b * a.Sq * a.ldo + (size_t)h * a.d;
