@@ -96,6 +96,31 @@ def test_attention_running_max_rescale_branch(impl):
     close(out, ref, f"{impl} rescale")
 
 
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("pattern", ["rising", "falling", "outlier_query", "flat", "ragged_rising"])
+def test_attention_lazy_running_max_patterns(impl, pattern):
+    """ORIGINAL refreshes its running max lazily (only when a tile exceeds the old max by 2^8) and
+    the SPLIT schedules skip the rescale when no max moved: score profiles that refresh on every
+    tile, never after the first, for one row only, and never at all (all scores equal)."""
+    b, h, d, sq, sk = 1, 2, 64, 256, 448 if pattern != "ragged_rising" else 397
+    rs = np.random.RandomState(11)
+    q, k, v = (rs.randn(b, h * d, 1, n).astype(np.float32) for n in (sq, sk, sk))
+    tile = np.arange(sk) // 64
+    if pattern in ("rising", "ragged_rising"):
+        k *= (1.0 + 0.9 * tile)[None, None, None, :]          # every 64-key tile raises the max
+    elif pattern == "falling":
+        k *= (6.0 / (1.0 + tile))[None, None, None, :]        # the first tile dominates
+    elif pattern == "outlier_query":
+        q[:, :, :, 37] *= 12.0                                # one row keeps triggering the wave-wide vote
+        k *= (1.0 + 0.4 * tile)[None, None, None, :]
+    elif pattern == "flat":
+        q[:] = 0.0                                            # all scores 0 -> uniform weights
+    q, k, v = h16(q), h16(k), h16(v)
+    out, _ = _lib.attention(impl, q, k, v, h, d)
+    ref = attention_ref.original(q.astype(np.float32), k.astype(np.float32), v.astype(np.float32), h, d)
+    close(out, ref, f"{impl} lazy-max {pattern}")
+
+
 def test_three_attention_schedules_agree_with_each_other():
     rs = np.random.RandomState(9)
     q, k, v = (h16(rs.randn(2, 320, 1, n)) for n in (1024, 1024, 1024))
