@@ -511,11 +511,8 @@ void launch_one(const AttnArgs& a, int B, hipStream_t s) {
   size_t lds = (size_t)2 * KT * (DKP + 8) * 2 + (size_t)2 * DCP * VROW * 2;
   if (MODE == 0) lds += (size_t)WAVES * QT * 32 * (KT + 8) * 2;
   auto k = attn_kernel<DK16, DC32, MODE, WAVES, QT>;
-  static bool attr = false;
-  if (!attr) {
-    SD_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr = true;
-  }
+  static DynLdsOnce once;   // per instantiation, per device
+  once.set(k, lds);
   dim3 grid(cdiv(a.Sq, WAVES * QT * 32), a.heads, B);
   hipLaunchKernelGGL(k, grid, dim3(WAVES * 64), lds, s, a);
 }

@@ -1144,11 +1144,8 @@ void launch_halo(IgemmArgs a, int splitk, hipStream_t s) {
   a.splitk = cdiv(nch, a.nk_per_split);
   const size_t lds = ((size_t)2 * HALO_LDS_ROWS * BK + (size_t)2 * BN * BK) * sizeof(half_t);
   auto k = conv3x3_halo_kernel<BN>;
-  static bool attr = false;
-  if (!attr) {
-    SD_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr = true;
-  }
+  static DynLdsOnce once;   // per instantiation, per device
+  once.set(k, lds);
   dim3 grid(a.B * a.tiles_x * a.tiles_y * cdiv(a.N, BN), a.splitk);
   hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
 }
@@ -1159,11 +1156,8 @@ void launch_variant(const IgemmArgs& a, hipStream_t s) {
   static_assert((size_t)BN * (BM + 8) <= (size_t)NST * (BM + BN) * (GLDS ? BK : LDS_ROW), "transposed staging fits");
   dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), a.splitk);
   auto k = igemm_kernel<BM, BN, WGM, WGN, TRANS, GLDS, NST, 0, LNF>;
-  static bool attr = false;
-  if (!attr) {
-    SD_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr = true;
-  }
+  static DynLdsOnce once;   // per instantiation, per device
+  once.set(k, lds);
   hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
 }
 

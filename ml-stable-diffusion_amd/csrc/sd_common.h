@@ -78,4 +78,20 @@ struct DevBuf {
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per (kernel, device): remember it per device so a
+// process that drives several GPUs (one handle per device) raises the limit on each of them.
+struct DynLdsOnce {
+  bool done[32] = {};
+  template <class K>
+  void set(K kernel, size_t bytes) {
+    int dev = 0;
+    SD_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 32 || !done[dev]) {
+      SD_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+      if (dev >= 0 && dev < 32) done[dev] = true;
+    }
+  }
+};
+
 }  // namespace sd
