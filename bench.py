@@ -145,6 +145,8 @@ def main():
         "e2e": {"model_build_s": round(build_s, 1), "final_latents_finite": True,
                 "gathered_latents": list(all_final.shape), "hbm_bytes": int(model.device_bytes)},
     }
+    if world == 1:   # the most FLOP-heavy single kernel of the step, timed alone through the C ABI
+        out["roofline"]["dominant_kernel"] = dominant_kernel()
     if world == 1:   # end-to-end latency of one generation: 20 DDIM steps + VAE decode (pipeline.py:500-589)
         out["e2e"].update(e2e_latency(model, checkpoint, my_ehs[[0, ppg]], latents[:1], args.guidance_scale,
                                       local_rank))
@@ -153,6 +155,22 @@ def main():
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def dominant_kernel():
+    """3x3 convolutions are 49.8 % of the step's FLOPs; the 320->320 conv at 64x64
+    (seven per step, 15.1 GFLOP each at CFG batch 2) is the largest family.  HIP-event time of the
+    conv kernel the step graph uses for that shape, launched alone (inputs L2/MALL-warm)."""
+    from python_hip_stable_diffusion import _lib
+    rs = np.random.RandomState(7)
+    x = rs.randn(2, 320, 64, 64).astype(np.float16)
+    w = (rs.randn(320, 320, 3, 3) / np.sqrt(320 * 9)).astype(np.float16)
+    _, ms = _lib.conv2d(x, w, np.zeros(320, np.float32), None, iters=50)
+    flop = 2.0 * 2 * 64 * 64 * 320 * 320 * 9
+    tf = flop / (ms * 1e-3) / 1e12
+    return {"kernel": "3x3 conv 320->320 @64x64, CFG batch 2 (implicit-GEMM / LDS-halo MFMA kernel, plan from tuned_convs.inc)",
+            "flop_per_launch": flop, "launch_ms": round(ms, 5), "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "bound": "L2->LDS operand fill (DESIGN.md section 3)"}
 
 
 def e2e_latency(model, checkpoint, ehs, latents, guidance, device):
