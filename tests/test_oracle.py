@@ -38,6 +38,31 @@ def test_layernorm_oracle_matches_reference_golden():
     np.testing.assert_allclose(out, g["out"], atol=2e-6)
 
 
+def test_layernorm_fold_identity_used_by_the_gemm_kernels():
+    """The MFMA path never runs LayerNorm as a kernel: y = LN(x) W^T + b is evaluated as
+    rstd*(x (W*gamma)^T) - rstd*mean*colsum(W*gamma) + (b + W beta)  (csrc/unet.cpp fold_layernorm,
+    igemm.hip LNF epilogue), with W*gamma rounded to fp16 and Sum x, Sum x^2 accumulated in fp32 from
+    the fp16 activations.  Same arithmetic in numpy vs the oracle's LayerNormANE + 1x1 conv."""
+    rs = np.random.RandomState(3)
+    C, N, M = 320, 192, 64
+    x = (rs.randn(M, C) * 3.0 + 1.5).astype(np.float16).astype(np.float32)     # rows with a non-zero mean
+    gamma, beta = (1.0 + 0.2 * rs.randn(C)).astype(np.float32), (0.3 * rs.randn(C)).astype(np.float32)
+    W, b = (rs.randn(N, C) / np.sqrt(C)).astype(np.float32), rs.randn(N).astype(np.float32)
+    ln = unet_ref.layer_norm_ane(torch.from_numpy(x.T.reshape(1, C, 1, M).copy()), torch.from_numpy(gamma),
+                                 torch.from_numpy(beta)).numpy().reshape(C, M).T
+    ref = ln.astype(np.float64) @ W.T.astype(np.float64) + b
+    Wg = (W * gamma).astype(np.float16).astype(np.float32)                     # what the MFMA multiplies
+    colsum = Wg.astype(np.float64).sum(1).astype(np.float32)
+    bias2 = (b.astype(np.float64) + W.astype(np.float64) @ beta).astype(np.float32)
+    s1, s2 = x.sum(1, dtype=np.float32), (x * x).sum(1, dtype=np.float32)
+    mean = s1 / C
+    rstd = 1.0 / np.sqrt(np.maximum(s2 / C - mean * mean, 0.0) + 1e-5)
+    acc = x @ Wg.T
+    got = acc * rstd[:, None] + (-rstd * mean)[:, None] * colsum[None, :] + bias2[None, :]
+    assert psnr.compute_psnr(got, ref) > 75.0
+    np.testing.assert_allclose(got, ref, atol=6e-3)
+
+
 def test_timestep_embedding_oracle_matches_reference_golden():
     g = load_golden("timestep_golden.npz")
     out = unet_ref.timestep_embedding(torch.from_numpy(g["t"]), 320).numpy()
