@@ -36,6 +36,11 @@ UNet::UNet(const sd_unet_config& cfg, const WeightStore& ws, int device) : cfg_(
   SD_REQUIRE(device >= 0 && device < ndev, kInvalidArgument, "device %d out of range (%d visible)", device, ndev);
   SD_HIP(hipSetDevice(device));
   SD_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  if (getenv("SD_SIDE_TIME") && atoi(getenv("SD_SIDE_TIME")) != 0) {
+    SD_HIP(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
+    SD_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+    SD_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+  }
   if (cfg_.is_vae_decoder)
     build_vae_decoder();
   else
@@ -51,6 +56,12 @@ UNet::~UNet() {
   if (stream_) {
     (void)hipStreamSynchronize(stream_);
     (void)hipStreamDestroy(stream_);
+  }
+  if (side_) {
+    (void)hipStreamSynchronize(side_);
+    (void)hipStreamDestroy(side_);
+    (void)hipEventDestroy(ev_fork_);
+    (void)hipEventDestroy(ev_join_);
   }
 }
 
@@ -291,6 +302,7 @@ Tensor UNet::resnet(std::vector<Op>& ops, const std::string& p, const Tensor& x,
   const int cin = x.C + (x2 ? x2->C : 0);
   Tensor t0 = group_norm(ops, p + ".norm1", x, x2, cfg_.norm_eps, true);
   const float* temb = has_temb ? register_temb(p + ".time_emb_proj", cout) : nullptr;
+  if (temb && temb_join_pos_ < 0 && &ops == &main_ops_) temb_join_pos_ = (int)ops.size();   // first consumer of the time path
   Tensor h = conv(ops, p + ".conv1", t0, nullptr, cout, 3, 1, 1, true, temb, nullptr);
   Tensor t1 = group_norm(ops, p + ".norm2", h, nullptr, cfg_.norm_eps, true);
   const half_t* shortcut;
@@ -784,6 +796,26 @@ void UNet::run_ops(const std::vector<Op>& ops) {
   for (auto& op : ops) op(stream_);
 }
 
+void UNet::run_time_and_main() {
+  if (!side_ || time_ops_.empty() || temb_join_pos_ < 0) {
+    run_ops(time_ops_);
+    run_ops(main_ops_);
+    return;
+  }
+  // fork: the side stream sees everything queued so far (the timestep buffer), runs the embedding
+  // MLP + the batched time_emb_proj GEMV, and the main stream waits for it only where the first
+  // ResNet conv adds its slice.  Works eagerly and under stream capture (the side stream joins the
+  // capture through the event and is joined back before the capture ends).
+  SD_HIP(hipEventRecord(ev_fork_, stream_));
+  SD_HIP(hipStreamWaitEvent(side_, ev_fork_, 0));
+  for (auto& op : time_ops_) op(side_);
+  SD_HIP(hipEventRecord(ev_join_, side_));
+  for (size_t i = 0; i < main_ops_.size(); ++i) {
+    if ((int)i == temb_join_pos_) SD_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));
+    main_ops_[i](stream_);
+  }
+}
+
 void UNet::upload_inputs(const sd_unet_io& io, bool loop_mode) {
   const int B = cfg_.batch, L = cfg_.context_len;
   const bool dev = (io.flags & SD_FLAG_DEVICE_PTRS) != 0;
@@ -848,14 +880,12 @@ void UNet::ensure_graph() {
   if (graph_ || !cfg_.use_graph) return;
   // first run eagerly (sets kernel attributes, warms code objects), then capture
   run_ops(in_ops_);
-  run_ops(time_ops_);
-  run_ops(main_ops_);
+  run_time_and_main();
   SD_HIP(hipStreamSynchronize(stream_));
   hipGraph_t g = nullptr;
   SD_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
   run_ops(in_ops_);
-  run_ops(time_ops_);
-  run_ops(main_ops_);
+  run_time_and_main();
   SD_HIP(hipStreamEndCapture(stream_, &g));
   SD_HIP(hipGraphInstantiate(&graph_, g, nullptr, nullptr, 0));
   SD_HIP(hipGraphDestroy(g));
@@ -870,8 +900,7 @@ void UNet::forward(const sd_unet_io& io) {
     SD_HIP(hipGraphLaunch(graph_, stream_));
   } else {
     run_ops(in_ops_);
-    run_ops(time_ops_);
-    run_ops(main_ops_);
+    run_time_and_main();
   }
   const bool dev = (io.flags & SD_FLAG_DEVICE_PTRS) != 0;
   const hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
@@ -898,8 +927,7 @@ float UNet::time_forward(int warmup, int iters) {
       SD_HIP(hipGraphLaunch(graph_, stream_));
     } else {
       run_ops(in_ops_);
-      run_ops(time_ops_);
-      run_ops(main_ops_);
+      run_time_and_main();
     }
   };
   for (int i = 0; i < warmup; ++i) once();
@@ -951,8 +979,7 @@ void UNet::denoise_loop(const sd_unet_io& io, float* latents, int n_images, int 
   LoopTables tab{tab_timesteps_, tab_coef_, step_};
   auto step_ops = [&]() {
     launch_loop_prep(latents_, x_in_.p, tbuf_, tab, n_images, C, H, W, cfgmul, stream_);
-    run_ops(time_ops_);
-    run_ops(main_ops_);
+    run_time_and_main();
     launch_cfg_sched_step(noise_pred_, latents_, eps_hist_, tab, guidance, n_images, C * H * W, cfgmul, history,
                           stream_);
   };
@@ -970,8 +997,7 @@ void UNet::denoise_loop(const sd_unet_io& io, float* latents, int n_images, int 
     if (!loop_graph_ || loop_graph_key_ != full_key) {
       if (loop_graph_) { (void)hipGraphExecDestroy(loop_graph_); loop_graph_ = nullptr; }
       if (!graph_) {   // make sure every kernel has been launched eagerly once (attributes, code objects)
-        run_ops(time_ops_);
-        run_ops(main_ops_);
+        run_time_and_main();
         SD_HIP(hipStreamSynchronize(stream_));
       }
       hipGraph_t g = nullptr;
