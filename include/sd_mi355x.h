@@ -131,15 +131,48 @@ int sd_unet_forward(sd_unet* u, const sd_unet_io* io);
  * the last sd_unet_forward call and returns the mean milliseconds per forward. */
 int sd_unet_time_forward(sd_unet* u, int warmup, int iters, float* ms_per_iter);
 
+/* Measurement hook: HIP-event time of every launch-list entry ("op": one kernel, or a kernel plus its
+ * split-K reduce) of one forward on the inputs of the last call, in launch order, eager launches (the
+ * same dependent-kernel sequence the HIP graph replays), median over `iters` passes.  Fills up to `cap`
+ * entries of ms / flop (algorithmic FLOP of MFMA ops, 0 for bandwidth ops) / labels (cap x label_bytes
+ * chars, NUL-terminated) and always sets *n_ops to the number of ops.  No reference counterpart: it is
+ * what bench.py derives the in-sequence roofline of the dominant kernel family from. */
+int sd_unet_profile(sd_unet* u, int iters, int cap, float* ms, double* flop, char* labels, int label_bytes,
+                    int* n_ops);
+
 /* Device-resident denoising loop (pipeline.py:500-573 with latents, CFG combine and scheduler
- * update never leaving HBM).  latents: (n_images, C, H, W) f32 host in/out; the UNet batch must
- * be cfg * n_images with cfg = (guidance_scale > 1 ? 2 : 1) (pipeline.py:443).  `timesteps`
- * (n_steps) and `coef` (n_steps x 8: x_prev = coef[0]*x + coef[1]*eps + sum_j coef[2+j]*eps_hist[j])
- * come from the host-side scheduler tables.  The encoder_hidden_states / SDXL extras are taken
- * from `io`.  ms_per_step (may be NULL) receives HIP-event time per loop iteration. */
+ * update never leaving HBM; Swift twin StableDiffusionPipeline.swift:233-333 incl. imageCount > 1).
+ * latents: (n_images, C, H, W) f32 host in/out; the UNet batch must be cfg * n_images with
+ * cfg = (guidance_scale > 1 ? 2 : 1) (pipeline.py:443), batch order [uncond..., cond...] (:245).
+ * `timesteps` (n_steps) and `coef` (n_steps x 8) come from the host-side scheduler tables; every
+ * scheduler on the path (DDIM, PNDM/PLMS Scheduler.swift:137-344, DPM-Solver++ 2M
+ * DPMSolverMultistepScheduler.swift:27-273) is the linear multistep rule
+ *     eps = u + g*(c - u);  m = a*x + b*eps;  x <- cx*x + cm*m + sum_{j<history} ch[j]*hist[j]
+ * with coef row = [cx, cm, ch0, ch1, ch2, a, b, flags]; hist[j] is the m of j+1 pushes ago and
+ * flags != 0 keeps this step's m out of the history (PLMS warm-up).  history <= 3.
+ * `sample_scale` (may be NULL): n_steps factors of scheduler.scale_model_input (pipeline.py:504-505;
+ * 1/sqrt(sigma^2+1) for the sigma-space Euler / LMS schedulers), applied to the UNet input only.
+ * `history_io` (may be NULL): (history, n_images, C, H, W) f32 host buffer read before the first
+ * step and written after the last, so a loop can continue on another handle (SDXL base -> refiner
+ * hand-off, StableDiffusionXLPipeline.swift:205-225).  The encoder_hidden_states / SDXL extras are
+ * taken from `io`; ControlNet residuals come from the attached ControlNet handles (below).
+ * ms_per_step (may be NULL) receives HIP-event time per loop iteration. */
 int sd_unet_denoise_loop(sd_unet* u, const sd_unet_io* io, float* latents, int n_images, int n_steps,
-                         const float* timesteps, const float* coef, int history, float guidance_scale,
-                         float* ms_per_step);
+                         const float* timesteps, const float* coef, const float* sample_scale, int history,
+                         float guidance_scale, float* history_io, float* ms_per_step);
+
+/* ControlNet residuals on the device (replaces the host round trip of pipeline.py:259-284 / :519-529
+ * and ControlNet.swift:64-118): `u` (built with support_controlnet) runs the n <= 3 attached
+ * ControlNet handles on its own stream before every forward - same sample / timestep /
+ * encoder_hidden_states - reads their 13 fp16 residual tensors straight from HBM, sums them over
+ * the ControlNets (pipeline.py:269-282) and adds them to its skip / mid tensors (unet.py:1009-1022).
+ * With ControlNets attached, sd_unet_forward ignores io->additional_residuals and
+ * sd_unet_denoise_loop runs ControlNet + UNet every step.  n = 0 detaches.  The ControlNet handles
+ * must outlive the attachment and share the UNet's device and static shapes. */
+int sd_unet_attach_controlnets(sd_unet* u, sd_unet* const* controlnets, int n);
+/* the conditioning image of an attached ControlNet, (B, 3, 8H, 8W) f16 (pipeline.py:346-357); its
+ * embedding (controlnet.py:211-215) is computed once here, not every step */
+int sd_controlnet_set_cond(sd_unet* controlnet, const void* controlnet_cond, int flags);
 
 /* ------------------------------------------------------------------------------------------
  * VAE decoder: image = decoder(post_quant_conv(z)) in [-1, 1] (torch2coreml.py:584-594; call

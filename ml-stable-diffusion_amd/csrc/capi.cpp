@@ -167,11 +167,45 @@ int sd_unet_time_forward(sd_unet* u, int warmup, int iters, float* ms_per_iter) 
   });
 }
 int sd_unet_denoise_loop(sd_unet* u, const sd_unet_io* io, float* latents, int n_images, int n_steps,
-                         const float* timesteps, const float* coef, int history, float guidance_scale,
-                         float* ms_per_step) {
+                         const float* timesteps, const float* coef, const float* sample_scale, int history,
+                         float guidance_scale, float* history_io, float* ms_per_step) {
   return guarded([&] {
     SD_REQUIRE(u && io && latents && timesteps && coef, kInvalidArgument, "NULL argument");
-    u->impl->denoise_loop(*io, latents, n_images, n_steps, timesteps, coef, history, guidance_scale, ms_per_step);
+    u->impl->denoise_loop(*io, latents, n_images, n_steps, timesteps, coef, sample_scale, history, guidance_scale,
+                          history_io, ms_per_step);
+  });
+}
+
+int sd_unet_profile(sd_unet* u, int iters, int cap, float* ms, double* flop, char* labels, int label_bytes, int* n_ops) {
+  return guarded([&] {
+    SD_REQUIRE(u && n_ops && cap >= 0 && (cap == 0 || (ms && flop && labels && label_bytes > 1)), kInvalidArgument,
+               "NULL argument");
+    const std::vector<OpTime> t = u->impl->profile(iters);
+    *n_ops = (int)t.size();
+    for (int i = 0; i < (int)t.size() && i < cap; ++i) {
+      ms[i] = t[i].ms;
+      flop[i] = t[i].flop;
+      std::snprintf(labels + (size_t)i * label_bytes, (size_t)label_bytes, "%s", t[i].label.c_str());
+    }
+  });
+}
+
+int sd_unet_attach_controlnets(sd_unet* u, sd_unet* const* controlnets, int n) {
+  return guarded([&] {
+    SD_REQUIRE(u && n >= 0 && (n == 0 || controlnets), kInvalidArgument, "NULL argument");
+    std::vector<UNet*> v;
+    for (int i = 0; i < n; ++i) {
+      SD_REQUIRE(controlnets[i], kInvalidArgument, "controlnets[%d] is NULL", i);
+      v.push_back(controlnets[i]->impl.get());
+    }
+    u->impl->attach_controlnets(v);
+  });
+}
+
+int sd_controlnet_set_cond(sd_unet* cn, const void* controlnet_cond, int flags) {
+  return guarded([&] {
+    SD_REQUIRE(cn && controlnet_cond, kInvalidArgument, "NULL argument");
+    cn->impl->set_controlnet_cond(controlnet_cond, flags);
   });
 }
 

@@ -116,19 +116,22 @@ void launch_half_to_float(const half_t* src, float* dst, size_t n, hipStream_t s
 void launch_float_to_half(const float* src, half_t* dst, size_t n, hipStream_t s);
 // y = a + b (fp16), used for ControlNet residual adds when not fused
 void launch_add_half(const half_t* a, const half_t* b, half_t* y, size_t n, hipStream_t s);
+// y = srcs[0] + ... + srcs[nsrc-1] (nsrc <= 4, fp32 accumulation): device-side ControlNet residual sum
+void launch_sum_half(const half_t* const* srcs, int nsrc, half_t* y, size_t n, hipStream_t s);
 // BC1S (B,C,1,S) fp16 -> token-major [B][S][C] fp16 (encoder_hidden_states boundary)
 void launch_bc1s_to_tokens(const half_t* src, half_t* dst, int B, int C, int S, hipStream_t s);
 
 // Device-resident denoising loop helpers (pipeline.py:500-573).  `step` is a device counter.
 struct LoopTables {
   const float* timesteps;   // [n_steps]
-  const float* coef;        // [n_steps][8]: cx, c_eps0..c_eps3 (linear multistep), spare
+  const float* coef;        // [n_steps][8]: cx, cm, ch0..ch2, a, b, flags  (cfg_sched_step_kernel, misc.hip)
   int* step;                // device scalar
+  const float* in_scale;    // [n_steps] scale_model_input factor (sigma-space schedulers), or null
 };
 // latents fp32 NCHW [Bimg][4][H][W] -> UNet sample fp16 NHWC [cfg*Bimg][H][W][4], timestep buffer
 void launch_loop_prep(const float* latents, half_t* sample, float* tbuf, LoopTables t, int Bimg, int C, int H,
                       int W, int cfg, hipStream_t s);
-// eps = u + g*(c-u) (pipeline.py:561-562); latents = cx*latents + sum ce_i * eps_hist_i; step++
+// eps = u + g*(c-u) (pipeline.py:561-562); m = a*x + b*eps; latents = cx*x + cm*m + sum ch_j * hist_j; step++
 void launch_cfg_sched_step(const float* noise_pred, float* latents, float* eps_hist, LoopTables t, float guidance,
                            int Bimg, int CHW, int cfg, int hist, hipStream_t s);
 

@@ -167,6 +167,28 @@ __global__ void add_half_kernel(const half_t* __restrict__ a, const half_t* __re
     reinterpret_cast<half8*>(y)[i] = o;
   }
 }
+// y = a + r0 (+ r1 + r2): ControlNet residual hand-off (unet.py:1009-1022) with the multi-ControlNet sum
+// of pipeline.py:269-282 folded in; fp32 accumulation, one fp16 rounding
+struct SumSrc {
+  const half_t* p[4];
+};
+__global__ void sum_half_kernel(SumSrc src, int nsrc, half_t* __restrict__ y, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    float acc[8];
+    const half8 x = reinterpret_cast<const half8*>(src.p[0])[i];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = (float)x[e];
+    for (int k = 1; k < nsrc; ++k) {
+      const half8 z = reinterpret_cast<const half8*>(src.p[k])[i];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += (float)z[e];
+    }
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)acc[e];
+    reinterpret_cast<half8*>(y)[i] = o;
+  }
+}
 // (B, C, 1, S) -> [B][S][C]
 __global__ void bc1s_to_tokens_kernel(const half_t* __restrict__ src, half_t* __restrict__ dst, int B, int C, int S) {
   const size_t total = (size_t)B * C * S;
@@ -192,39 +214,50 @@ __global__ void loop_prep_kernel(const float* __restrict__ latents, half_t* __re
     const size_t bp = idx / C;
     const int p = (int)(bp % HW);
     const int b = (int)(bp / HW);
-    const half_t v = (half_t)latents[((size_t)b * C + c) * HW + p];   // fp16 cast at the UNet boundary (:532)
+    // scheduler.scale_model_input (:504-505; identity for DDIM / PNDM / DPM-Solver++), then the fp16 cast at
+    // the UNet boundary (:532)
+    const half_t v = (half_t)(latents[((size_t)b * C + c) * HW + p] * (t.in_scale ? t.in_scale[step] : 1.0f));
     for (int r = 0; r < cfg; ++r) sample[((size_t)(r * Bimg + b) * HW + p) * C + c] = v;   // [uncond..., cond...]
   }
   if (blockIdx.x == 0 && threadIdx.x < cfg * Bimg) tbuf[threadIdx.x] = t.timesteps[step];
 }
 
 // pipeline.py:539, 561-569.  noise_pred fp32 NCHW [cfg*Bimg][CHW]; rows [0,Bimg) uncond, [Bimg,2Bimg) text.
-// latents <- cx * latents + sum_i ce_i * eps_hist_i, eps_hist_0 = this step's guided eps.
-__global__ void cfg_sched_step_kernel(const float* __restrict__ noise_pred, float* __restrict__ latents,
-                                      float* __restrict__ eps_hist, LoopTables t, float guidance, int Bimg,
-                                      int CHW, int cfg, int hist) {
+// Generic linear-multistep update on the device (DDIM / PLMS / DPM-Solver++ 2M are all instances):
+//   eps = u + g*(c-u);  m = a*x + b*eps;  x <- cx*x + cm*m + sum_j ch[j]*hist[j];  hist <- [m, hist[0..]]
+// coef row: [cx, cm, ch0, ch1, ch2, a, b, flags]; flags != 0: m is NOT pushed into the history (the second
+// evaluation of the PLMS warm-up, Scheduler.swift:228-236).  One workgroup: the whole update is a few
+// hundred KB, and the last statement can then advance the device step counter without a second launch.
+__global__ __launch_bounds__(1024) void cfg_sched_step_kernel(const float* __restrict__ noise_pred,
+                                                               float* __restrict__ latents, float* __restrict__ eps_hist,
+                                                               LoopTables t, float guidance, int Bimg, int CHW, int cfg,
+                                                               int hist) {
   const int step = *t.step;
   const float* cf = t.coef + (size_t)step * 8;
+  const float cx = cf[0], cm = cf[1], ma = cf[5], mb = cf[6];
+  const bool push = cf[7] == 0.f;
   const size_t total = (size_t)Bimg * CHW;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (size_t)gridDim.x * blockDim.x) {
+  for (size_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
     float eps = noise_pred[idx];
     if (cfg == 2) {
       const float c = noise_pred[total + idx];
       eps = eps + guidance * (c - eps);
     }
-    float x = cf[0] * latents[idx] + cf[1] * eps;
-    // linear multistep history (PLMS / DPM++ style): slot j holds eps from j+1 steps ago
+    const float x0 = latents[idx];
+    const float m = ma * x0 + mb * eps;
+    float x = cx * x0 + cm * m;
+    // history slot j holds the converted model output of j+1 pushes ago
     for (int j = hist - 1; j >= 0; --j) {
       const float old = eps_hist[(size_t)j * total + idx];
       x += cf[2 + j] * old;
-      if (j + 1 < hist) eps_hist[(size_t)(j + 1) * total + idx] = old;
+      if (push && j + 1 < hist) eps_hist[(size_t)(j + 1) * total + idx] = old;
     }
-    if (hist > 0) eps_hist[idx] = eps;
+    if (push && hist > 0) eps_hist[idx] = m;
     latents[idx] = x;
   }
+  __syncthreads();   // every thread has read *t.step
+  if (threadIdx.x == 0) *t.step = step + 1;
 }
-__global__ void step_increment_kernel(int* step) { *step += 1; }
 
 inline int grid_for(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 2048); }
 
@@ -292,6 +325,13 @@ void launch_add_half(const half_t* a, const half_t* b, half_t* y, size_t n, hipS
   hipLaunchKernelGGL(add_half_kernel, dim3(grid_for(n / 8)), dim3(256), 0, s, a, b, y, n / 8);
   SD_HIP(hipGetLastError());
 }
+void launch_sum_half(const half_t* const* srcs, int nsrc, half_t* y, size_t n, hipStream_t s) {
+  SD_REQUIRE(n % 8 == 0 && nsrc >= 1 && nsrc <= 4, kInvalidArgument, "sum_half: n %% 8 != 0 or %d sources", nsrc);
+  SumSrc src{};
+  for (int i = 0; i < nsrc; ++i) src.p[i] = srcs[i];
+  hipLaunchKernelGGL(sum_half_kernel, dim3(grid_for(n / 8)), dim3(256), 0, s, src, nsrc, y, n / 8);
+  SD_HIP(hipGetLastError());
+}
 void launch_bc1s_to_tokens(const half_t* src, half_t* dst, int B, int C, int S, hipStream_t s) {
   const size_t n = (size_t)B * C * S;
   hipLaunchKernelGGL(bc1s_to_tokens_kernel, dim3(grid_for(n)), dim3(256), 0, s, src, dst, B, C, S);
@@ -309,9 +349,9 @@ void launch_loop_prep(const float* latents, half_t* sample, float* tbuf, LoopTab
 void launch_cfg_sched_step(const float* noise_pred, float* latents, float* eps_hist, LoopTables t, float guidance,
                            int Bimg, int CHW, int cfg, int hist, hipStream_t s) {
   const size_t n = (size_t)Bimg * CHW;
-  hipLaunchKernelGGL(cfg_sched_step_kernel, dim3(grid_for(n)), dim3(256), 0, s, noise_pred, latents, eps_hist, t,
-                     guidance, Bimg, CHW, cfg, hist);
-  hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, s, t.step);
+  (void)n;
+  hipLaunchKernelGGL(cfg_sched_step_kernel, dim3(1), dim3(1024), 0, s, noise_pred, latents, eps_hist, t, guidance, Bimg,
+                     CHW, cfg, hist);
   SD_HIP(hipGetLastError());
 }
 

@@ -14,6 +14,7 @@
 //    time_emb_proj(SiLU(emb)) (unet.py:477) are one batched GEMV per step.
 #include "unet.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -254,6 +255,14 @@ Tensor UNet::conv_w(std::vector<Op>& ops, const std::string& name, const half_t*
     const int so = silu_out ? 1 : 0;
     ops.push_back([d, so](hipStream_t s) { launch_conv_generic(d, so, s); });
   }
+  {
+    const int cin = x.C + (x2 ? x2->C : 0);
+    char buf[256];
+    snprintf(buf, sizeof(buf), "%s%s %d->%d @%dx%d M=%d K=%d %s", k == 3 ? "conv3x3" : (geglu ? "geglu1x1" : "gemm1x1"),
+             ex && ex->ln_colsum ? "+ln" : "", cin, cout, d.Ho, d.Wo, x.B * d.Ho * d.Wo, cin * k * k, name.c_str());
+    ops.back().label = buf;
+    ops.back().flop = 2.0 * x.B * d.Ho * d.Wo * (double)cout * cin * k * k;
+  }
   return out;
 }
 
@@ -273,6 +282,7 @@ Tensor UNet::group_norm(std::vector<Op>& ops, const std::string& name, const Ten
   ops.push_back([=](hipStream_t s) {
     launch_groupnorm(p0, C0, p1, C1, partial, gamma, beta, yp, B, HW, G, eps, si, s);
   });
+  ops.back().label = "groupnorm C=" + std::to_string(C) + " @" + std::to_string(x.H) + "x" + std::to_string(x.W) + " " + name;
   return y;
 }
 
@@ -285,6 +295,7 @@ Tensor UNet::layer_norm(std::vector<Op>& ops, const std::string& name, const Ten
   half_t* yp = y.p;
   const int M = x.M(), C = x.C;
   ops.push_back([=](hipStream_t s) { launch_layernorm(xp, w, b, yp, M, C, 1e-5f, s); });
+  ops.back().label = "layernorm C=" + std::to_string(C) + " M=" + std::to_string(M) + " " + name;
   return y;
 }
 
@@ -339,6 +350,9 @@ Tensor UNet::attention(std::vector<Op>& ops, const Tensor& q, const half_t* k, c
     dd.impl = cfg_.attention_impl;   // run-time switch (the reference's global, unet.py:39)
     launch_attention(dd, s);
   });
+  ops.back().label = "attention h=" + std::to_string(heads) + " d=" + std::to_string(d.d) + " Sq=" + std::to_string(Sq) +
+                     " Sk=" + std::to_string(Sk);
+  ops.back().flop = 4.0 * q.B * (double)q.C * Sq * Sk;
   return o;
 }
 
@@ -480,6 +494,7 @@ void UNet::build_unet() {
       launch_half_to_float(ts, tb, B, s);
       launch_nchw_to_nhwc(smp, 0, xin.p, B, xin.C, xin.H, xin.W, s);
     });
+    in_ops_.back().label = "boundary: timestep f16->f32, sample NCHW->NHWC";
     half_t* ehs = in_ehs_;
     Tensor ctx = ctx_;
     ctx_ops_.push_back([=](hipStream_t s) { launch_bc1s_to_tokens(ehs, ctx.p, B, ctx.C, ctx.W, s); });
@@ -508,6 +523,7 @@ void UNet::build_unet() {
       launch_gemv(w1, b1, t_emb, C0, e1, tdim, B, tdim, C0, 0, 1, 0, s);
       launch_gemv(w2, b2, e1, tdim, emb, tdim, B, tdim, tdim, 0, 0, 0, s);
     });
+    time_ops_.back().label = "time embedding: sinusoid + 2 GEMV (time_embedding.linear_1/2)";
     if (xl) {
       const int nt = cfg_.num_time_ids, adim = cfg_.addition_time_embed_dim;
       const int pin = cfg_.projection_class_embeddings_input_dim;
@@ -537,6 +553,7 @@ void UNet::build_unet() {
         launch_gemv(aw1, ab1, add_in, pin, a1, tdim, B, tdim, pin, 0, 1, 0, s);
         launch_gemv(aw2, ab2, a1, tdim, emb, tdim, B, tdim, tdim, 0, 0, 1, s);   // emb += aug_emb (:1090)
       });
+      time_ops_.back().label = "text_time add-embedding: sinusoid + concat + 2 GEMV";
     }
   }
 
@@ -582,7 +599,7 @@ void UNet::build_unet() {
       float* o = arena_.alloc_n<float>(t.numel());
       res_out_.push_back(o);
       Tensor tt = t;
-      main_ops_.push_back([=](hipStream_t s) { launch_nhwc_to_nchw_f32(tt.p, o, tt.B, tt.C, tt.H, tt.W, s); });
+      out_ops_.push_back([=](hipStream_t s) { launch_nhwc_to_nchw_f32(tt.p, o, tt.B, tt.C, tt.H, tt.W, s); });
     }
     finalize_temb();
   } else {
@@ -596,9 +613,16 @@ void UNet::build_unet() {
         const Tensor base = (i + 1 == res_shapes_.size()) ? h : skips[i];
         Tensor sum = new_tensor(sh[0], sh[2], sh[3], sh[1]);
         main_ops_.push_back([=](hipStream_t s) {
-          launch_nchw_to_nhwc(src, 0, r.p, r.B, r.C, r.H, r.W, s);
-          launch_add_half(base.p, r.p, sum.p, r.numel(), s);
+          if (attached_.empty()) {   // residuals arrive through the host boundary like the reference (pipeline.py:519-529)
+            launch_nchw_to_nhwc(src, 0, r.p, r.B, r.C, r.H, r.W, s);
+            launch_add_half(base.p, r.p, sum.p, r.numel(), s);
+          } else {                   // device hand-off: skip[i] + sum over ControlNets of residual[i], one launch
+            const half_t* srcs[4] = {base.p, nullptr, nullptr, nullptr};
+            for (size_t k = 0; k < attached_.size(); ++k) srcs[1 + k] = attached_[k]->cn_out_[i].p;
+            launch_sum_half(srcs, 1 + (int)attached_.size(), sum.p, r.numel(), s);
+          }
         });
+        main_ops_.back().label = "controlnet residual add " + std::to_string(i);
         added.push_back(sum);
       }
       for (size_t i = 0; i < skips.size(); ++i) skips[i] = added[i];
@@ -634,6 +658,8 @@ void UNet::build_unet() {
     float* np = noise_pred_;
     if (cfg_.out_channels <= 8 && t.C % 8 == 0) {
       main_ops_.push_back([=](hipStream_t s) { launch_conv_small_n(d, np, s); });
+      main_ops_.back().label = "conv3x3 small-N conv_out -> fp32 NCHW";
+      main_ops_.back().flop = 2.0 * B * H * W * (double)cfg_.out_channels * t.C * 9;
     } else {
       Tensor o = new_tensor(B, H, W, cfg_.out_channels);
       ConvDesc d2 = d;
@@ -654,6 +680,7 @@ void UNet::build_unet() {
     float* out = temb_all_;
     const int N = temb_used_;
     time_ops_.push_back([=](hipStream_t s) { launch_gemv(w, b, emb, tdim, out, kTembCap, B, N, tdim, 1, 0, 0, s); });
+    time_ops_.back().label = "time_emb_proj of all resnets: one batched GEMV N=" + std::to_string(N);
   }
   if (ws_need_ > 0) {
     ws_conv_.partial = reinterpret_cast<float*>(arena_.alloc(ws_need_));
@@ -716,6 +743,8 @@ void UNet::build_vae_decoder() {
         launch_row_softmax(scores, S, S, scale, s);
         launch_conv(d2, ws_conv_, s);
       });
+      main_ops_.back().label = "VAE attention: QK^T GEMM + row softmax + PV GEMM, S=" + std::to_string(S);
+      main_ops_.back().flop = 4.0 * (double)S * S * C;
     }
     h = conv(main_ops_, p + ".to_out.0", a, nullptr, C, 1, 1, 1, true, nullptr, h.p);
   }
@@ -742,6 +771,8 @@ void UNet::build_vae_decoder() {
     d.ksize = 3; d.stride = 1; d.up = 1; d.N = cfg_.out_channels;
     float* dst = image_;
     main_ops_.push_back([=](hipStream_t s) { launch_conv_small_n(d, dst, s); });
+    main_ops_.back().label = "conv3x3 small-N decoder.conv_out -> fp32 NCHW";
+    main_ops_.back().flop = 2.0 * t.B * t.H * t.W * (double)cfg_.out_channels * t.C * 9;
   }
   if (ws_need_ > 0) {
     ws_conv_.partial = reinterpret_cast<float*>(arena_.alloc(ws_need_));
@@ -766,12 +797,7 @@ void UNet::vae_decode(const void* z, int z_is_f32, float* image, int flags) {
     if (!graph_) {
       run_ops(main_ops_);
       SD_HIP(hipStreamSynchronize(stream_));
-      hipGraph_t g = nullptr;
-      SD_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
-      run_ops(main_ops_);
-      SD_HIP(hipStreamEndCapture(stream_, &g));
-      SD_HIP(hipGraphInstantiate(&graph_, g, nullptr, nullptr, 0));
-      SD_HIP(hipGraphDestroy(g));
+      graph_ = capture([&] { run_ops(main_ops_); });
     }
     SD_HIP(hipGraphLaunch(graph_, stream_));
   } else {
@@ -783,18 +809,63 @@ void UNet::vae_decode(const void* z, int z_is_f32, float* image, int flags) {
   have_inputs_ = true;
 }
 
+void UNet::invalidate_graphs() {
+  if (graph_) { (void)hipGraphExecDestroy(graph_); graph_ = nullptr; }
+  if (loop_graph_) { (void)hipGraphExecDestroy(loop_graph_); loop_graph_ = nullptr; }
+}
+
 void UNet::set_attention(int impl) {
   SD_REQUIRE(impl >= 0 && impl <= 2, kInvalidArgument, "attention impl %d", impl);
   if (impl != cfg_.attention_impl) {
     cfg_.attention_impl = impl;
-    if (graph_) { (void)hipGraphExecDestroy(graph_); graph_ = nullptr; }
-    if (loop_graph_) { (void)hipGraphExecDestroy(loop_graph_); loop_graph_ = nullptr; }
+    invalidate_graphs();
   }
+  for (UNet* cn : attached_) cn->set_attention(impl);   // their launches live inside this handle's graph
 }
 
-void UNet::run_ops(const std::vector<Op>& ops) {
-  for (auto& op : ops) op(stream_);
+void UNet::run_ops(const std::vector<Op>& ops) { run_ops_on(ops, stream_); }
+void UNet::run_ops_on(const std::vector<Op>& ops, hipStream_t s) {
+  for (auto& op : ops) op(s);
 }
+
+// Stream capture that cannot leave the stream in capture mode: an op that throws between Begin and
+// End (SD_HIP / SD_REQUIRE inside a launch) ends and discards the capture before the error travels on.
+hipGraphExec_t UNet::capture(const std::function<void()>& body) {
+  SD_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+  hipGraph_t g = nullptr;
+  try {
+    body();
+  } catch (...) {
+    (void)hipStreamEndCapture(stream_, &g);
+    if (g) (void)hipGraphDestroy(g);
+    throw;
+  }
+  SD_HIP(hipStreamEndCapture(stream_, &g));
+  hipGraphExec_t exec = nullptr;
+  const hipError_t e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  SD_REQUIRE(e == hipSuccess, kHipError, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+  return exec;
+}
+
+namespace {
+// hipEvents that are destroyed on every exit path
+struct EventList {
+  std::vector<hipEvent_t> ev;
+  explicit EventList(size_t n) {
+    ev.reserve(n);
+    for (size_t i = 0; i < n; ++i) {
+      hipEvent_t e = nullptr;
+      SD_HIP(hipEventCreate(&e));
+      ev.push_back(e);
+    }
+  }
+  ~EventList() {
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+  }
+  hipEvent_t operator[](size_t i) const { return ev[i]; }
+};
+}  // namespace
 
 void UNet::run_time_and_main() {
   if (!side_ || time_ops_.empty() || temb_join_pos_ < 0) {
@@ -814,6 +885,67 @@ void UNet::run_time_and_main() {
     if ((int)i == temb_join_pos_) SD_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));
     main_ops_[i](stream_);
   }
+}
+
+// ---- device-resident ControlNet hand-off ---------------------------------------------------------
+void UNet::attach_controlnets(const std::vector<UNet*>& cns) {
+  SD_REQUIRE(!cfg_.is_controlnet && !cfg_.is_vae_decoder, kInvalidArgument, "attach_controlnets needs a UNet handle");
+  SD_REQUIRE(cns.empty() || cfg_.support_controlnet, kInvalidArgument,
+             "this UNet was built without support_controlnet (unet.py:1009-1022)");
+  SD_REQUIRE(cns.size() <= 3, kUnsupported, "at most 3 ControlNets per UNet handle, got %zu", cns.size());
+  for (UNet* cn : cns) {
+    SD_REQUIRE(cn && cn->cfg_.is_controlnet, kInvalidArgument, "attach_controlnets: handle is not a ControlNet");
+    SD_REQUIRE(cn->device_ == device_, kInvalidArgument, "ControlNet lives on device %d, UNet on %d", cn->device_, device_);
+    SD_REQUIRE(cn->cfg_.batch == cfg_.batch && cn->cfg_.height == cfg_.height && cn->cfg_.width == cfg_.width &&
+                   cn->cfg_.cross_attention_dim == cfg_.cross_attention_dim && cn->cfg_.context_len == cfg_.context_len,
+               kInvalidArgument, "ControlNet static shapes differ from the UNet's");
+    SD_REQUIRE(cn->res_shapes_ == res_shapes_, kInvalidArgument, "ControlNet residual shapes differ from the UNet's skips");
+  }
+  SD_HIP(hipSetDevice(device_));
+  SD_HIP(hipStreamSynchronize(stream_));
+  attached_ = cns;
+  for (UNet* cn : attached_) cn->set_attention(cfg_.attention_impl);
+  invalidate_graphs();     // the captured launches bake in which residual sources are read
+  have_ctx_ = false;       // the ControlNets' hoisted cross-attention K/V follow this handle's prompt
+}
+
+// controlnet.py:211-215: the conditioning embedding depends only on the image -> once per generation
+void UNet::set_controlnet_cond(const void* cond, int flags) {
+  SD_HIP(hipSetDevice(device_));
+  SD_REQUIRE(cfg_.is_controlnet && in_cond_, kInvalidArgument, "set_controlnet_cond needs a ControlNet handle");
+  SD_REQUIRE(cond != nullptr, kInvalidArgument, "missing input 'controlnet_cond'");
+  const size_t n = (size_t)cfg_.batch * 3 * cfg_.height * 8 * cfg_.width * 8;
+  const bool dev = (flags & SD_FLAG_DEVICE_PTRS) != 0;
+  SD_HIP(hipMemcpyAsync(in_cond_, cond, n * 2, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream_));
+  run_ops(cond_ops_);
+  SD_HIP(hipStreamSynchronize(stream_));
+  have_cond_ = true;
+  if (!dev) {
+    const uint16_t* src = reinterpret_cast<const uint16_t*>(cond);
+    last_cond_.assign(src, src + n);
+  } else {
+    last_cond_.clear();
+  }
+}
+
+void UNet::set_context_from(const half_t* ehs_dev, hipStream_t s) {
+  const size_t n = (size_t)cfg_.batch * cfg_.cross_attention_dim * cfg_.context_len;
+  SD_HIP(hipMemcpyAsync(in_ehs_, ehs_dev, n * 2, hipMemcpyDeviceToDevice, s));
+  run_ops_on(ctx_ops_, s);
+  have_ctx_ = true;
+  last_ehs_.clear();
+}
+
+void UNet::run_as_controlnet(hipStream_t s, const half_t* x_nhwc, const float* tbuf) {
+  SD_REQUIRE(have_cond_, kInvalidArgument, "ControlNet has no conditioning image: call sd_controlnet_set_cond first");
+  SD_HIP(hipMemcpyAsync(x_in_.p, x_nhwc, x_in_.numel() * sizeof(half_t), hipMemcpyDeviceToDevice, s));
+  SD_HIP(hipMemcpyAsync(tbuf_, tbuf, (size_t)cfg_.batch * sizeof(float), hipMemcpyDeviceToDevice, s));
+  run_ops_on(time_ops_, s);
+  run_ops_on(main_ops_, s);
+}
+
+void UNet::run_attached() {
+  for (UNet* cn : attached_) cn->run_as_controlnet(stream_, x_in_.p, tbuf_);
 }
 
 void UNet::upload_inputs(const sd_unet_io& io, bool loop_mode) {
@@ -847,6 +979,7 @@ void UNet::upload_inputs(const sd_unet_io& io, bool loop_mode) {
       SD_HIP(hipMemcpyAsync(in_ehs_, io.encoder_hidden_states, n * 2, kind, stream_));
       run_ops(ctx_ops_);
       have_ctx_ = true;
+      for (UNet* cn : attached_) cn->set_context_from(in_ehs_, stream_);   // same prompt (pipeline.py:266-268)
     }
   }
   if (in_cond_) {
@@ -864,7 +997,7 @@ void UNet::upload_inputs(const sd_unet_io& io, bool loop_mode) {
       have_cond_ = true;
     }
   }
-  if (!in_res_nchw_.empty()) {
+  if (!in_res_nchw_.empty() && attached_.empty()) {
     SD_REQUIRE(io.additional_residuals && io.num_additional_residuals == (int)in_res_nchw_.size(), kInvalidArgument,
                "expected %zu additional_residual inputs, got %d", in_res_nchw_.size(), io.num_additional_residuals);
     for (size_t i = 0; i < in_res_nchw_.size(); ++i) {
@@ -876,19 +1009,21 @@ void UNet::upload_inputs(const sd_unet_io& io, bool loop_mode) {
   have_inputs_ = true;
 }
 
+// one forward: boundary conversions, [attached ControlNets,] time embedding, the network, [ControlNet
+// boundary outputs]
+void UNet::run_forward_ops() {
+  run_ops(in_ops_);
+  run_attached();
+  run_time_and_main();
+  run_ops(out_ops_);
+}
+
 void UNet::ensure_graph() {
   if (graph_ || !cfg_.use_graph) return;
   // first run eagerly (sets kernel attributes, warms code objects), then capture
-  run_ops(in_ops_);
-  run_time_and_main();
+  run_forward_ops();
   SD_HIP(hipStreamSynchronize(stream_));
-  hipGraph_t g = nullptr;
-  SD_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
-  run_ops(in_ops_);
-  run_time_and_main();
-  SD_HIP(hipStreamEndCapture(stream_, &g));
-  SD_HIP(hipGraphInstantiate(&graph_, g, nullptr, nullptr, 0));
-  SD_HIP(hipGraphDestroy(g));
+  graph_ = capture([&] { run_forward_ops(); });
 }
 
 void UNet::forward(const sd_unet_io& io) {
@@ -899,8 +1034,7 @@ void UNet::forward(const sd_unet_io& io) {
     ensure_graph();
     SD_HIP(hipGraphLaunch(graph_, stream_));
   } else {
-    run_ops(in_ops_);
-    run_time_and_main();
+    run_forward_ops();
   }
   const bool dev = (io.flags & SD_FLAG_DEVICE_PTRS) != 0;
   const hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
@@ -922,52 +1056,88 @@ float UNet::time_forward(int warmup, int iters) {
   SD_REQUIRE(have_inputs_, kInvalidArgument, "time_forward: call sd_unet_forward once first");
   SD_REQUIRE(iters >= 1, kInvalidArgument, "iters must be >= 1");
   auto once = [&]() {
-    if (cfg_.use_graph) {
+    if (cfg_.is_vae_decoder) {
+      if (cfg_.use_graph && graph_)
+        SD_HIP(hipGraphLaunch(graph_, stream_));
+      else
+        run_ops(main_ops_);
+    } else if (cfg_.use_graph) {
       ensure_graph();
       SD_HIP(hipGraphLaunch(graph_, stream_));
     } else {
-      run_ops(in_ops_);
-      run_time_and_main();
+      run_forward_ops();
     }
   };
   for (int i = 0; i < warmup; ++i) once();
-  hipEvent_t e0, e1;
-  SD_HIP(hipEventCreate(&e0));
-  SD_HIP(hipEventCreate(&e1));
-  SD_HIP(hipEventRecord(e0, stream_));
+  EventList ev(2);
+  SD_HIP(hipEventRecord(ev[0], stream_));
   for (int i = 0; i < iters; ++i) once();
-  SD_HIP(hipEventRecord(e1, stream_));
-  SD_HIP(hipEventSynchronize(e1));
+  SD_HIP(hipEventRecord(ev[1], stream_));
+  SD_HIP(hipEventSynchronize(ev[1]));
   float ms = 0.f;
-  SD_HIP(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
+  SD_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
   return ms / (float)iters;
 }
 
-// pipeline.py:500-573 on the device: per step {duplicate latents + fp16 cast, UNet, CFG combine,
-// scheduler update}; the host only replays one graph per step.
-void UNet::denoise_loop(const sd_unet_io& io, float* latents, int n_images, int n_steps, const float* timesteps,
-                        const float* coef, int history, float guidance, float* ms_per_step) {
+std::vector<OpTime> UNet::profile(int iters) {
   SD_HIP(hipSetDevice(device_));
-  SD_REQUIRE(!cfg_.is_controlnet, kInvalidArgument, "denoise_loop needs a UNet handle");
+  SD_REQUIRE(have_inputs_, kInvalidArgument, "profile: call sd_unet_forward / sd_vae_decode once first");
+  SD_REQUIRE(iters >= 1 && iters <= 100, kInvalidArgument, "iters must be in 1..100");
+  std::vector<const Op*> seq;
+  for (const auto* list : {&in_ops_, &time_ops_, &main_ops_, &out_ops_})
+    for (const Op& op : *list) seq.push_back(&op);
+  const size_t n = seq.size();
+  std::vector<std::vector<float>> t(n, std::vector<float>((size_t)iters));
+  for (const Op* op : seq) (*op)(stream_);   // warm (kernel attributes, code objects)
+  SD_HIP(hipStreamSynchronize(stream_));
+  EventList ev(n + 1);
+  for (int it = 0; it < iters; ++it) {
+    SD_HIP(hipEventRecord(ev[0], stream_));
+    for (size_t i = 0; i < n; ++i) {
+      (*seq[i])(stream_);
+      SD_HIP(hipEventRecord(ev[i + 1], stream_));
+    }
+    SD_HIP(hipEventSynchronize(ev[n]));
+    for (size_t i = 0; i < n; ++i) SD_HIP(hipEventElapsedTime(&t[i][(size_t)it], ev[i], ev[i + 1]));
+  }
+  std::vector<OpTime> out;
+  for (size_t i = 0; i < n; ++i) {
+    std::sort(t[i].begin(), t[i].end());
+    out.push_back({seq[i]->label.empty() ? std::string("op") : seq[i]->label, seq[i]->flop, t[i][(size_t)iters / 2]});
+  }
+  return out;
+}
+
+// pipeline.py:500-573 on the device: per step {duplicate latents + fp16 cast, [ControlNets,] UNet, CFG
+// combine, scheduler update}; the host only replays one graph per step.
+void UNet::denoise_loop(const sd_unet_io& io, float* latents, int n_images, int n_steps, const float* timesteps,
+                        const float* coef, const float* sample_scale, int history, float guidance, float* history_io,
+                        float* ms_per_step) {
+  SD_HIP(hipSetDevice(device_));
+  SD_REQUIRE(!cfg_.is_controlnet && !cfg_.is_vae_decoder, kInvalidArgument, "denoise_loop needs a UNet handle");
   const int cfgmul = guidance > 1.0f ? 2 : 1;   // pipeline.py:443
   SD_REQUIRE(cfgmul * n_images == cfg_.batch, kInvalidArgument,
              "UNet batch %d != %d images x %d (guidance_scale %s 1)", cfg_.batch, n_images, cfgmul,
              cfgmul == 2 ? ">" : "<=");
   SD_REQUIRE(cfg_.in_channels == cfg_.out_channels, kInvalidArgument, "loop needs in_channels == out_channels");
-  SD_REQUIRE(history >= 0 && history <= 4 && n_steps >= 1, kInvalidArgument, "bad history/n_steps");
+  SD_REQUIRE(history >= 0 && history <= 3 && n_steps >= 1, kInvalidArgument, "bad history (%d, max 3) / n_steps (%d)",
+             history, n_steps);
+  SD_REQUIRE(in_res_nchw_.empty() || !attached_.empty(), kInvalidArgument,
+             "a UNet built with support_controlnet needs attached ControlNets for the device-resident loop "
+             "(sd_unet_attach_controlnets); host residuals only travel through sd_unet_forward");
   const int C = cfg_.in_channels, H = cfg_.height, W = cfg_.width;
   const size_t lat_n = (size_t)n_images * C * H * W;
+  const size_t hist_n = (size_t)3 * cfg_.batch * C * H * W;
   if (!latents_) {
     latents_ = arena_.alloc_n<float>((size_t)cfg_.batch * C * H * W);
-    eps_hist_ = arena_.alloc_n<float>((size_t)4 * cfg_.batch * C * H * W);
+    eps_hist_ = arena_.alloc_n<float>(hist_n);
     step_ = arena_.alloc_n<int>(1);
   }
   if (tab_cap_ < n_steps) {
     tab_cap_ = std::max(n_steps, 1024);
     tab_timesteps_ = arena_.alloc_n<float>(tab_cap_);
     tab_coef_ = arena_.alloc_n<float>((size_t)tab_cap_ * 8);
+    tab_scale_ = arena_.alloc_n<float>(tab_cap_);
     if (loop_graph_) { (void)hipGraphExecDestroy(loop_graph_); loop_graph_ = nullptr; }
   }
   upload_inputs(io, true);
@@ -975,20 +1145,24 @@ void UNet::denoise_loop(const sd_unet_io& io, float* latents, int n_images, int 
   SD_HIP(hipMemcpyAsync(tab_timesteps_, timesteps, (size_t)n_steps * sizeof(float), hipMemcpyHostToDevice, stream_));
   SD_HIP(hipMemcpyAsync(tab_coef_, coef, (size_t)n_steps * 8 * sizeof(float), hipMemcpyHostToDevice, stream_));
   SD_HIP(hipMemsetAsync(step_, 0, sizeof(int), stream_));
-  SD_HIP(hipMemsetAsync(eps_hist_, 0, (size_t)4 * cfg_.batch * C * H * W * sizeof(float), stream_));
-  LoopTables tab{tab_timesteps_, tab_coef_, step_};
+  SD_HIP(hipMemsetAsync(eps_hist_, 0, hist_n * sizeof(float), stream_));
+  if (history_io && history > 0)   // slot j: [n_images][C][H][W], continuing a loop another handle began (refiner swap)
+    for (int j = 0; j < history; ++j)
+      SD_HIP(hipMemcpyAsync(eps_hist_ + (size_t)j * lat_n, history_io + (size_t)j * lat_n, lat_n * sizeof(float),
+                            hipMemcpyHostToDevice, stream_));
+  if (sample_scale)
+    SD_HIP(hipMemcpyAsync(tab_scale_, sample_scale, (size_t)n_steps * sizeof(float), hipMemcpyHostToDevice, stream_));
+  LoopTables tab{tab_timesteps_, tab_coef_, step_, sample_scale ? tab_scale_ : nullptr};
   auto step_ops = [&]() {
     launch_loop_prep(latents_, x_in_.p, tbuf_, tab, n_images, C, H, W, cfgmul, stream_);
+    run_attached();
     run_time_and_main();
     launch_cfg_sched_step(noise_pred_, latents_, eps_hist_, tab, guidance, n_images, C * H * W, cfgmul, history,
                           stream_);
   };
-  const int key = n_images * 16 + history * 2 + (cfgmul - 1);
-  std::vector<hipEvent_t> ev;
-  if (ms_per_step) {
-    ev.resize(n_steps + 1);
-    for (auto& e : ev) SD_HIP(hipEventCreate(&e));
-  }
+  const int key = n_images * 32 + history * 4 + (cfgmul - 1) * 2 + (sample_scale ? 1 : 0);
+  std::unique_ptr<EventList> ev;
+  if (ms_per_step) ev = std::make_unique<EventList>((size_t)n_steps + 1);
   if (cfg_.use_graph) {
     // guidance is baked into the captured kernel arguments -> key the graph on its bit pattern too
     int gbits;
@@ -997,32 +1171,31 @@ void UNet::denoise_loop(const sd_unet_io& io, float* latents, int n_images, int 
     if (!loop_graph_ || loop_graph_key_ != full_key) {
       if (loop_graph_) { (void)hipGraphExecDestroy(loop_graph_); loop_graph_ = nullptr; }
       if (!graph_) {   // make sure every kernel has been launched eagerly once (attributes, code objects)
+        launch_loop_prep(latents_, x_in_.p, tbuf_, tab, n_images, C, H, W, cfgmul, stream_);
+        run_attached();
         run_time_and_main();
         SD_HIP(hipStreamSynchronize(stream_));
       }
-      hipGraph_t g = nullptr;
-      SD_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
-      step_ops();
-      SD_HIP(hipStreamEndCapture(stream_, &g));
-      SD_HIP(hipGraphInstantiate(&loop_graph_, g, nullptr, nullptr, 0));
-      SD_HIP(hipGraphDestroy(g));
+      loop_graph_ = capture(step_ops);
       loop_graph_key_ = full_key;
     }
   }
   for (int i = 0; i < n_steps; ++i) {
-    if (ms_per_step) SD_HIP(hipEventRecord(ev[i], stream_));
+    if (ms_per_step) SD_HIP(hipEventRecord((*ev)[i], stream_));
     if (cfg_.use_graph)
       SD_HIP(hipGraphLaunch(loop_graph_, stream_));
     else
       step_ops();
   }
-  if (ms_per_step) SD_HIP(hipEventRecord(ev[n_steps], stream_));
+  if (ms_per_step) SD_HIP(hipEventRecord((*ev)[n_steps], stream_));
   SD_HIP(hipMemcpyAsync(latents, latents_, lat_n * sizeof(float), hipMemcpyDeviceToHost, stream_));
+  if (history_io && history > 0)
+    for (int j = 0; j < history; ++j)
+      SD_HIP(hipMemcpyAsync(history_io + (size_t)j * lat_n, eps_hist_ + (size_t)j * lat_n, lat_n * sizeof(float),
+                            hipMemcpyDeviceToHost, stream_));
   SD_HIP(hipStreamSynchronize(stream_));
-  if (ms_per_step) {
-    for (int i = 0; i < n_steps; ++i) SD_HIP(hipEventElapsedTime(&ms_per_step[i], ev[i], ev[i + 1]));
-    for (auto& e : ev) (void)hipEventDestroy(e);
-  }
+  if (ms_per_step)
+    for (int i = 0; i < n_steps; ++i) SD_HIP(hipEventElapsedTime(&ms_per_step[i], (*ev)[i], (*ev)[i + 1]));
 }
 
 }  // namespace sd

@@ -16,7 +16,22 @@ struct Tensor {
   size_t numel() const { return (size_t)B * H * W * C; }
 };
 
-using Op = std::function<void(hipStream_t)>;
+// One entry of a handle's launch list: the launch closure plus what the per-op profile reports about it.
+struct Op {
+  std::function<void(hipStream_t)> fn;
+  std::string label;   // "<kind> <shape> <checkpoint name>"
+  double flop = 0;     // algorithmic FLOP (2 per MAC) of MFMA ops, 0 for bandwidth ops
+  Op() = default;
+  template <class F, class = std::enable_if_t<!std::is_same<std::decay_t<F>, Op>::value>>
+  Op(F&& f) : fn(std::forward<F>(f)) {}
+  void operator()(hipStream_t s) const { fn(s); }
+};
+
+struct OpTime {
+  std::string label;
+  double flop;
+  float ms;
+};
 
 class UNet {
  public:
@@ -25,8 +40,16 @@ class UNet {
 
   void forward(const sd_unet_io& io);
   float time_forward(int warmup, int iters);
+  // HIP-event time of every op of one forward, in launch order (eager launches, cold caches between
+  // dependent kernels exactly as inside the graph); median over `iters` passes
+  std::vector<OpTime> profile(int iters);
   void denoise_loop(const sd_unet_io& io, float* latents, int n_images, int n_steps, const float* timesteps,
-                    const float* coef, int history, float guidance, float* ms_per_step);
+                    const float* coef, const float* sample_scale, int history, float guidance, float* history_io,
+                    float* ms_per_step);
+  // device-resident ControlNet hand-off (pipeline.py:259-284, unet.py:1009-1022): this UNet reads the
+  // residual tensors of the attached ControlNet handles straight from HBM and sums them on the device
+  void attach_controlnets(const std::vector<UNet*>& cns);
+  void set_controlnet_cond(const void* cond, int flags);
   void set_attention(int impl);
   void vae_decode(const void* z, int z_is_f32, float* image, int flags);
   int num_residuals() const { return (int)res_shapes_.size(); }
@@ -78,6 +101,15 @@ class UNet {
   void finalize_temb();
   void upload_inputs(const sd_unet_io& io, bool loop_mode);
   void run_ops(const std::vector<Op>& ops);
+  void run_ops_on(const std::vector<Op>& ops, hipStream_t s);
+  // ControlNet handle driven by a UNet handle: sample / timesteps come from the UNet's device buffers,
+  // everything runs on the UNet's stream (and inside its HIP graph)
+  void run_as_controlnet(hipStream_t s, const half_t* x_nhwc, const float* tbuf);
+  void set_context_from(const half_t* ehs_dev, hipStream_t s);
+  void run_attached();
+  void invalidate_graphs();
+  hipGraphExec_t capture(const std::function<void()>& body);
+  void run_forward_ops();
   void run_time_and_main();   // time_ops_ (optionally on the forked side stream) + main_ops_
   void ensure_graph();
 
@@ -124,6 +156,8 @@ class UNet {
   size_t ws_need_ = 0;
 
   std::vector<Op> in_ops_, time_ops_, ctx_ops_, cond_ops_, main_ops_;
+  std::vector<Op> out_ops_;          // ControlNet: fp16 NHWC residuals -> fp32 NCHW for the host boundary only
+  std::vector<UNet*> attached_;      // UNet with support_controlnet: ControlNets whose outputs it consumes on device
   std::vector<uint16_t> last_ehs_, last_cond_;
   bool have_ctx_ = false, have_cond_ = false, have_inputs_ = false;
   hipGraphExec_t graph_ = nullptr, loop_graph_ = nullptr;
@@ -134,6 +168,7 @@ class UNet {
   float* eps_hist_ = nullptr;
   float* tab_timesteps_ = nullptr;
   float* tab_coef_ = nullptr;
+  float* tab_scale_ = nullptr;
   int* step_ = nullptr;
   int tab_cap_ = 0;
 };

@@ -73,10 +73,28 @@ void WeightStore::add(const std::string& name, const void* data, int dtype, cons
   map_[name] = std::move(t);
 }
 
-const HostTensor& WeightStore::get(const std::string& name) const {
+// Public SD 1.x / 2.x VAE checkpoints keep the deprecated attention names (query / key / value /
+// proj_attn) that diffusers renames at load time; look those up when the current name is absent.
+const HostTensor* WeightStore::find(const std::string& name) const {
   auto it = map_.find(name);
-  if (it == map_.end()) fail(kNotFound, "checkpoint is missing tensor '%s'", name.c_str());
-  return it->second;
+  if (it != map_.end()) return &it->second;
+  static const char* const kAlias[][2] = {
+      {".to_q.", ".query."}, {".to_k.", ".key."}, {".to_v.", ".value."}, {".to_out.0.", ".proj_attn."}};
+  for (const auto& a : kAlias) {
+    const size_t pos = name.find(a[0]);
+    if (pos == std::string::npos) continue;
+    std::string old = name;
+    old.replace(pos, std::strlen(a[0]), a[1]);
+    it = map_.find(old);
+    if (it != map_.end()) return &it->second;
+  }
+  return nullptr;
+}
+
+const HostTensor& WeightStore::get(const std::string& name) const {
+  const HostTensor* t = find(name);
+  if (!t) fail(kNotFound, "checkpoint is missing tensor '%s'", name.c_str());
+  return *t;
 }
 
 // Minimal safetensors reader: 8-byte LE header length, JSON header
@@ -116,12 +134,19 @@ struct Scanner {
     ws();
     size_t j = i;
     while (j < s.size() && (isdigit((unsigned char)s[j]) || s[j] == '-')) ++j;
-    int64_t v = std::stoll(s.substr(i, j - i));
+    if (j == i || j - i > 18) fail(kInvalidArgument, "safetensors header: expected a number at byte %zu", i);
+    int64_t v = 0;
+    try {
+      v = std::stoll(s.substr(i, j - i));
+    } catch (const std::exception&) {
+      fail(kInvalidArgument, "safetensors header: bad number at byte %zu", i);
+    }
     i = j;
     return v;
   }
   void skip_value() {   // for __metadata__
     ws();
+    if (i >= s.size()) fail(kInvalidArgument, "safetensors header: truncated");
     if (s[i] == '{') {
       int depth = 0;
       bool in_str = false;
@@ -151,8 +176,14 @@ void WeightStore::load_safetensors(const std::string& path, const std::string& p
   uint64_t hlen = 0;
   f.read(reinterpret_cast<char*>(&hlen), 8);
   SD_REQUIRE(f && hlen > 0 && hlen < ((uint64_t)1 << 30), kInvalidArgument, "%s: bad safetensors header", path.c_str());
+  f.seekg(0, std::ios::end);
+  const uint64_t file_size = (uint64_t)f.tellg();
+  SD_REQUIRE(8 + hlen <= file_size, kInvalidArgument, "%s: safetensors header (%llu bytes) exceeds the file", path.c_str(),
+             (unsigned long long)hlen);
+  f.seekg(8);
   std::string header(hlen, '\0');
   f.read(&header[0], (std::streamsize)hlen);
+  SD_REQUIRE((bool)f && (uint64_t)f.gcount() == hlen, kInvalidArgument, "%s: truncated safetensors header", path.c_str());
   const uint64_t data_start = 8 + hlen;
   Scanner sc(header);
   sc.expect('{');
@@ -196,6 +227,20 @@ void WeightStore::load_safetensors(const std::string& path, const std::string& p
     sc.eat(',');
     int dt = dtype == "F16" ? 0 : dtype == "F32" ? 1 : dtype == "BF16" ? 2 : -1;
     if (dt < 0) continue;   // integer buffers etc. are not part of the path
+    // never trust the header: offsets inside the file, non-negative dims, byte count == numel * element size
+    SD_REQUIRE(b >= 0 && e >= b && data_start + (uint64_t)e <= file_size, kInvalidArgument,
+               "%s: tensor '%s' has data_offsets [%lld, %lld) outside the file", path.c_str(), key.c_str(), (long long)b,
+               (long long)e);
+    SD_REQUIRE(shape.size() <= 8, kInvalidArgument, "%s: tensor '%s' has %zu dims", path.c_str(), key.c_str(), shape.size());
+    uint64_t numel = 1;
+    for (int64_t dim : shape) {
+      SD_REQUIRE(dim >= 0 && (dim == 0 || numel <= ((uint64_t)1 << 40) / (uint64_t)dim), kInvalidArgument,
+                 "%s: tensor '%s' has a bad dimension %lld", path.c_str(), key.c_str(), (long long)dim);
+      numel *= (uint64_t)dim;
+    }
+    SD_REQUIRE((uint64_t)(e - b) == numel * (dt == 1 ? 4u : 2u), kInvalidArgument,
+               "%s: tensor '%s' stores %lld bytes but its shape needs %llu", path.c_str(), key.c_str(), (long long)(e - b),
+               (unsigned long long)(numel * (dt == 1 ? 4u : 2u)));
     raw.resize((size_t)(e - b));
     f.seekg((std::streamoff)(data_start + (uint64_t)b));
     f.read(raw.data(), (std::streamsize)raw.size());

@@ -22,7 +22,8 @@ class WeightStore {
            const int64_t* shape, int ndim);
   void load_safetensors(const std::string& path, const std::string& prefix);
   const HostTensor& get(const std::string& name) const;   // throws kNotFound
-  bool has(const std::string& name) const { return map_.count(name) != 0; }
+  const HostTensor* find(const std::string& name) const;  // nullptr when absent (deprecated VAE attention names accepted)
+  bool has(const std::string& name) const { return find(name) != nullptr; }
   size_t size() const { return map_.size(); }
 
  private:

@@ -187,6 +187,7 @@ class HipModel:
         self.batch, self.latent_height, self.latent_width = batch, h, w
         self.attention_implementation = attention_implementation
         self.num_residuals = _lib.lib().sd_unet_num_residuals(self._h)
+        self._attached = []
 
         f16 = np.dtype(np.float16)
         ei = {
@@ -248,7 +249,7 @@ class HipModel:
 
         for f in ("sample", "timestep", "encoder_hidden_states", "time_ids", "text_embeds", "controlnet_cond"):
             put(f, f)
-        if self.kind == "unet" and self._cfg_struct.support_controlnet:
+        if self.kind == "unet" and self._cfg_struct.support_controlnet and not self._attached:
             arrs = [np.ascontiguousarray(kwargs[f"additional_residual_{i}"]) for i in range(self.num_residuals)]
             keep.extend(arrs)
             ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
@@ -286,19 +287,97 @@ class HipModel:
         _lib.check(_lib.lib().sd_unet_time_forward(self._h, warmup, iters, C.byref(ms)))
         return ms.value
 
-    def denoise_loop(self, latents, timesteps, coef, guidance_scale, history=0, **kwargs):
+    def denoise_loop(self, latents, timesteps, coef, guidance_scale, history=0, sample_scale=None, history_state=None,
+                     **kwargs):
         """Device-resident pipeline.py:500-573.  latents (n_img, C, H, W) float32 -> final latents,
-        per-step HIP-event milliseconds."""
+        per-step HIP-event milliseconds.  ``kwargs`` are the loop-invariant model inputs
+        (encoder_hidden_states, SDXL time_ids / text_embeds), validated like ``__call__`` validates them
+        (coreml_model.py:97-116).  ``history_state`` (history, n_img, C, H, W) float32 carries the
+        scheduler's multistep history in and out (updated in place) when a loop continues on another
+        handle (SDXL base -> refiner)."""
+        if self.kind != "unet":
+            raise ValueError("denoise_loop needs a UNet handle")
+        loop_inputs = {k: v for k, v in self.expected_inputs.items()
+                       if k not in ("sample", "timestep") and not k.startswith("additional_residual_")}
+        for k, v in kwargs.items():
+            if k not in loop_inputs:
+                raise ValueError(f"Received unexpected input kwarg: {k}")
+            if not isinstance(v, np.ndarray):
+                raise TypeError(f"Expected numpy.ndarray, got {v} for input: {k}")
+            if v.dtype != loop_inputs[k]["dtype"]:
+                raise TypeError(f"Expected dtype {loop_inputs[k]['dtype']}, got {v.dtype} for input: {k}")
+            if v.shape != loop_inputs[k]["shape"]:
+                raise TypeError(f"Expected shape {loop_inputs[k]['shape']}, got {v.shape} for input: {k}")
+        missing = [k for k in loop_inputs if k not in kwargs]
+        if missing:
+            raise ValueError(f"Missing input kwargs: {missing}")
+        if self._cfg_struct.support_controlnet and not self._attached:
+            raise ValueError("this UNet consumes ControlNet residuals: attach_controlnets() first, or step through "
+                             "__call__ with additional_residual_* inputs")
+        lat = np.ascontiguousarray(latents, dtype=np.float32).copy()
+        cfg_mul = 2 if guidance_scale > 1.0 else 1                                    # pipeline.py:443
+        want = (self.batch // cfg_mul, self.config["in_channels"], self.latent_height, self.latent_width)
+        if lat.shape != want or self.batch % cfg_mul:
+            raise ValueError(f"Unexpected latents shape, got {lat.shape}, expected {want} (UNet batch {self.batch}, "
+                             f"guidance_scale {guidance_scale})")
+        ts = np.ascontiguousarray(timesteps, dtype=np.float32).reshape(-1)
+        cf = np.ascontiguousarray(coef, dtype=np.float32)
+        if cf.size != len(ts) * 8 or len(ts) < 1:
+            raise ValueError(f"coef must hold len(timesteps) x 8 = {len(ts) * 8} entries, got {cf.size}")
+        if not 0 <= int(history) <= 3:
+            raise ValueError(f"history must be in 0..3, got {history}")
+        sc = None
+        if sample_scale is not None:
+            sc = np.ascontiguousarray(sample_scale, dtype=np.float32).reshape(-1)
+            if len(sc) != len(ts):
+                raise ValueError("sample_scale must have one entry per timestep")
+        hs = None
+        if history_state is not None and history:
+            if (not isinstance(history_state, np.ndarray) or history_state.dtype != np.float32
+                    or history_state.shape != (int(history),) + lat.shape or not history_state.flags.c_contiguous):
+                raise ValueError(f"history_state must be a C-contiguous float32 array of shape {(int(history),) + lat.shape}")
+            hs = history_state
         keep = []
         io = self._io(kwargs, keep)
-        lat = np.ascontiguousarray(latents, dtype=np.float32).copy()
-        ts = np.ascontiguousarray(timesteps, dtype=np.float32)
-        cf = np.ascontiguousarray(coef, dtype=np.float32).reshape(len(ts), 8)
         ms = np.zeros(len(ts), np.float32)
         _lib.check(_lib.lib().sd_unet_denoise_loop(self._h, C.byref(io), _lib.fptr(lat), lat.shape[0], len(ts),
-                                                   _lib.fptr(ts), _lib.fptr(cf), history, float(guidance_scale),
-                                                   _lib.fptr(ms)))
+                                                   _lib.fptr(ts), _lib.fptr(cf), _lib.fptr(sc), int(history),
+                                                   float(guidance_scale), _lib.fptr(hs), _lib.fptr(ms)))
         return lat, ms
+
+    def profile(self, iters=5):
+        """[(label, flop, ms)] for every launch-list entry of one forward, in launch order (sd_unet_profile)."""
+        return _profile(self._h, iters)
+
+    def attach_controlnets(self, controlnets):
+        """Device-resident ControlNet hand-off (sd_unet_attach_controlnets): this UNet runs the given
+        ControlNet ``HipModel`` handles before every forward / loop step and reads their residuals from
+        HBM.  ``[]`` detaches (residuals then come through ``additional_residual_*`` again)."""
+        controlnets = list(controlnets or [])
+        for cn in controlnets:
+            if not isinstance(cn, HipModel) or cn.kind != "controlnet":
+                raise TypeError("attach_controlnets takes HipModel(kind='controlnet') handles")
+        arr = (C.c_void_p * max(1, len(controlnets)))(*[cn._h for cn in controlnets])
+        _lib.check(_lib.lib().sd_unet_attach_controlnets(self._h, C.cast(arr, C.POINTER(C.c_void_p)), len(controlnets)))
+        self._attached = controlnets      # keeps the handles alive while attached
+        ei = {k: v for k, v in self.expected_inputs.items() if not k.startswith("additional_residual_")}
+        if self._cfg_struct.support_controlnet and not controlnets:
+            for i, s_ in enumerate(self._res_shapes):
+                ei[f"additional_residual_{i}"] = {"shape": s_, "dtype": np.dtype(np.float16)}
+        self.expected_inputs = ei
+
+    def set_controlnet_cond(self, cond):
+        """ControlNet handle: upload the conditioning image (B, 3, 8H, 8W) fp16 and embed it once
+        (controlnet.py:211-215) for the device-resident hand-off."""
+        if self.kind != "controlnet":
+            raise ValueError("set_controlnet_cond needs a ControlNet handle")
+        want = self.expected_inputs["controlnet_cond"]
+        if not isinstance(cond, np.ndarray):
+            raise TypeError(f"Expected numpy.ndarray, got {cond} for input: controlnet_cond")
+        if cond.dtype != want["dtype"] or cond.shape != want["shape"]:
+            raise TypeError(f"Expected {want['dtype']} {want['shape']}, got {cond.dtype} {cond.shape} for input: controlnet_cond")
+        c = np.ascontiguousarray(cond)
+        _lib.check(_lib.lib().sd_controlnet_set_cond(self._h, _lib.ptr(c), 0))
 
     @property
     def device_bytes(self):
@@ -306,6 +385,11 @@ class HipModel:
 
     def close(self):
         if getattr(self, "_h", None):
+            if getattr(self, "_attached", None):
+                try:
+                    self.attach_controlnets([])
+                except Exception:
+                    pass
             _lib.lib().sd_unet_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -314,6 +398,18 @@ class HipModel:
             self.close()
         except Exception:
             pass
+
+
+def _profile(handle, iters):
+    n = C.c_int(0)
+    _lib.check(_lib.lib().sd_unet_profile(handle, iters, 0, None, None, None, 0, C.byref(n)))
+    cap, lb = n.value, 160
+    ms = np.zeros(cap, np.float32)
+    flop = np.zeros(cap, np.float64)
+    labels = C.create_string_buffer(cap * lb)
+    _lib.check(_lib.lib().sd_unet_profile(handle, iters, cap, _lib.fptr(ms), flop.ctypes.data_as(C.POINTER(C.c_double)),
+                                          labels, lb, C.byref(n)))
+    return [(labels.raw[i * lb:(i + 1) * lb].split(b"\0", 1)[0].decode(), float(flop[i]), float(ms[i])) for i in range(cap)]
 
 
 VAE_CONFIGS = {   # public AutoencoderKL config of SD 1.x / 2.x (decoder side)
@@ -367,6 +463,9 @@ class HipVaeDecoder:
         _lib.check(_lib.lib().sd_vae_decode(self._h, _lib.ptr(z), 1 if z.dtype == np.float32 else 0,
                                             _lib.fptr(image), 0))
         return {"image": image}
+
+    def profile(self, iters=5):
+        return _profile(self._h, iters)
 
     def time_forward(self, warmup=1, iters=5):
         ms = C.c_float(0)

@@ -76,6 +76,12 @@ CONFIGS = {
     "mini-control": make_config(sample_size=16, block_out_channels=(64, 128, 256, 256),
                                 attention_head_dim=(1, 2, 4, 4), cross_attention_dim=128,
                                 support_controlnet=True),
+    # SDXL-refiner topology in miniature (4 levels DN,CA,CA,DN, depth 2, 5 time ids -> 32*5 + 64)
+    "mini-refiner": make_config(
+        sample_size=16, block_out_channels=(64, 128, 256, 256), down_block_types=(DN, CA, CA, DN),
+        up_block_types=(UP, CAUP, CAUP, UP), attention_head_dim=(1, 2, 4, 4), cross_attention_dim=128,
+        transformer_layers_per_block=2, addition_embed_type="text_time",
+        addition_time_embed_dim=32, projection_class_embeddings_input_dim=64 + 5 * 32),
     # odd little config: exercises the generic (non-MFMA) fallbacks and d_head != 64
     "tiny": make_config(sample_size=8, block_out_channels=(32, 64), down_block_types=(CA, DN),
                         up_block_types=(UP, CAUP), layers_per_block=1, attention_head_dim=(2, 4),

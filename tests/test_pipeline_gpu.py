@@ -89,7 +89,7 @@ def test_callback_path_steps_through_the_boundary_and_agrees_with_device_loop():
 
 def test_pipeline_argument_checks_mirror_the_reference():
     pipe, *_ = build()
-    with pytest.raises(NotImplementedError):          # pipeline.py:434-438
+    with pytest.raises(ValueError, match="static batch"):   # two prompts need a batch-4 handle (pipeline.py:112-114)
         pipe(["a", "b"], num_inference_steps=2)
     with pytest.raises(ValueError):                   # pipeline.py:359-382
         pipe("a", num_inference_steps=2, callback_steps=0)
