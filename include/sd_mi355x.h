@@ -185,6 +185,33 @@ int sd_vae_decoder_create(const sd_unet_config* cfg, const sd_weights* w, int de
 int sd_vae_decode(sd_unet* vae, const void* z, sd_dtype z_dtype, float* image, int flags);
 
 /* ------------------------------------------------------------------------------------------
+ * CLIP text encoder(s): transformers' CLIPTextModel / CLIPTextModelWithProjection as the reference
+ * wraps them for conversion (torch2coreml.py:379-441, causal mask -1e4 :363-377) and calls them
+ * (pipeline.py:151-175, `text_encoder(input_ids=...)`; TextEncoder.swift / TextEncoderXL.swift).
+ * One prompt per call: input_ids (1, max_position_embeddings) int32.  Outputs (each may be NULL), f32:
+ *   last_hidden_state (1, S, D)  final_layer_norm(last layer)          - SD 1.x / 2.x context
+ *   hidden_embeds     (1, S, D)  hidden_states[-2], no final LN        - SDXL context (:416-428)
+ *   pooled            (1, projection_dim) text_projection(final_LN(last)[eos_index]) when
+ *                     projection_dim > 0 ("text_embeds"), else (1, D) pooler_output = final_LN(last)[eos_index]
+ * Weights use the transformers key names (text_model.embeddings.*, text_model.encoder.layers.N.*,
+ * text_model.final_layer_norm.*, text_projection.weight).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct sd_text_encoder_config {
+  int32_t vocab_size, hidden_size, intermediate_size, num_hidden_layers, num_attention_heads;
+  int32_t max_position_embeddings; /* 77 */
+  int32_t hidden_act;              /* 0: quick_gelu (CLIP ViT-L), 1: gelu (OpenCLIP H / bigG) */
+  int32_t projection_dim;          /* 0: CLIPTextModel, > 0: CLIPTextModelWithProjection */
+  float layer_norm_eps;            /* 1e-5 */
+  int32_t use_graph;
+} sd_text_encoder_config;
+typedef struct sd_text_encoder sd_text_encoder;
+int sd_text_encoder_create(const sd_text_encoder_config* cfg, const sd_weights* w, int device, sd_text_encoder** out);
+void sd_text_encoder_destroy(sd_text_encoder* t);
+size_t sd_text_encoder_device_bytes(const sd_text_encoder* t);
+int sd_text_encoder_encode(sd_text_encoder* t, const int32_t* input_ids, int eos_index, float* last_hidden_state,
+                           float* hidden_embeds, float* pooled);
+
+/* ------------------------------------------------------------------------------------------
  * Operator-level entry points (what the parity tests and micro-benchmarks bind).  Host
  * pointers unless SD_FLAG_DEVICE_PTRS; each call is synchronous on an internal stream.
  * `ms` (may be NULL) returns HIP-event kernel time averaged over `iters` (>=1) launches.

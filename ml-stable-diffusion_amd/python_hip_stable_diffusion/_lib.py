@@ -79,6 +79,10 @@ SYMBOLS = [
     ("sd_controlnet_set_cond", _I, [_P, _P, _I]),
     ("sd_vae_decoder_create", _I, [C.POINTER(UNetConfig), _P, _I, C.POINTER(_P)]),
     ("sd_vae_decode", _I, [_P, _P, _I, _FP, _I]),
+    ("sd_text_encoder_create", _I, [_P, _P, _I, C.POINTER(_P)]),
+    ("sd_text_encoder_destroy", None, [_P]),
+    ("sd_text_encoder_device_bytes", C.c_size_t, [_P]),
+    ("sd_text_encoder_encode", _I, [_P, C.POINTER(C.c_int32), _I, _FP, _FP, _FP]),
     ("sd_op_attention", _I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _FP]),
     ("sd_op_layernorm", _I, [_P, _FP, _FP, _P, _I, _I, _I, _F, _I, _FP]),
     ("sd_op_groupnorm", _I, [_P, _FP, _FP, _P, _I, _I, _I, _I, _I, _F, _I, _I, _FP]),

@@ -148,3 +148,34 @@ def test_pndm_schedule_matches_swift_restatement():
     for t in ts[:6]:
         x = s.step(0.1 * np.ones_like(x), int(t), x)
     assert np.isfinite(x).all()
+
+
+@pytest.mark.parametrize("name", ["mini-l", "mini-g"])
+def test_clip_oracle_matches_the_installed_transformers(name):
+    """The CLIP restatement (oracle/clip_ref.py) against transformers' CLIPTextModel(WithProjection) with the
+    same random weights.  Third-party pin only: the reference holds no golden for the encoder (PARITY UNPINNED)."""
+    transformers = pytest.importorskip("transformers")
+    from oracle import clip_ref
+    cfg = clip_ref.CONFIGS[name]
+    sd = weights.to_torch(weights.make_state_dict(clip_ref.param_shapes(cfg), seed=7, gain=2.0))
+    hf_cfg = transformers.CLIPTextConfig(**{k: v for k, v in cfg.items() if k != "architectures"}, bos_token_id=0, pad_token_id=1)
+    cls = transformers.CLIPTextModelWithProjection if cfg.get("projection_dim") else transformers.CLIPTextModel
+    model = cls(hf_cfg).eval()
+    own = set(model.state_dict().keys())
+    if not any(k.startswith("text_model.") for k in own):                # transformers 5.x dropped the wrapper prefix
+        sd_hf = {k[len("text_model."):] if k.startswith("text_model.") else k: v for k, v in sd.items()}
+    else:
+        sd_hf = sd
+    missing, unexpected = model.load_state_dict(sd_hf, strict=False)
+    assert not [k for k in missing if "position_ids" not in k] and not unexpected
+    ids = torch.from_numpy(np.random.RandomState(3).randint(3, cfg["vocab_size"], (1, 77)))
+    ids[0, 20] = cfg["vocab_size"] - 1                                   # the arg-max token marks the pooled position
+    with torch.no_grad():
+        ref = model(input_ids=ids, output_hidden_states=True)
+    mine = clip_ref.text_encoder_forward(sd, cfg, ids)
+    np.testing.assert_allclose(mine["last_hidden_state"].numpy(), ref.last_hidden_state.numpy(), atol=2e-4)
+    np.testing.assert_allclose(mine["hidden_embeds"].numpy(), ref.hidden_states[-2].numpy(), atol=2e-4)
+    if cfg.get("projection_dim"):
+        np.testing.assert_allclose(mine["text_embeds"].numpy(), ref.text_embeds.numpy(), atol=2e-4)
+    else:
+        np.testing.assert_allclose(mine["pooler_output"].numpy(), ref.pooler_output.numpy(), atol=2e-4)

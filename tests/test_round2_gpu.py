@@ -157,7 +157,7 @@ def test_diffusers_format_safetensors_round_trip_is_bit_equal(tmp_path):
     kw = dict(sample=g["sample"], timestep=g["timestep"].astype(np.float16), encoder_hidden_states=g["encoder_hidden_states"])
     ya, yb = a(**kw)["noise_pred"], b(**kw)["noise_pred"]
     assert np.array_equal(ya, yb)
-    assert psnr.compute_psnr(ya, g["noise_pred"]) >= 55.0          # bf16-rounded weights: still the same network
+    assert psnr.compute_psnr(ya, g["noise_pred"]) >= 45.0          # a fifth of the tensors truncated to bf16: still the same network
     a.close(), b.close(), w.close()
 
 

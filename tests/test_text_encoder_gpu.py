@@ -1,0 +1,143 @@
+"""GPU parity tests of the CLIP text encoder(s) (csrc/text_encoder.cpp + clip.hip behind HipTextEncoder) and of
+the complete drop-in surface: get_hip_pipe over a diffusers-layout checkpoint directory and the CLI main().
+Oracle: oracle/clip_ref.py (pinned against the installed transformers by tests/test_oracle.py; PARITY UNPINNED
+against the reference, which holds no golden for the encoder).  Tolerance: fp16 HIP vs fp32 oracle, PSNR >= 50 dB
+(torch2coreml.py:59-77 protocol, reference floor 35 dB)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import clip_ref, psnr, scheduler_ref, unet_ref, vae_ref, weights
+from python_hip_stable_diffusion import HipTextEncoder, pipeline as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _ids(cfg, seed, eos_at):
+    ids = np.random.RandomState(seed).randint(3, cfg["vocab_size"] - 1, (1, 77))
+    ids[0, eos_at:] = cfg["vocab_size"] - 1            # eos = the largest id, then padding with eos (CLIP convention)
+    return ids
+
+
+@pytest.mark.parametrize("name,xl", [("mini-l", False), ("mini-l", True), ("mini-g", True), ("openclip-h", False)])
+def test_text_encoder_matches_oracle(name, xl):
+    cfg = clip_ref.CONFIGS[name]
+    sd16 = weights.make_state_dict(clip_ref.param_shapes(cfg), seed=7, dtype=np.float16, gain=2.0)
+    sd = weights.to_torch({k: v.astype(np.float32) for k, v in sd16.items()})
+    enc = HipTextEncoder(cfg, sd16, xl=xl)
+    assert enc.expected_inputs["input_ids"] == {"shape": (1, 77), "dtype": np.dtype(np.float32)}
+    for seed, eos_at in ((3, 9), (4, 76)):
+        ids = _ids(cfg, seed, eos_at)
+        out = enc(input_ids=ids.astype(np.float32))                         # ids as float32 (pipeline.py:173)
+        ref = clip_ref.text_encoder_forward(sd, cfg, torch.from_numpy(ids))
+        key = "hidden_embeds" if xl else "last_hidden_state"
+        assert set(out) == {key, "pooled_outputs"} and out[key].shape == (1, 77, cfg["hidden_size"])
+        p = psnr.compute_psnr(out[key], ref[key].numpy())
+        assert p >= 50.0, f"{name} {key}: PSNR {p:.1f} dB"
+        want_pooled = ref["text_embeds" if cfg.get("projection_dim") else "pooler_output"].numpy()
+        assert out["pooled_outputs"].shape == want_pooled.shape
+        pp = psnr.compute_psnr(out["pooled_outputs"], want_pooled)
+        assert pp >= 45.0, f"{name} pooled: PSNR {pp:.1f} dB"
+    with pytest.raises(TypeError):
+        enc(input_ids=ids.astype(np.int32))
+    with pytest.raises(TypeError):
+        enc(input_ids=ids[:, :50].astype(np.float32))
+    with pytest.raises(ValueError):
+        enc(tokens=ids.astype(np.float32))
+    enc.close()
+
+
+def _bytes_to_unicode():
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(ord("\xa1"), ord("\xac") + 1)) + list(range(ord("\xae"), ord("\xff") + 1))
+    cs, n = bs[:], 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b)
+            cs.append(256 + n)
+            n += 1
+    return [chr(c) for c in cs]
+
+
+def write_checkpoint_dir(root):
+    """A diffusers-layout Stable Diffusion checkpoint in miniature with seeded random weights."""
+    from safetensors.numpy import save_file
+    from transformers import CLIPTokenizer
+    ucfg, vcfg, tcfg = unet_ref.CONFIGS["mini"], vae_ref.VAE_CONFIGS["mini"], clip_ref.CONFIGS["mini-l"]
+    parts = {}
+    for sub, cfg, shapes, seed, gain, fname in (
+            ("unet", dict(ucfg, _class_name="UNet2DConditionModel"), unet_ref.unet_param_shapes(ucfg), 21, 1.0,
+             "diffusion_pytorch_model.safetensors"),
+            ("vae", dict(vcfg, _class_name="AutoencoderKL", scaling_factor=0.18215), vae_ref.vae_decoder_param_shapes(vcfg), 61, 1.6,
+             "diffusion_pytorch_model.safetensors"),
+            ("text_encoder", tcfg, clip_ref.param_shapes(tcfg), 7, 2.0, "model.safetensors")):
+        os.makedirs(os.path.join(root, sub))
+        sd16 = weights.make_state_dict(shapes, seed=seed, dtype=np.float16, gain=gain)
+        save_file(sd16, os.path.join(root, sub, fname), metadata={"format": "pt"})
+        json.dump({k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()}, open(os.path.join(root, sub, "config.json"), "w"))
+        parts[sub] = weights.to_torch({k: v.astype(np.float32) for k, v in sd16.items()})
+    os.makedirs(os.path.join(root, "scheduler"))
+    json.dump({"_class_name": "PNDMScheduler", "beta_schedule": "scaled_linear", "skip_prk_steps": True, "steps_offset": 1},
+              open(os.path.join(root, "scheduler", "scheduler_config.json"), "w"))
+    alpha = _bytes_to_unicode()
+    vocab = {}
+    for ch in alpha:
+        vocab[ch] = len(vocab)
+    for ch in alpha:
+        vocab[ch + "</w>"] = len(vocab)
+    vocab["<|startoftext|>"] = len(vocab)
+    vocab["<|endoftext|>"] = len(vocab)
+    tmp = os.path.join(root, "_tok")
+    os.makedirs(tmp)
+    json.dump(vocab, open(os.path.join(tmp, "vocab.json"), "w"))
+    open(os.path.join(tmp, "merges.txt"), "w").write("#version: 0.2\n")
+    tok = CLIPTokenizer(os.path.join(tmp, "vocab.json"), os.path.join(tmp, "merges.txt"), model_max_length=77)
+    tok.save_pretrained(os.path.join(root, "tokenizer"))
+    return parts, tok
+
+
+def test_get_hip_pipe_and_cli_generate_an_image_from_a_text_prompt(tmp_path):
+    """prompt -> tokenizer -> CLIP on HIP -> PNDM device loop (the checkpoint's default scheduler) -> VAE on HIP ->
+    PNG, through get_hip_pipe / main with the reference's flags; against the same loop around the oracles."""
+    root = str(tmp_path / "mini-sd")
+    os.makedirs(root)
+    parts, tok = write_checkpoint_dir(root)
+    ucfg, vcfg, tcfg = unet_ref.CONFIGS["mini"], vae_ref.VAE_CONFIGS["mini"], clip_ref.CONFIGS["mini-l"]
+    prompt, neg, seed, steps, gs = "a photo of an astronaut riding a horse", "blurry", 93, 6, 7.5
+    pipe = P.get_hip_pipe(root, "mini/stable-diffusion", attention_implementation="ORIGINAL", guidance_scale=gs)
+    assert type(pipe.scheduler).__name__ == "PNDMScheduler" and pipe.height == pipe.width == 128
+    out = pipe(prompt, num_inference_steps=steps, guidance_scale=gs, negative_prompt=neg, seed=seed)
+    assert out.images.shape == (1, 128, 128, 3) and len(out.step_ms) == steps + 1           # fused PNDM loop
+
+    def embed(text):
+        ids = tok(text, padding="max_length", max_length=77, truncation=True, return_tensors="np").input_ids
+        return clip_ref.text_encoder_forward(parts["text_encoder"], tcfg, torch.from_numpy(ids))["last_hidden_state"].numpy()
+
+    emb = np.concatenate([embed(neg), embed(prompt)]).transpose(0, 2, 1)[:, :, None, :]       # pipeline.py:245-252
+    got_emb, _ = pipe._encode_prompt(prompt, None, True, neg, None)
+    assert psnr.compute_psnr(got_emb, emb) >= 50.0
+
+    def unet(x, t, e):
+        return unet_ref.unet_forward(parts["unet"], ucfg, torch.from_numpy(x.astype(np.float32)), torch.from_numpy(t.astype(np.float32)),
+                                     torch.from_numpy(e.astype(np.float32))).numpy()
+
+    np.random.seed(seed)
+    lat0 = np.random.randn(1, 4, 16, 16).astype(np.float16)
+    lat = scheduler_ref.denoise_loop(unet, scheduler_ref.PNDM(), lat0.astype(np.float32), emb, steps, gs)
+    img = vae_ref.vae_decode(parts["vae"], vcfg, torch.from_numpy(lat / 0.18215)).numpy()
+    img = np.clip(img / 2 + 0.5, 0, 1).transpose(0, 2, 3, 1)
+    assert psnr.compute_psnr(out.latents, lat) >= 35.0
+    assert psnr.compute_psnr(out.images, img) >= 35.0                                          # tests/test_stable_diffusion.py:33
+    pipe.unet.close(), pipe.vae_decoder.close(), pipe.text_encoder.close()
+
+    # the CLI: same flags as the reference's `python -m python_coreml_stable_diffusion.pipeline`
+    args = P.build_parser().parse_args(["--prompt", prompt, "-i", root, "-o", str(tmp_path / "out"), "--seed", str(seed),
+                                        "--model-version", "mini/stable-diffusion", "--scheduler", "DDIM",
+                                        "--num-inference-steps", "4", "--attention-implementation", "SPLIT_EINSUM_V2",
+                                        "--negative-prompt", neg, "--compute-unit", "CPU_AND_NE"])
+    path = P.main(args)
+    from PIL import Image
+    im = Image.open(path)
+    assert im.size == (128, 128) and os.path.basename(path).startswith("randomSeed_93_computeUnit_CPU_AND_NE_")
