@@ -140,6 +140,12 @@ int sd_unet_time_forward(sd_unet* u, int warmup, int iters, float* ms_per_iter);
 int sd_unet_profile(sd_unet* u, int iters, int cap, float* ms, double* flop, char* labels, int label_bytes,
                     int* n_ops);
 
+/* Tuning hook of the same kind: while tile != 0, every convolution / GEMM whose constraints admit it runs with
+ * this plan (tile 1-6, LDS-DMA ring code 0-5, split-K; csrc/igemm.hip) instead of the table's, so ONE profiled
+ * forward measures a candidate on every layer shape in sequence (tools/tune_plans.py).  tile = 0 switches it off.
+ * Process-global; never set in production. */
+int sd_tune_set_candidate(int tile, int staging, int splitk);
+
 /* Device-resident denoising loop (pipeline.py:500-573 with latents, CFG combine and scheduler
  * update never leaving HBM; Swift twin StableDiffusionPipeline.swift:233-333 incl. imageCount > 1).
  * latents: (n_images, C, H, W) f32 host in/out; the UNet batch must be cfg * n_images with

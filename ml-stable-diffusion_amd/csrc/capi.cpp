@@ -1,6 +1,7 @@
 // extern "C" surface of libsdmi355 (include/sd_mi355x.h).  Exceptions never cross the ABI:
 // every entry point converts sd::Error into a status code + thread-local message.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "unet.h"
@@ -70,6 +71,27 @@ struct Scratch {
     if (iters < 1) iters = 1;
     launch();   // warm (also sets kernel attributes)
     SD_HIP(hipStreamSynchronize(stream));
+    // SD_BENCH_COLD=1: every timed launch starts with cold caches like a kernel inside the UNet step does (its
+    // weights were last touched 1.7 GB of traffic ago): a 512-MiB fill between launches evicts the L2s and the
+    // 256-MiB Infinity Cache; each launch gets its own event pair.  Default: back-to-back launches, operands warm.
+    static const bool cold = getenv("SD_BENCH_COLD") != nullptr;
+    if (cold) {
+      const size_t flush_bytes = (size_t)512 << 20;
+      void* flush = dev<char>(flush_bytes);
+      float total = 0.f;
+      for (int i = 0; i < iters; ++i) {
+        SD_HIP(hipMemsetAsync(flush, i & 0xff, flush_bytes, stream));
+        SD_HIP(hipEventRecord(e0, stream));
+        launch();
+        SD_HIP(hipEventRecord(e1, stream));
+        SD_HIP(hipEventSynchronize(e1));
+        float t = 0.f;
+        SD_HIP(hipEventElapsedTime(&t, e0, e1));
+        total += t;
+      }
+      if (ms) *ms = total / (float)iters;
+      return;
+    }
     SD_HIP(hipEventRecord(e0, stream));
     for (int i = 0; i < iters; ++i) launch();
     SD_HIP(hipEventRecord(e1, stream));
@@ -173,6 +195,14 @@ int sd_unet_denoise_loop(sd_unet* u, const sd_unet_io* io, float* latents, int n
     SD_REQUIRE(u && io && latents && timesteps && coef, kInvalidArgument, "NULL argument");
     u->impl->denoise_loop(*io, latents, n_images, n_steps, timesteps, coef, sample_scale, history, guidance_scale,
                           history_io, ms_per_step);
+  });
+}
+
+int sd_tune_set_candidate(int tile, int staging, int splitk) {
+  return guarded([&] {
+    SD_REQUIRE(tile >= 0 && tile <= 6 && staging >= 0 && staging <= 5 && splitk >= 0 && splitk <= 64, kInvalidArgument,
+               "tune candidate (tile %d, staging %d, splitk %d)", tile, staging, splitk);
+    conv_tune_set_candidate(tile, staging, splitk);
   });
 }
 

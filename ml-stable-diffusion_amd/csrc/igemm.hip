@@ -14,6 +14,7 @@
 // The tile is computed TRANSPOSED (rows = n, cols = m) so each lane owns 4 consecutive output
 // channels of one pixel: bias / timestep-embedding / residual adds and the fp16 store are 8-byte
 // vector accesses with no cross-lane traffic.
+#include <cstdio>
 #include <cstdlib>
 
 #include "kernels.h"
@@ -107,6 +108,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half_t* Xs = reinterpret_cast<half_t*>(smem);                 // [NST][BM][ROW]
   half_t* Ws = Xs + NST * BM * ROW;                             // [NST][BN][ROW]
+  // behind the ring: per-column epilogue constants [BN] bias (+ timestep-embedding row when the tile lies in
+  // one sample) | [BN] LayerNorm colsum.  Loaded once per workgroup next to the first tile's DMA, so the
+  // epilogue reads them from LDS instead of issuing dependent global loads per accumulator fragment
+  // (those cost the 128x128 tile ~9k cycles, profiles/r01_prof_conv_phases.log).
+  float* sconst = reinterpret_cast<float*>(smem + (size_t)NST * (BM + BN) * ROW * sizeof(half_t));
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -332,6 +338,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     }
   };
 
+  // the tile lies inside one sample -> its timestep-embedding row is a per-column constant too
+  const bool temb_uniform = a.temb != nullptr && (a.HoWo % BM) == 0;
+  // issued before the first tile's DMA (oldest VMEM ops of the wave, so the counted vmcnt waits of the ring
+  // are unaffected); first used after the K loop, where they are written to LDS ahead of the epilogue barrier
+  float const_b = 0.f, const_t = 0.f, const_c = 0.f;   // combined only at the store: no early use, no early wait
+  const bool use_consts = !TRANS_OUT && a.splitk == 1;
+  if (use_consts && tid < BN) {
+    const int n = n_blk + tid;
+    if (n < a.N) {
+      if (a.bias) const_b = a.bias[n];
+      if (temb_uniform) const_t = a.temb[(size_t)(m_blk / a.HoWo) * a.temb_stride + n];
+      if constexpr (LNF) const_c = a.ln_colsum[n];
+    }
+  }
+
   if (prof) prof_t[1] = clock64();
   if constexpr (GLDS && NST >= 3) {
     // NST-stage ring: the DMA of tile kt+NST-1 is issued while tile kt is computed and tiles
@@ -341,19 +362,24 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     // cdna guide section 5 "Pipelining across barriers"); wait + barrier sit in one asm statement
     // with a memory clobber so no LDS access is scheduled across them.
     constexpr int PER_TILE = XR + WR;    // LDS-DMA instructions per wave per tile
-    static_assert((NST - 2) * PER_TILE <= 63, "vmcnt range");
+    constexpr int DEPTH = NST - 2;       // tiles that may still be in flight while tile kt is computed
+    static_assert(DEPTH * PER_TILE <= 63, "vmcnt range");
 #pragma unroll
     for (int p = 0; p < NST - 1; ++p)
       if (kt_begin + p < kt_end) load_tile(p);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       const int rel = kt - kt_begin;
       const int ahead = kt_end - 1 - kt;   // tiles after this one that are already issued (capped below)
-      if (NST >= 4 && ahead >= 2)
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * PER_TILE) : "memory");
-      else if (ahead >= 1)
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PER_TILE) : "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      // wait until at most min(ahead, DEPTH) newer tiles are outstanding == tile kt has landed (loads of one
+      // wave return in order); the immediate must be a literal, hence the ladder
+      const int fly = ahead < DEPTH ? ahead : DEPTH;
+      if (DEPTH >= 6 && fly == 6) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((DEPTH >= 6 ? 6 : 0) * PER_TILE) : "memory");
+      else if (DEPTH >= 5 && fly == 5) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((DEPTH >= 5 ? 5 : 0) * PER_TILE) : "memory");
+      else if (DEPTH >= 4 && fly == 4) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((DEPTH >= 4 ? 4 : 0) * PER_TILE) : "memory");
+      else if (DEPTH >= 3 && fly == 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((DEPTH >= 3 ? 3 : 0) * PER_TILE) : "memory");
+      else if (DEPTH >= 2 && fly == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((DEPTH >= 2 ? 2 : 0) * PER_TILE) : "memory");
+      else if (fly == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PER_TILE) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
       read_frags(rel % NST);
       if (kt + NST - 1 < kt_end) load_tile((rel + NST - 1) % NST);
       mfma_step();
@@ -464,7 +490,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
       constexpr int TROW = BM + 8;           // transposed staging (fused q|k|v: the V^T columns), [BN][TROW]
       half_t* ot = reinterpret_cast<half_t*>(smem);   // [BM][OROW] or [BN][TROW]  (<= the K-loop buffers)
       const bool tblock = n_blk >= a.n_trans;         // block-uniform
-      __syncthreads();                       // every wave is done with its last fragment reads
+      if (tid < BN) {
+        sconst[tid] = const_b + const_t;
+        if constexpr (LNF) sconst[BN + tid] = const_c;
+      }
+      __syncthreads();                       // every wave is done with its last fragment reads; sconst is visible
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int ml = (wm * TM + i) * 32 + frow;
@@ -477,18 +507,23 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
                 const int nl = (wn * TN + j) * 32 + 8 * q + 4 * hi;          // value rows (interleaved W)
-                const int nv = n_blk + nl, ng = nv + 32;
                 half4 o;
+                const floatx4 bv4 = *reinterpret_cast<const floatx4*>(sconst + nl);        // 0 beyond N
+                const floatx4 bg4 = *reinterpret_cast<const floatx4*>(sconst + nl + 32);
+                floatx4 cv4 = {0.f, 0.f, 0.f, 0.f}, cg4 = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (LNF) {
+                  cv4 = *reinterpret_cast<const floatx4*>(sconst + BN + nl);
+                  cg4 = *reinterpret_cast<const floatx4*>(sconst + BN + nl + 32);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                   float v, g;
                   if constexpr (LNF) {
-                    const bool in = ng < a.N;
-                    v = fmaf(acc[i][j][4 * q + e], ln_a[i], in ? fmaf(ln_b[i], a.ln_colsum[nv + e], a.bias[nv + e]) : 0.f);
-                    g = fmaf(acc[i][j + 1][4 * q + e], ln_a[i], in ? fmaf(ln_b[i], a.ln_colsum[ng + e], a.bias[ng + e]) : 0.f);
+                    v = fmaf(acc[i][j][4 * q + e], ln_a[i], fmaf(ln_b[i], cv4[e], bv4[e]));
+                    g = fmaf(acc[i][j + 1][4 * q + e], ln_a[i], fmaf(ln_b[i], cg4[e], bg4[e]));
                   } else {
-                    v = acc[i][j][4 * q + e] + ((a.bias && ng < a.N) ? a.bias[nv + e] : 0.f);
-                    g = acc[i][j + 1][4 * q + e] + ((a.bias && ng < a.N) ? a.bias[ng + e] : 0.f);
+                    v = acc[i][j][4 * q + e] + bv4[e];
+                    g = acc[i][j + 1][4 * q + e] + bg4[e];
                   }
                   o[e] = (half_t)(v * gelu_erf(g));
                 }
@@ -503,22 +538,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
               const int nl = (wn * TN + j) * 32 + 8 * q + 4 * hi;
               const int n = n_blk + nl;
               float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-              if (n < a.N) {
-                if constexpr (LNF) {
-                  const floatx4 cs = *reinterpret_cast<const floatx4*>(a.ln_colsum + n);
-                  const floatx4 bb = *reinterpret_cast<const floatx4*>(a.bias + n);
+              const floatx4 bb = *reinterpret_cast<const floatx4*>(sconst + nl);            // bias (+ temb), 0 beyond N
+              if constexpr (LNF) {
+                const floatx4 cs = *reinterpret_cast<const floatx4*>(sconst + BN + nl);
 #pragma unroll
-                  for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], ln_a[i], fmaf(ln_b[i], cs[e], bb[e]));
-                } else if (a.bias) {
-                  floatx4 bb = *reinterpret_cast<const floatx4*>(a.bias + n);
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], ln_a[i], fmaf(ln_b[i], cs[e], bb[e]));
+              } else {
 #pragma unroll
-                  for (int e = 0; e < 4; ++e) v[e] += bb[e];
-                }
-                if (a.temb) {
-                  floatx4 tt = *reinterpret_cast<const floatx4*>(a.temb + (size_t)b * a.temb_stride + n);
+                for (int e = 0; e < 4; ++e) v[e] += bb[e];
+              }
+              if (a.temb && !temb_uniform && n < a.N) {   // tile straddles samples (HoWo < BM): per-row sample index
+                floatx4 tt = *reinterpret_cast<const floatx4*>(a.temb + (size_t)b * a.temb_stride + n);
 #pragma unroll
-                  for (int e = 0; e < 4; ++e) v[e] += tt[e];
-                }
+                for (int e = 0; e < 4; ++e) v[e] += tt[e];
               }
               half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
               if (tblock) {   // V^T columns: staged [n][m] so the write-out rows are token-contiguous
@@ -596,6 +628,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(IgemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half_t* Xh = reinterpret_cast<half_t*>(smem);                  // [2][HALO_LDS_ROWS][BK]
   half_t* Ws = Xh + 2 * HALO_LDS_ROWS * BK;                      // [2][BN][BK]
+  float* sconst = reinterpret_cast<float*>(Ws + 2 * BN * BK);    // [BN] bias + timestep-embedding row of this tile's sample
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -690,6 +723,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(IgemmArgs a) {
     hr0[i] = (ml >> 4) * HALO_W + (ml & 15);
   }
 
+  // per-column epilogue constants: loaded first (oldest VMEM ops), used after the K loop
+  float const_b = 0.f, const_t = 0.f;
+  if (a.splitk == 1 && tid < BN && n_blk + tid < a.N) {
+    if (a.bias) const_b = a.bias[n_blk + tid];
+    if (a.temb) const_t = a.temb[(size_t)b * a.temb_stride + n_blk + tid];
+  }
   if (ch_begin < ch_end) {
 #pragma unroll
     for (int j = 0; j < HALO_PPW; ++j) issue_x_piece(j, ch_begin, 0);
@@ -762,6 +801,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(IgemmArgs a) {
   }
   constexpr int OROW = BN + 8;
   half_t* ot = reinterpret_cast<half_t*>(smem);   // [BM][OROW]
+  if (tid < BN) sconst[tid] = const_b + const_t;
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -773,18 +813,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(IgemmArgs a) {
         const int nl = (wn * TN + j) * 32 + 8 * q + 4 * hi;
         const int n = n_blk + nl;
         float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-        if (n < a.N) {
-          if (a.bias) {
-            floatx4 bb = *reinterpret_cast<const floatx4*>(a.bias + n);
+        const floatx4 bb = *reinterpret_cast<const floatx4*>(sconst + nl);   // 0 beyond N
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += bb[e];
-          }
-          if (a.temb) {
-            floatx4 tt = *reinterpret_cast<const floatx4*>(a.temb + (size_t)b * a.temb_stride + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += tt[e];
-          }
-        }
+        for (int e = 0; e < 4; ++e) v[e] += bb[e];
         half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
         *reinterpret_cast<half4*>(ot + ml * OROW + nl) = o;
       }
@@ -1068,7 +1099,9 @@ void tile_dims(int tile, int& bm, int& bn) {
 // split), still gives every CU work (>= ~1.5 workgroups per CU); deep-K small-M layers (8x8 /
 // 16x16 levels stream weights: SURVEY.md 7.3(1)) end up split, shallow 1x1 GEMMs end up on the
 // small tile with many workgroups.
-struct TunedConv { int ksize, stride, up, ctot, n, m, tile, splitk; };
+// kind: 0 plain epilogue (bias / timestep embedding / residual), 1 LayerNorm-folded, 2 GEGLU (LayerNorm-folded or
+// not), 3 fused q|k|v (LayerNorm-folded, V columns leave transposed).  staging: see launch_tile.
+struct TunedConv { int kind, ksize, stride, up, ctot, n, m, tile, staging, splitk; };
 #if __has_include("tuned_convs.inc")
 static const TunedConv kTuned[] = {
 #include "tuned_convs.inc"
@@ -1079,14 +1112,61 @@ static const TunedConv* kTuned = nullptr;
 static const int kNumTuned = 0;
 #endif
 
+// SD_PLAN_TABLE=<file>: rows "{kind, ksize, stride, up, Ctot, N, M, tile, staging, splitk}" (the format of
+// tuned_convs.inc) read at first use and consulted BEFORE the compiled-in table - how tools/tune_plans.py
+// validates a freshly measured table in the same GPU session without a rebuild.
+const std::vector<TunedConv>& runtime_table() {
+  static const std::vector<TunedConv> table = [] {
+    std::vector<TunedConv> t;
+    const char* path = getenv("SD_PLAN_TABLE");
+    if (!path) return t;
+    FILE* f = fopen(path, "r");
+    if (!f) {
+      fprintf(stderr, "[sd] SD_PLAN_TABLE=%s cannot be opened - ignored\n", path);
+      return t;
+    }
+    char line[512];
+    while (fgets(line, sizeof(line), f)) {
+      TunedConv r;
+      if (sscanf(line, " {%d, %d, %d, %d, %d, %d, %d, %d, %d, %d}", &r.kind, &r.ksize, &r.stride, &r.up, &r.ctot, &r.n, &r.m,
+                 &r.tile, &r.staging, &r.splitk) == 10)
+        t.push_back(r);
+    }
+    fclose(f);
+    fprintf(stderr, "[sd] SD_PLAN_TABLE=%s: %zu plans\n", path, t.size());
+    return t;
+  }();
+  return table;
+}
+
+// measurement hook (sd_tune_set_candidate): while tile != 0 every conv whose constraints allow it runs this plan,
+// so one profiled forward evaluates a candidate on every layer shape at once, in sequence (tools/tune_plans.py)
+struct TuneCandidate { int tile = 0, staging = 0, splitk = 0; };
+TuneCandidate g_tune;
+
+int conv_kind(const ConvDesc& d) {
+  if (d.out_t) return 3;
+  if (d.out_mode == kOutGeglu) return 2;
+  return d.ln_colsum ? 1 : 0;
+}
+
 Plan choose_plan(const ConvDesc& d, const IgemmArgs& a) {
   Plan p{d.tile, d.splitk};
+  p.staging = d.staging;
   const bool geglu = d.out_mode == kOutGeglu;
   // the LayerNorm fold needs whole rows per workgroup, the fused q|k|v epilogue has no slab path
   const bool can_split = d.out_mode == kOutHalf && !d.ln_colsum && !d.out_t;
-  if (d.ln_colsum || d.out_t) p.splitk = 1;
-  if ((p.tile == 5 || p.tile == 6) && !halo_ok(d)) p.tile = 0;
   auto is_halo = [](int c) { return c == 5 || c == 6; };
+  auto tile_ok = [&](int c) {
+    if (c < 1 || c > 6) return false;
+    if (is_halo(c)) return halo_ok(d) && !d.ln_colsum && !d.out_t && !geglu;
+    int bm, bn;
+    tile_dims(c, bm, bn);
+    if (geglu && c != 1 && c != 4) return false;       // GEGLU value/gate pairs need 64 n-columns per wave
+    if (d.out_t && d.n_trans % bn != 0) return false;  // the q|k / v boundary must be a tile boundary
+    return true;
+  };
+  if (!tile_ok(p.tile)) p.tile = 0;
   auto blocks_of = [&](int c) {
     int bm, bn;
     tile_dims(c, bm, bn);
@@ -1102,30 +1182,36 @@ Plan choose_plan(const ConvDesc& d, const IgemmArgs& a) {
     while (can_split && s < 16 && ksteps(c) / (s * 2) >= per_min) s *= 2;
     return s;
   };
-  if (p.tile == 0 && p.splitk == 0 && can_split) {
-    for (int i = 0; i < kNumTuned; ++i) {
-      const TunedConv& t = kTuned[i];
-      if (t.ksize == a.ksize && t.stride == a.stride && t.up == a.up && t.ctot == a.Ctot && t.n == a.N && t.m == a.M) {
-        p.tile = t.tile % 10;
-        p.staging = t.tile / 10;
-        p.splitk = t.splitk;
-        if (is_halo(p.tile) && !halo_ok(d)) p.tile = p.splitk = 0;
-        break;
-      }
+  const bool pinned = p.tile != 0 || p.splitk != 0 || p.staging != 0;   // the caller chose (operator-level A/B tests)
+  if (!pinned && g_tune.tile != 0 && tile_ok(g_tune.tile)) {
+    p.tile = g_tune.tile;
+    p.staging = g_tune.staging;
+    p.splitk = g_tune.splitk;
+  } else if (!pinned) {
+    const int kind = conv_kind(d);
+    auto match = [&](const TunedConv& t) {
+      return t.kind == kind && t.ksize == a.ksize && t.stride == a.stride && t.up == a.up && t.ctot == a.Ctot && t.n == a.N &&
+             t.m == a.M && tile_ok(t.tile);
+    };
+    const TunedConv* hit = nullptr;
+    for (const TunedConv& t : runtime_table())
+      if (!hit && match(t)) hit = &t;
+    for (int i = 0; i < kNumTuned && !hit; ++i)
+      if (match(kTuned[i])) hit = &kTuned[i];
+    if (hit) {
+      p.tile = hit->tile;
+      p.staging = hit->staging;
+      p.splitk = hit->splitk;
     }
   }
   if (p.tile == 0) {
     p.tile = 3;
     for (int c : {1, 2, 4, 3}) {
-      if (geglu && c != 1 && c != 4) continue;   // GEGLU value/gate pairs need 64 n-columns per wave
-      int bm, bn;
-      tile_dims(c, bm, bn);
-      if (d.out_t && d.n_trans % bn != 0) continue;   // the q|k / v boundary must be a tile boundary
+      if (!tile_ok(c)) continue;
       if (blocks_of(c) * max_split(c) >= 384 || c == 3) { p.tile = c; break; }
     }
-    if (geglu && p.tile == 3) p.tile = 4;
+    if (!tile_ok(p.tile)) p.tile = 4;
   }
-  if (geglu && p.tile != 1 && p.tile != 4) p.tile = 4;
   if (p.splitk == 0) {
     p.splitk = 1;
     const int ms = max_split(p.tile);
@@ -1133,6 +1219,7 @@ Plan choose_plan(const ConvDesc& d, const IgemmArgs& a) {
   }
   if (!can_split) p.splitk = 1;
   if (p.splitk > ksteps(p.tile)) p.splitk = ksteps(p.tile);
+  if (p.splitk < 1) p.splitk = 1;
   return p;
 }
 
@@ -1142,7 +1229,7 @@ void launch_halo(IgemmArgs a, int splitk, hipStream_t s) {
   a.nk_total = nch;
   a.nk_per_split = cdiv(nch, splitk);
   a.splitk = cdiv(nch, a.nk_per_split);
-  const size_t lds = ((size_t)2 * HALO_LDS_ROWS * BK + (size_t)2 * BN * BK) * sizeof(half_t);
+  const size_t lds = ((size_t)2 * HALO_LDS_ROWS * BK + (size_t)2 * BN * BK) * sizeof(half_t) + BN * sizeof(float);
   auto k = conv3x3_halo_kernel<BN>;
   static DynLdsOnce once;   // per instantiation, per device
   once.set(k, lds);
@@ -1152,7 +1239,7 @@ void launch_halo(IgemmArgs a, int splitk, hipStream_t s) {
 
 template <int BM, int BN, int WGM, int WGN, bool TRANS, bool GLDS, int NST, bool LNF = false>
 void launch_variant(const IgemmArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)NST * (BM + BN) * (GLDS ? BK : LDS_ROW) * sizeof(half_t);
+  const size_t lds = (size_t)NST * (BM + BN) * (GLDS ? BK : LDS_ROW) * sizeof(half_t) + 2 * BN * sizeof(float);
   static_assert((size_t)BN * (BM + 8) <= (size_t)NST * (BM + BN) * (GLDS ? BK : LDS_ROW), "transposed staging fits");
   dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), a.splitk);
   auto k = igemm_kernel<BM, BN, WGM, WGN, TRANS, GLDS, NST, 0, LNF>;
@@ -1163,7 +1250,7 @@ void launch_variant(const IgemmArgs& a, hipStream_t s) {
 
 template <int BM, int BN, int DBG>
 void launch_debug(const IgemmArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(half_t);
+  const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(half_t) + 2 * BN * sizeof(float);
   dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), a.splitk);
   auto k = igemm_kernel<BM, BN, 2, 2, false, true, 2, DBG>;
   SD_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1182,22 +1269,41 @@ bool launch_debug_mode(const IgemmArgs& a, int dbg, hipStream_t s) {
   }
 }
 
-// staging: 0 = LDS-DMA 2 stages, 1 = register staging (A/B reference), 2 / 3 = LDS-DMA 3- / 4-stage ring
+// staging: 0 = LDS-DMA 2 stages, 1 = register staging (A/B reference), 2 / 3 / 4 / 5 = LDS-DMA ring of
+// 3 / 4 / 6 / 8 stages (a ring that would not fit the 160 KB of LDS falls back to the deepest one that does)
+constexpr size_t kLdsBudget = 160 * 1024;
+template <int BM, int BN>
+constexpr bool ring_fits(int nst) {
+  return (size_t)nst * (BM + BN) * BK * sizeof(half_t) + 2 * BN * sizeof(float) <= kLdsBudget;
+}
+template <int BM, int BN, int WGM, int WGN, bool LNF>
+void launch_ring(const IgemmArgs& a, int staging, hipStream_t s) {
+  if (staging >= 5) {
+    if constexpr (ring_fits<BM, BN>(8)) { launch_variant<BM, BN, WGM, WGN, false, true, 8, LNF>(a, s); return; }
+  }
+  if (staging >= 4) {
+    if constexpr (ring_fits<BM, BN>(6)) { launch_variant<BM, BN, WGM, WGN, false, true, 6, LNF>(a, s); return; }
+  }
+  if (staging >= 3) {
+    if constexpr (ring_fits<BM, BN>(4)) { launch_variant<BM, BN, WGM, WGN, false, true, 4, LNF>(a, s); return; }
+  }
+  if (staging >= 2) { launch_variant<BM, BN, WGM, WGN, false, true, 3, LNF>(a, s); return; }
+  launch_variant<BM, BN, WGM, WGN, false, true, 2, LNF>(a, s);
+}
+
 template <int BM, int BN, int WGM, int WGN>
 void launch_tile(const IgemmArgs& a, bool trans, int staging, hipStream_t s) {
-  if (a.ln_colsum) {   // LayerNorm-folded 1x1 GEMM: LDS-DMA two-stage kernel only
-    launch_variant<BM, BN, WGM, WGN, false, true, 2, true>(a, s);
+  if (a.ln_colsum) {   // LayerNorm-folded 1x1 GEMM
+    launch_ring<BM, BN, WGM, WGN, true>(a, staging == 1 ? 0 : staging, s);
     return;
   }
   if (trans) {
     if (staging == 1) launch_variant<BM, BN, WGM, WGN, true, false, 2>(a, s);
-    else if (staging == 2) launch_variant<BM, BN, WGM, WGN, true, true, 3>(a, s);
+    else if (staging >= 2) launch_variant<BM, BN, WGM, WGN, true, true, 3>(a, s);
     else launch_variant<BM, BN, WGM, WGN, true, true, 2>(a, s);
   } else {
     if (staging == 1) launch_variant<BM, BN, WGM, WGN, false, false, 2>(a, s);
-    else if (staging == 2) launch_variant<BM, BN, WGM, WGN, false, true, 3>(a, s);
-    else if (staging == 3) launch_variant<BM, BN, WGM, WGN, false, true, 4>(a, s);
-    else launch_variant<BM, BN, WGM, WGN, false, true, 2>(a, s);
+    else launch_ring<BM, BN, WGM, WGN, false>(a, staging, s);
   }
 }
 
@@ -1217,7 +1323,17 @@ size_t conv_workspace_bytes(const ConvDesc& d) {
   if (!conv_fast_path_ok(d)) return 0;
   IgemmArgs a = make_args(d);
   Plan p = choose_plan(d, a);
-  return p.splitk > 1 ? (size_t)p.splitk * a.M * a.N * sizeof(float) : 0;   // upper bound (launch may use fewer splits)
+  // SD_TUNE=1 (tools/tune_plans.py): room for any split-K candidate of the sweep
+  static const bool tuning = getenv("SD_TUNE") != nullptr;
+  const bool can_split = d.out_mode == kOutHalf && !d.ln_colsum && !d.out_t;
+  const int splits = (tuning && can_split) ? std::max(p.splitk, 16) : p.splitk;
+  return splits > 1 ? (size_t)splits * a.M * a.N * sizeof(float) : 0;   // upper bound (launch may use fewer splits)
+}
+
+void conv_tune_set_candidate(int tile, int staging, int splitk) {
+  g_tune.tile = tile;
+  g_tune.staging = staging;
+  g_tune.splitk = splitk;
 }
 
 void launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
@@ -1247,7 +1363,7 @@ void launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
     a.partial = ws.partial;
   }
   const bool trans = d.out_mode == kOutHalfT;
-  const int st = d.staging ? d.staging : p.staging;
+  const int st = p.staging;
   static const bool log_plans = getenv("SD_LOG_CONVS") != nullptr;
   if (log_plans)
     fprintf(stderr, "[sd conv] k%d s%d up%d C0=%d C1=%d M=%d N=%d K=%d mode=%d tile=%d splitk=%d\n", a.ksize, a.stride, a.up,

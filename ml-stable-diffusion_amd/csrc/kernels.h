@@ -57,6 +57,8 @@ struct ConvWorkspace {
 size_t conv_workspace_bytes(const ConvDesc& d);
 void launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s);
 bool conv_fast_path_ok(const ConvDesc& d);
+// tuning hook: plan (tile 1-6, staging 0-5, splitk) forced on every conv that admits it; tile 0 = off
+void conv_tune_set_candidate(int tile, int staging, int splitk);
 
 // direct conv for tiny / odd shapes (any Cin, any N): fp32 accumulate, one thread per output
 void launch_conv_generic(const ConvDesc& d, int act_silu_out, hipStream_t s);
@@ -127,6 +129,7 @@ struct LoopTables {
   const float* coef;        // [n_steps][8]: cx, cm, ch0..ch2, a, b, flags  (cfg_sched_step_kernel, misc.hip)
   int* step;                // device scalar
   const float* in_scale;    // [n_steps] scale_model_input factor (sigma-space schedulers), or null
+  unsigned* ticket;         // device scalar (0 between launches): arrival counter of cfg_sched_step_kernel
 };
 // latents fp32 NCHW [Bimg][4][H][W] -> UNet sample fp16 NHWC [cfg*Bimg][H][W][4], timestep buffer
 void launch_loop_prep(const float* latents, half_t* sample, float* tbuf, LoopTables t, int Bimg, int C, int H,

@@ -226,18 +226,19 @@ __global__ void loop_prep_kernel(const float* __restrict__ latents, half_t* __re
 // Generic linear-multistep update on the device (DDIM / PLMS / DPM-Solver++ 2M are all instances):
 //   eps = u + g*(c-u);  m = a*x + b*eps;  x <- cx*x + cm*m + sum_j ch[j]*hist[j];  hist <- [m, hist[0..]]
 // coef row: [cx, cm, ch0, ch1, ch2, a, b, flags]; flags != 0: m is NOT pushed into the history (the second
-// evaluation of the PLMS warm-up, Scheduler.swift:228-236).  One workgroup: the whole update is a few
-// hundred KB, and the last statement can then advance the device step counter without a second launch.
-__global__ __launch_bounds__(1024) void cfg_sched_step_kernel(const float* __restrict__ noise_pred,
-                                                               float* __restrict__ latents, float* __restrict__ eps_hist,
-                                                               LoopTables t, float guidance, int Bimg, int CHW, int cfg,
-                                                               int hist) {
+// evaluation of the PLMS warm-up, Scheduler.swift:228-236).  The workgroup that arrives last at the ticket
+// advances the device step counter (every workgroup read it before arriving), so the step needs no second
+// launch; the ticket only orders that one store, the arithmetic stays atomics-free and deterministic.
+__global__ __launch_bounds__(256) void cfg_sched_step_kernel(const float* __restrict__ noise_pred,
+                                                              float* __restrict__ latents, float* __restrict__ eps_hist,
+                                                              LoopTables t, float guidance, int Bimg, int CHW, int cfg,
+                                                              int hist) {
   const int step = *t.step;
   const float* cf = t.coef + (size_t)step * 8;
   const float cx = cf[0], cm = cf[1], ma = cf[5], mb = cf[6];
   const bool push = cf[7] == 0.f;
   const size_t total = (size_t)Bimg * CHW;
-  for (size_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     float eps = noise_pred[idx];
     if (cfg == 2) {
       const float c = noise_pred[total + idx];
@@ -255,8 +256,14 @@ __global__ __launch_bounds__(1024) void cfg_sched_step_kernel(const float* __res
     if (push && hist > 0) eps_hist[idx] = m;
     latents[idx] = x;
   }
-  __syncthreads();   // every thread has read *t.step
-  if (threadIdx.x == 0) *t.step = step + 1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned arrived = __hip_atomic_fetch_add(t.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (arrived == gridDim.x - 1) {
+      *t.ticket = 0;
+      *t.step = step + 1;
+    }
+  }
 }
 
 inline int grid_for(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 2048); }
@@ -349,9 +356,8 @@ void launch_loop_prep(const float* latents, half_t* sample, float* tbuf, LoopTab
 void launch_cfg_sched_step(const float* noise_pred, float* latents, float* eps_hist, LoopTables t, float guidance,
                            int Bimg, int CHW, int cfg, int hist, hipStream_t s) {
   const size_t n = (size_t)Bimg * CHW;
-  (void)n;
-  hipLaunchKernelGGL(cfg_sched_step_kernel, dim3(1), dim3(1024), 0, s, noise_pred, latents, eps_hist, t, guidance, Bimg,
-                     CHW, cfg, hist);
+  hipLaunchKernelGGL(cfg_sched_step_kernel, dim3(std::min(grid_for(n), 64)), dim3(256), 0, s, noise_pred, latents,
+                     eps_hist, t, guidance, Bimg, CHW, cfg, hist);
   SD_HIP(hipGetLastError());
 }
 

@@ -258,8 +258,11 @@ Tensor UNet::conv_w(std::vector<Op>& ops, const std::string& name, const half_t*
   {
     const int cin = x.C + (x2 ? x2->C : 0);
     char buf[256];
-    snprintf(buf, sizeof(buf), "%s%s %d->%d @%dx%d M=%d K=%d %s", k == 3 ? "conv3x3" : (geglu ? "geglu1x1" : "gemm1x1"),
-             ex && ex->ln_colsum ? "+ln" : "", cin, cout, d.Ho, d.Wo, x.B * d.Ho * d.Wo, cin * k * k, name.c_str());
+    // trailing "#kind,ksize,stride,up,Ctot,N,M" is the plan-table key of this op (tools/tune_plans.py)
+    const int kind = d.out_t ? 3 : (geglu ? 2 : (d.ln_colsum ? 1 : 0));
+    snprintf(buf, sizeof(buf), "%s%s %d->%d @%dx%d M=%d K=%d %s #%d,%d,%d,%d,%d,%d,%d", k == 3 ? "conv3x3" : (geglu ? "geglu1x1" : "gemm1x1"),
+             ex && ex->ln_colsum ? "+ln" : "", cin, cout, d.Ho, d.Wo, x.B * d.Ho * d.Wo, cin * k * k, name.c_str(), kind, k,
+             stride, up, cin, cout, x.B * d.Ho * d.Wo);
     ops.back().label = buf;
     ops.back().flop = 2.0 * x.B * d.Ho * d.Wo * (double)cout * cin * k * k;
   }
@@ -1131,7 +1134,7 @@ void UNet::denoise_loop(const sd_unet_io& io, float* latents, int n_images, int 
   if (!latents_) {
     latents_ = arena_.alloc_n<float>((size_t)cfg_.batch * C * H * W);
     eps_hist_ = arena_.alloc_n<float>(hist_n);
-    step_ = arena_.alloc_n<int>(1);
+    step_ = arena_.alloc_n<int>(2);   // [0]: step counter, [1]: arrival ticket of cfg_sched_step_kernel
   }
   if (tab_cap_ < n_steps) {
     tab_cap_ = std::max(n_steps, 1024);
@@ -1144,7 +1147,7 @@ void UNet::denoise_loop(const sd_unet_io& io, float* latents, int n_images, int 
   SD_HIP(hipMemcpyAsync(latents_, latents, lat_n * sizeof(float), hipMemcpyHostToDevice, stream_));
   SD_HIP(hipMemcpyAsync(tab_timesteps_, timesteps, (size_t)n_steps * sizeof(float), hipMemcpyHostToDevice, stream_));
   SD_HIP(hipMemcpyAsync(tab_coef_, coef, (size_t)n_steps * 8 * sizeof(float), hipMemcpyHostToDevice, stream_));
-  SD_HIP(hipMemsetAsync(step_, 0, sizeof(int), stream_));
+  SD_HIP(hipMemsetAsync(step_, 0, 2 * sizeof(int), stream_));
   SD_HIP(hipMemsetAsync(eps_hist_, 0, hist_n * sizeof(float), stream_));
   if (history_io && history > 0)   // slot j: [n_images][C][H][W], continuing a loop another handle began (refiner swap)
     for (int j = 0; j < history; ++j)
@@ -1152,7 +1155,8 @@ void UNet::denoise_loop(const sd_unet_io& io, float* latents, int n_images, int 
                             hipMemcpyHostToDevice, stream_));
   if (sample_scale)
     SD_HIP(hipMemcpyAsync(tab_scale_, sample_scale, (size_t)n_steps * sizeof(float), hipMemcpyHostToDevice, stream_));
-  LoopTables tab{tab_timesteps_, tab_coef_, step_, sample_scale ? tab_scale_ : nullptr};
+  LoopTables tab{tab_timesteps_, tab_coef_, step_, sample_scale ? tab_scale_ : nullptr,
+                 reinterpret_cast<unsigned*>(step_ + 1)};
   auto step_ops = [&]() {
     launch_loop_prep(latents_, x_in_.p, tbuf_, tab, n_images, C, H, W, cfgmul, stream_);
     run_attached();
