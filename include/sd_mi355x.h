@@ -245,6 +245,11 @@ int sd_op_timestep_embedding(const float* t, float* out, int n, int dim, int fli
 /* numpy legacy stream: np.random.seed(seed); np.random.randn(n) (pipeline.py:331,:726;
  * NumPyRandomSource.swift:28-102).  Host-side, bit-exact. */
 int sd_numpy_randn(uint32_t seed, double* out, size_t n);
+/* the other two seed-exact sources of the reference (RandomSource.swift): torch's CPU generator
+ * (`torch.manual_seed(seed); torch.randn(n)`, TorchRandomSource.swift:116-150) and torch's CUDA generator
+ * (Philox4x32-10, NvRandomSource.swift:25-80; `offset` = number of arrays drawn before).  Host-side. */
+int sd_torch_randn(uint32_t seed, double* out, size_t n);
+int sd_philox_randn(uint64_t seed, uint32_t offset, double* out, size_t n);
 /* MFMA fragment layout self-check used by the build/smoke tests (returns 0 when the hardware
  * layout matches what the kernels assume). */
 int sd_selftest_mfma(void);

@@ -452,35 +452,44 @@ int sd_op_timestep_embedding(const float* t, float* out, int n, int dim, int fli
   });
 }
 
-// numpy legacy RandomState: MT19937 + 53-bit doubles + Marsaglia polar method
-// (NumPyRandomSource.swift:28-102; golden: StableDiffusionTests.swift:52-62)
-int sd_numpy_randn(uint32_t seed, double* out, size_t n) {
-  return guarded([&] {
-    SD_REQUIRE(out || n == 0, kInvalidArgument, "NULL output");
-    uint32_t key[624];
+namespace {
+// MT19937 as numpy's legacy RandomState and torch's CPU generator both use it (init_genrand + genrand_int32)
+struct Mt19937 {
+  uint32_t key[624];
+  int pos = 624;
+  explicit Mt19937(uint32_t seed) {
     uint32_t s = seed;
     for (uint32_t i = 0; i < 624; ++i) {
       key[i] = s;
       s = 1812433253u * (s ^ (s >> 30)) + i + 1;
     }
-    int pos = 624;
-    auto next_u32 = [&]() -> uint32_t {
-      if (pos == 624) {
-        for (int i = 0; i < 624; ++i) {
-          const uint32_t y = (key[i] & 0x80000000u) | (key[(i + 1) % 624] & 0x7fffffffu);
-          key[i] = key[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-        }
-        pos = 0;
+  }
+  uint32_t next_u32() {
+    if (pos == 624) {
+      for (int i = 0; i < 624; ++i) {
+        const uint32_t y = (key[i] & 0x80000000u) | (key[(i + 1) % 624] & 0x7fffffffu);
+        key[i] = key[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
       }
-      uint32_t y = key[pos++];
-      y ^= y >> 11;
-      y ^= (y << 7) & 0x9d2c5680u;
-      y ^= (y << 15) & 0xefc60000u;
-      y ^= y >> 18;
-      return y;
-    };
+      pos = 0;
+    }
+    uint32_t y = key[pos++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+  }
+};
+}  // namespace
+
+// numpy legacy RandomState: MT19937 + 53-bit doubles + Marsaglia polar method
+// (NumPyRandomSource.swift:28-102; golden: StableDiffusionTests.swift:52-62)
+int sd_numpy_randn(uint32_t seed, double* out, size_t n) {
+  return guarded([&] {
+    SD_REQUIRE(out || n == 0, kInvalidArgument, "NULL output");
+    Mt19937 mt(seed);
     auto next_double = [&]() -> double {
-      const uint32_t a = next_u32() >> 5, b = next_u32() >> 6;
+      const uint32_t a = mt.next_u32() >> 5, b = mt.next_u32() >> 6;
       return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
     };
     bool has_cached = false;
@@ -501,6 +510,81 @@ int sd_numpy_randn(uint32_t seed, double* out, size_t n) {
       cached = f * x1;
       has_cached = true;
       out[i] = f * x2;
+    }
+  });
+}
+
+// torch.manual_seed(seed); torch.randn(n) on the CPU (TorchRandomSource.swift:116-150): 24-bit uniforms, Box-Muller
+// over blocks of 16, ragged tail from 53-bit doubles over the last 16; n < 16 scalar Box-Muller with the sine cached
+int sd_torch_randn(uint32_t seed, double* out, size_t n) {
+  return guarded([&] {
+    SD_REQUIRE(out || n == 0, kInvalidArgument, "NULL output");
+    Mt19937 mt(seed);
+    const double two_pi = 6.283185307179586476925286766559;
+    auto next_double53 = [&]() -> double {
+      const uint64_t hi = mt.next_u32(), lo = mt.next_u32();
+      return (double)(((hi << 32) | lo) & 9007199254740991ull) * (1.0 / 9007199254740992.0);
+    };
+    if (n < 16) {
+      bool has_cached = false;
+      double cached = 0.0;
+      for (size_t i = 0; i < n; ++i) {
+        if (has_cached) {
+          out[i] = cached;
+          has_cached = false;
+          continue;
+        }
+        const double u1 = next_double53();
+        const double u2 = 1.0 - next_double53();
+        const double radius = std::sqrt(-2.0 * std::log(u2));
+        cached = radius * std::sin(two_pi * u1);
+        has_cached = true;
+        out[i] = radius * std::cos(two_pi * u1);
+      }
+      return;
+    }
+    for (size_t i = 0; i < n; ++i) out[i] = (double)(mt.next_u32() & 16777215u) * (1.0 / 16777216.0);
+    auto fill16 = [&](size_t i) {
+      for (size_t j = 0; j < 8; ++j) {
+        const double u1 = 1.0 - out[i + j], u2 = out[i + j + 8];
+        const double radius = std::sqrt(-2.0 * std::log(u1)), theta = two_pi * u2;
+        out[i + j] = radius * std::cos(theta);
+        out[i + j + 8] = radius * std::sin(theta);
+      }
+    };
+    for (size_t i = 0; i + 15 < n; i += 16) fill16(i);
+    if (n % 16) {
+      // ragged tail: the last 16 values are redrawn.  torch draws them like the rest (24-bit floats); the Swift
+      // restatement draws 53-bit doubles here (TorchRandomSource.swift:135-137).  Latent counts on the path are
+      // multiples of 16, where the two agree; torch itself is followed for the tail (tests pin it against torch).
+      for (size_t i = n - 16; i < n; ++i) out[i] = (double)(mt.next_u32() & 16777215u) * (1.0 / 16777216.0);
+      fill16(n - 16);
+    }
+  });
+}
+
+// torch.randn on a CUDA device (NvRandomSource.swift:25-80): Philox4x32-10, counter (offset, 0, i, 0), key = seed,
+// Box-Muller on the first two output words of element i
+int sd_philox_randn(uint64_t seed, uint32_t offset, double* out, size_t n) {
+  return guarded([&] {
+    SD_REQUIRE(out || n == 0, kInvalidArgument, "NULL output");
+    const double pi = 3.14159265358979323846;
+    for (size_t i = 0; i < n; ++i) {
+      uint32_t c0 = offset, c1 = 0, c2 = (uint32_t)i, c3 = 0;
+      uint32_t k0 = (uint32_t)(seed & 0xffffffffu), k1 = (uint32_t)(seed >> 32);
+      for (int r = 0; r < 10; ++r) {
+        const uint64_t v1 = (uint64_t)c0 * 0xD2511F53u, v2 = (uint64_t)c2 * 0xCD9E8D57u;
+        const uint32_t n0 = (uint32_t)(v2 >> 32) ^ c1 ^ k0, n1 = (uint32_t)v2;
+        const uint32_t n2 = (uint32_t)(v1 >> 32) ^ c3 ^ k1, n3 = (uint32_t)v1;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        if (r < 9) {
+          k0 += 0x9E3779B9u;
+          k1 += 0xBB67AE85u;
+        }
+      }
+      const double u = (double)c0 / 4294967296.0 + (1.0 / 8589934592.0);
+      const double v = (double)c1 * (pi / 2147483648.0) + (pi / 4294967296.0);
+      out[i] = std::sqrt(-2.0 * std::log(u)) * std::sin(v);
     }
   });
 }

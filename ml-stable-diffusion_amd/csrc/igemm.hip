@@ -622,13 +622,51 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
 // ---------------------------------------------------------------------------------------------
 constexpr int HALO_W = 18, HALO_ROWS = 180, HALO_PIECES = 23, HALO_LDS_ROWS = 184, HALO_PPW = 6;
 
-template <int BN>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(IgemmArgs a) {
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_barrier() {   // counted wait + raw barrier in one statement (no LDS access moves across)
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+constexpr int halo_mod9(int t) { return ((t % 9) + 9) % 9; }
+constexpr int halo_x_issued(int tap) { return halo_mod9(tap) < HALO_PPW ? 1 : 0; }
+// VMEM ops one wave has issued AFTER the weight tile of step s (tap `tap`) in steady state: per step, in order,
+// [WR weight pieces of step s+D-1] then [one halo piece of the next chunk when tap < HALO_PPW].  At tap 0 the halo
+// of this chunk must have landed too; its last piece went out at tap 5 of the previous chunk (3 steps = 3*WR ops ago).
+template <int D, int WR>
+constexpr int halo_wait_count(int tap) {
+  int n = halo_x_issued(tap - D + 1);
+  for (int i = 2; i <= D - 1; ++i) n += WR + halo_x_issued(tap - D + i);
+  if (tap == 0 && n > 3 * WR) n = 3 * WR;
+  return n;
+}
+
+template <int D, int WR>
+__device__ __forceinline__ void halo_wait(int tap) {   // folds to one wait once the tap loop is unrolled
+  switch (tap) {
+    case 0: wait_vmcnt_barrier<halo_wait_count<D, WR>(0)>(); break;
+    case 1: wait_vmcnt_barrier<halo_wait_count<D, WR>(1)>(); break;
+    case 2: wait_vmcnt_barrier<halo_wait_count<D, WR>(2)>(); break;
+    case 3: wait_vmcnt_barrier<halo_wait_count<D, WR>(3)>(); break;
+    case 4: wait_vmcnt_barrier<halo_wait_count<D, WR>(4)>(); break;
+    case 5: wait_vmcnt_barrier<halo_wait_count<D, WR>(5)>(); break;
+    case 6: wait_vmcnt_barrier<halo_wait_count<D, WR>(6)>(); break;
+    case 7: wait_vmcnt_barrier<halo_wait_count<D, WR>(7)>(); break;
+    default: wait_vmcnt_barrier<halo_wait_count<D, WR>(8)>(); break;
+  }
+}
+
+// D = stages of the weight ring (D - 1 tap steps of weights in flight; 2 = the round-1 double buffer).
+constexpr size_t halo_lds_bytes(int bn, int d) {
+  return ((size_t)2 * HALO_LDS_ROWS * BK + (size_t)d * bn * BK) * sizeof(half_t) + bn * sizeof(float);
+}
+// two workgroups per CU (two waves per SIMD, <= 256 VGPRs) wherever the LDS footprint allows it
+template <int BN, int D>
+__global__ __launch_bounds__(256, halo_lds_bytes(BN, D) <= 80 * 1024 ? 2 : 1) void conv3x3_halo_kernel(IgemmArgs a) {
   constexpr int BM = 128, TM = 2, TN = BN / 64, WR = BN / 32;
+  static_assert(halo_wait_count<D, WR>(1) <= 63 && (D - 2) * WR + 6 <= 63, "vmcnt range");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half_t* Xh = reinterpret_cast<half_t*>(smem);                  // [2][HALO_LDS_ROWS][BK]
-  half_t* Ws = Xh + 2 * HALO_LDS_ROWS * BK;                      // [2][BN][BK]
-  float* sconst = reinterpret_cast<float*>(Ws + 2 * BN * BK);    // [BN] bias + timestep-embedding row of this tile's sample
+  half_t* Ws = Xh + 2 * HALO_LDS_ROWS * BK;                      // [D][BN][BK]
+  float* sconst = reinterpret_cast<float*>(Ws + D * BN * BK);    // [BN] bias + timestep-embedding row of this tile's sample
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -662,7 +700,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(IgemmArgs a) {
   int hpix[HALO_PPW], hchunk[HALO_PPW];
 #pragma unroll
   for (int j = 0; j < HALO_PPW; ++j) {
-    const int p = wave + 4 * j;
+    const int p = (wave + 4 * j < HALO_PIECES) ? wave + 4 * j : HALO_PIECES - 1;
     const int hr = 8 * p + (lane >> 3);
     const int hy = hr / HALO_W, hx = hr - hy * HALO_W;
     const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
@@ -680,8 +718,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(IgemmArgs a) {
   }
 
   auto issue_x_piece = [&](int j, int ch, int xstage) {
+    // every wave issues exactly HALO_PPW pieces per chunk (the counted vmcnt waits rely on it): the one piece
+    // index past the halo (wave 3, j = 5) re-loads piece 22 - same bytes to the same LDS rows
     const int p = wave + 4 * j;
-    if (p >= HALO_PIECES) return;                       // wave-uniform
     int cc = ch * BK;
     const half_t* src = a.x0;
     int Csrc = a.C0;
@@ -691,7 +730,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(IgemmArgs a) {
       Csrc = a.C1;
     }
     const half_t* ptr = (hpix[j] >= 0) ? src + (size_t)hpix[j] * Csrc + cc + hchunk[j] * 8 : zeros;
-    char* dst = reinterpret_cast<char*>(Xh + xstage * HALO_LDS_ROWS * BK) + p * 1024;
+    char* dst = reinterpret_cast<char*>(Xh + xstage * HALO_LDS_ROWS * BK) + (p < HALO_PIECES ? p : HALO_PIECES - 1) * 1024;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ptr,
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   };
@@ -729,20 +768,40 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(IgemmArgs a) {
     if (a.bias) const_b = a.bias[n_blk + tid];
     if (a.temb) const_t = a.temb[(size_t)b * a.temb_stride + n_blk + tid];
   }
+  // weight-ring issue cursor: the next (chunk, tap) to fetch and the ring stage it goes to
+  const int total_steps = (ch_end - ch_begin) * 9;
+  int iw_ch = ch_begin, iw_tap = 0, iw_step = 0;
+  auto issue_next_w = [&]() {
+    if (iw_step >= total_steps) return;                 // wave-uniform
+    issue_w(iw_ch, iw_tap, iw_step % D);
+    ++iw_step;
+    if (++iw_tap == 9) {
+      iw_tap = 0;
+      ++iw_ch;
+    }
+  };
   if (ch_begin < ch_end) {
 #pragma unroll
     for (int j = 0; j < HALO_PPW; ++j) issue_x_piece(j, ch_begin, 0);
-    issue_w(ch_begin, 0, 0);
+#pragma unroll
+    for (int p = 0; p < D - 1; ++p) issue_next_w();
   }
   int step = 0;
   for (int ch = ch_begin; ch < ch_end; ++ch) {
     const int xst = (ch - ch_begin) & 1;
     const bool next_chunk = ch + 1 < ch_end;
     const half_t* xs = Xh + xst * HALO_LDS_ROWS * BK;
+    // first chunk: fewer halo pieces precede the weight tiles than in steady state -> the conservative count;
+    // the last D-2 steps: no newer weight tiles behind the one waited for -> drain
+    const bool first_chunk = ch == ch_begin;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap, ++step) {
-      const int wst = step & 1;
-      __syncthreads();   // vmcnt(0) + barrier: this step's W tile (and halo pieces issued so far) have landed
+      const int wst = step % D;
+      // this step's weight tile (and, at tap 0, this chunk's halo) have landed for every wave; every wave is done
+      // reading the stage the next DMA overwrites
+      if (step + D - 2 >= total_steps) wait_vmcnt_barrier<0>();
+      else if (first_chunk) wait_vmcnt_barrier<(D - 2) * WR>();
+      else halo_wait<D, WR>(tap);
       const half_t* ws = Ws + wst * BN * BK + (wn * TN * 32 + frow) * BK;
       const int toff = (tap / 3) * HALO_W + (tap % 3);
       // keep the 72 (tap, k, tile) fragment addresses from being hoisted out of the chunk loop into
@@ -762,11 +821,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(IgemmArgs a) {
         for (int j = 0; j < TN; ++j) wf[kk][j] = *reinterpret_cast<const half8*>(ws + j * 32 * BK + ((kc ^ fsw) * 8));
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (tap < 8)
-        issue_w(ch, tap + 1, wst ^ 1);
-      else if (next_chunk)
-        issue_w(ch + 1, 0, wst ^ 1);
-      if (tap < HALO_PPW && next_chunk) issue_x_piece(tap, ch + 1, xst ^ 1);
+      issue_next_w();                                              // weight tile of step + D - 1
+      if (tap < HALO_PPW) issue_x_piece(tap, next_chunk ? ch + 1 : ch, xst ^ 1);   // always issued: uniform op count
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // fragments in registers before the MFMAs (and before
+      __builtin_amdgcn_sched_barrier(0);                           // the next barrier lets a DMA overwrite their stage)
 #pragma unroll
       for (int kk = 0; kk < BK / 16; ++kk)
 #pragma unroll
@@ -1223,18 +1281,32 @@ Plan choose_plan(const ConvDesc& d, const IgemmArgs& a) {
   return p;
 }
 
-template <int BN>
-void launch_halo(IgemmArgs a, int splitk, hipStream_t s) {
-  const int nch = a.Ctot / BK;
-  a.nk_total = nch;
-  a.nk_per_split = cdiv(nch, splitk);
-  a.splitk = cdiv(nch, a.nk_per_split);
-  const size_t lds = ((size_t)2 * HALO_LDS_ROWS * BK + (size_t)2 * BN * BK) * sizeof(half_t) + BN * sizeof(float);
-  auto k = conv3x3_halo_kernel<BN>;
+template <int BN, int D>
+void launch_halo_d(const IgemmArgs& a, hipStream_t s) {
+  const size_t lds = halo_lds_bytes(BN, D);
+  static_assert(halo_lds_bytes(BN, D) <= 160 * 1024, "LDS");
+  auto k = conv3x3_halo_kernel<BN, D>;
   static DynLdsOnce once;   // per instantiation, per device
   once.set(k, lds);
   dim3 grid(a.B * a.tiles_x * a.tiles_y * cdiv(a.N, BN), a.splitk);
   hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+}
+
+// staging (the table's ring code): 0 = 2 weight stages (two workgroups per CU), 2 / 3 = 3 / 4 stages,
+// 4 / 5 = 6 / 8 stages (BN = 64 only: 8-KB stages); deeper rings keep more weight bytes in flight per CU
+template <int BN>
+void launch_halo(IgemmArgs a, int splitk, int staging, hipStream_t s) {
+  const int nch = a.Ctot / BK;
+  a.nk_total = nch;
+  a.nk_per_split = cdiv(nch, splitk);
+  a.splitk = cdiv(nch, a.nk_per_split);
+  if constexpr (BN == 64) {
+    if (staging >= 5) { launch_halo_d<BN, 8>(a, s); return; }
+    if (staging >= 4) { launch_halo_d<BN, 6>(a, s); return; }
+  }
+  if (staging >= 3) { launch_halo_d<BN, 4>(a, s); return; }
+  if (staging >= 2) { launch_halo_d<BN, 3>(a, s); return; }
+  launch_halo_d<BN, 2>(a, s);
 }
 
 template <int BM, int BN, int WGM, int WGN, bool TRANS, bool GLDS, int NST, bool LNF = false>
@@ -1369,8 +1441,8 @@ void launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
     fprintf(stderr, "[sd conv] k%d s%d up%d C0=%d C1=%d M=%d N=%d K=%d mode=%d tile=%d splitk=%d\n", a.ksize, a.stride, a.up,
             a.C0, a.C1, a.M, a.N, a.K, d.out_mode, p.tile, a.splitk);
   if (halo) {
-    if (p.tile == 5) launch_halo<128>(a, a.splitk, s);
-    else launch_halo<64>(a, a.splitk, s);
+    if (p.tile == 5) launch_halo<128>(a, a.splitk, st, s);
+    else launch_halo<64>(a, a.splitk, st, s);
   } else if (d.debug) {   // ablation builds exist for two tiles only (tools/prof_conv.py)
     const bool ok = p.tile == 1 ? launch_debug_mode<128, 128>(a, d.debug, s) : launch_debug_mode<64, 64>(a, d.debug, s);
     SD_REQUIRE(ok && !trans, kInvalidArgument, "no ablation kernel for debug mode %d", d.debug);

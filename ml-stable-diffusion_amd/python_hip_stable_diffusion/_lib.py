@@ -91,6 +91,8 @@ SYMBOLS = [
     ("sd_op_geglu", _I, [_P, _P, _FP, _P, _I, _I, _I, _I, _FP]),
     ("sd_op_timestep_embedding", _I, [_FP, _FP, _I, _I, _I, _F]),
     ("sd_numpy_randn", _I, [C.c_uint32, C.POINTER(C.c_double), C.c_size_t]),
+    ("sd_torch_randn", _I, [C.c_uint32, C.POINTER(C.c_double), C.c_size_t]),
+    ("sd_philox_randn", _I, [C.c_uint64, C.c_uint32, C.POINTER(C.c_double), C.c_size_t]),
     ("sd_selftest_mfma", _I, []),
 ]
 
@@ -222,4 +224,18 @@ def timestep_embedding(t, dim, flip_sin_to_cos=True, freq_shift=0.0):
 def numpy_randn(seed, n):
     out = np.empty(n, np.float64)
     check(lib().sd_numpy_randn(seed, out.ctypes.data_as(C.POINTER(C.c_double)), n))
+    return out
+
+
+def torch_randn(seed, n):
+    """torch.manual_seed(seed); torch.randn(n) on the CPU (TorchRandomSource.swift)."""
+    out = np.empty(n, np.float64)
+    check(lib().sd_torch_randn(seed, out.ctypes.data_as(C.POINTER(C.c_double)), n))
+    return out
+
+
+def philox_randn(seed, n, offset=0):
+    """torch.randn on a CUDA device (NvRandomSource.swift); offset = arrays drawn before this one."""
+    out = np.empty(n, np.float64)
+    check(lib().sd_philox_randn(seed, offset, out.ctypes.data_as(C.POINTER(C.c_double)), n))
     return out

@@ -145,14 +145,23 @@ class HipStableDiffusionPipeline:
         return image.transpose((0, 2, 3, 1))
 
     # ---- pipeline.py:322-344 ---------------------------------------------------------------
-    def prepare_latents(self, batch_size, num_channels_latents, height, width, latents=None, seed=None):
+    def prepare_latents(self, batch_size, num_channels_latents, height, width, latents=None, seed=None, rng="numpy"):
+        """``rng``: which of the reference's seed-exact sources draws the latents (RandomSource.swift, CLI --rng):
+        "numpy" (np.random.seed + randn, the Python pipeline's), "torch" (torch CPU generator), "nvidia" (torch CUDA
+        generator, Philox)."""
         shape = (batch_size, num_channels_latents, self.height // 8, self.width // 8)
         if latents is None:
             n = int(np.prod(shape))
             if seed is None:
                 latents = np.random.randn(*shape).astype(np.float16)           # reference behaviour (:331)
-            else:
+            elif rng == "numpy":
                 latents = _lib.numpy_randn(int(seed), n).reshape(shape).astype(np.float16)
+            elif rng == "torch":
+                latents = _lib.torch_randn(int(seed), n).reshape(shape).astype(np.float16)
+            elif rng == "nvidia":
+                latents = _lib.philox_randn(int(seed), n).reshape(shape).astype(np.float16)
+            else:
+                raise ValueError(f"rng must be 'numpy', 'torch' or 'nvidia', got {rng!r}")
         elif latents.shape != shape:
             raise ValueError(f"Unexpected latents shape, got {latents.shape}, expected {shape}")
         return latents * np.float32(self.scheduler.init_noise_sigma)
@@ -213,7 +222,7 @@ class HipStableDiffusionPipeline:
     def __call__(self, prompt, height=512, width=512, num_inference_steps=50, guidance_scale=7.5, negative_prompt=None,
                  num_images_per_prompt=1, eta=0.0, latents=None, output_type="np", return_dict=True, callback=None,
                  callback_steps=1, controlnet_cond=None, original_size=None, crops_coords_top_left=(0, 0),
-                 target_size=None, unet_batch_one=False, seed=None, device_loop=True, **kwargs):
+                 target_size=None, unet_batch_one=False, seed=None, device_loop=True, rng="numpy", **kwargs):
         self.check_inputs(prompt, height, width, callback_steps)
         height, width = self.height, self.width
         original_size = original_size or (height, width)
@@ -243,7 +252,7 @@ class HipStableDiffusionPipeline:
 
         self.scheduler.set_timesteps(num_inference_steps)
         timesteps = self.scheduler.timesteps
-        latents = self.prepare_latents(n_img, self.unet.in_channels, height, width, latents, seed)
+        latents = self.prepare_latents(n_img, self.unet.in_channels, height, width, latents, seed, rng)
         if controlnet_cond:
             controlnet_cond = self.prepare_control_cond(controlnet_cond, do_cfg, batch_size, num_images_per_prompt)
         extra_step_kwargs = self.prepare_extra_step_kwargs(eta)

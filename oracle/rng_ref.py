@@ -70,3 +70,81 @@ class NumpyLegacyRandom:
 GOLDEN_SEED = 12345
 GOLDEN_COUNT = 10000
 GOLDEN_LAST5 = [-0.86285345, 2.15229409, -0.00670556, -1.21472309, 0.65498866]
+
+
+class TorchCpuRandom(NumpyLegacyRandom):
+    """``torch.manual_seed(seed); torch.randn(n)`` on the CPU, restated from
+    swift/StableDiffusion/pipeline/TorchRandomSource.swift:116-150 (which restates ATen's
+    DistributionTemplates.h): n >= 16 fills an array of 24-bit uniforms, then Box-Muller over blocks of 16
+    (first 8 = u1 -> radius, last 8 = u2 -> angle), the ragged tail recomputed from fresh 53-bit doubles over the
+    LAST 16; n < 16 is scalar Box-Muller on 53-bit doubles with the sine cached.  Double arithmetic like the
+    Swift code (torch itself evaluates the float32 path with vectorised float math, so it agrees to ~1e-6, not
+    bit for bit - tests/test_oracle.py pins that)."""
+
+    def next_u64(self):
+        hi = self._next_u32()
+        lo = self._next_u32()
+        return (hi << 32) | lo
+
+    def next_double53(self):
+        return (self.next_u64() & 9007199254740991) * (1.0 / 9007199254740992.0)
+
+    def next_float24(self):
+        return (self._next_u32() & 16777215) * (1.0 / 16777216.0)
+
+    def _gauss(self):
+        if self.cached is not None:
+            g, self.cached = self.cached, None
+            return g
+        u1 = self.next_double53()
+        u2 = 1 - self.next_double53()
+        radius = math.sqrt(-2.0 * math.log(u2))
+        theta = 2.0 * math.pi * u1
+        self.cached = radius * math.sin(theta)
+        return radius * math.cos(theta)
+
+    def randn(self, n):
+        if n < 16:
+            return [self._gauss() for _ in range(n)]
+        data = [self.next_float24() for _ in range(n)]
+
+        def fill16(i):
+            for j in range(8):
+                u1 = 1 - data[i + j]
+                u2 = data[i + j + 8]
+                radius = math.sqrt(-2.0 * math.log(u1))
+                theta = 2.0 * math.pi * u2
+                data[i + j] = radius * math.cos(theta)
+                data[i + j + 8] = radius * math.sin(theta)
+
+        for i in range(0, n - 15, 16):
+            fill16(i)
+        if n % 16:
+            # torch redraws the last 16 as 24-bit floats; the Swift code uses 53-bit doubles here (:135-137), which
+            # torch.randn(float32) does not - the two only differ off the path (latent counts are multiples of 16)
+            for i in range(n - 16, n):
+                data[i] = self.next_float24()
+            fill16(n - 16)
+        return data
+
+
+def philox_randn(seed, offset, n):
+    """torch.randn on a CUDA device as swift/StableDiffusion/pipeline/NvRandomSource.swift:25-80 restates it:
+    Philox4x32-10 with counter (offset, 0, i, 0) and key (seed lo, seed hi) per element i, Box-Muller on the first
+    two output words.  ``offset`` counts previous calls (the Swift struct increments it per array).  No golden
+    exists in the reference and no CUDA device here: PARITY UNPINNED."""
+    m0, m1, w0, w1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+    out = []
+    for i in range(n):
+        c = [offset & M32, 0, i & M32, 0]
+        k = [seed & M32, (seed >> 32) & M32]
+        for r in range(10):
+            v1 = c[0] * m0
+            v2 = c[2] * m1
+            c = [((v2 >> 32) ^ c[1] ^ k[0]) & M32, v2 & M32, ((v1 >> 32) ^ c[3] ^ k[1]) & M32, v1 & M32]
+            if r < 9:
+                k = [(k[0] + w0) & M32, (k[1] + w1) & M32]
+        u = c[0] / 4294967296.0 + (1.0 / 8589934592.0)
+        v = c[1] * (math.pi / 2147483648.0) + (math.pi / 4294967296.0)
+        out.append(math.sqrt(-2.0 * math.log(u)) * math.sin(v))
+    return out

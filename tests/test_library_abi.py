@@ -90,3 +90,21 @@ def test_argument_validation_happens_before_any_device_work():
                        np.zeros((1, 64, 1, 8), np.float16), 1, 64)
     with pytest.raises(ValueError):
         hip_model.HipModel("stabilityai/stable-diffusion-2-1-base", weights={}, attention_implementation="FAST")
+
+
+def test_torch_cpu_and_philox_streams_match_their_restatements_and_torch(sdlib):
+    """TorchRandomSource.swift:116-150 / NvRandomSource.swift:25-80.  The reference has no golden for either; the CPU
+    stream is additionally checked against torch itself (float32 vectorised math there: agreement ~1e-6, not bits)."""
+    import torch
+    for seed, n in ((93, 4 * 64 * 64), (7, 16), (7, 5), (12345, 1000 + 7)):
+        got = _lib.torch_randn(seed, n)
+        want = np.array(rng_ref.TorchCpuRandom(seed).randn(n))
+        assert np.array_equal(got, want), (seed, n)
+        torch.manual_seed(seed)
+        t = torch.randn(n).numpy()
+        np.testing.assert_allclose(got, t, atol=5e-6, rtol=0)
+    for seed, off, n in ((93, 0, 64), ((1 << 40) + 5, 3, 33)):
+        got = _lib.philox_randn(seed, n, offset=off)
+        np.testing.assert_allclose(got, np.array(rng_ref.philox_randn(seed, off, n)), atol=1e-12, rtol=0)
+    g = _lib.philox_randn(93, 100000)
+    assert abs(g.mean()) < 0.02 and abs(g.std() - 1.0) < 0.02

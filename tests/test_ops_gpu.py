@@ -217,7 +217,7 @@ def test_conv2d_every_tile_and_splitk(tile, splitk):
     close(gen, conv_ref(x, w, bias, res, 1, False), "generic conv")
 
 
-@pytest.mark.parametrize("tile", [5, 6])
+@pytest.mark.parametrize("tile", [5, 6, 25, 26, 35, 36, 46, 56])      # tile // 10 = weight-ring code (3 / 4 / 6 / 8 stages)
 @pytest.mark.parametrize("splitk", [0, 1, 2, 3])
 @pytest.mark.parametrize("shape", [(2, 128, 16, 16, 128), (1, 64, 24, 40, 96), (2, 320, 32, 32, 320), (1, 192, 9, 17, 68)],
                          ids=lambda s: "x".join(map(str, s)))

@@ -30,7 +30,8 @@ total = sum(o[2] for o in ops)
 print(f"graph replay {graph_ms:.3f} ms; {len(ops)} ops, eager per-op sum {total:.3f} ms")
 fam = defaultdict(lambda: [0, 0.0, 0.0])
 for lbl, fl, ms in ops:
-    key = re.sub(r" (down_blocks|up_blocks|mid_block|conv_in|conv_out|time_embedding|conv_norm_out)\S*$", "", lbl)
+    key = re.sub(r" #[\d,]+$", "", lbl)
+    key = re.sub(r" (down_blocks|up_blocks|mid_block|conv_in|conv_out|time_embedding|conv_norm_out)\S*$", "", key)
     f = fam[key]
     f[0] += 1
     f[1] += ms
