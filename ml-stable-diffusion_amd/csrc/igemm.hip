@@ -89,8 +89,10 @@ __device__ __forceinline__ float xor32_sum(float v) {
 // The DMA writes lane-linear 1-KiB pieces (8 rows x 128 B), so the bank swizzle lives on the
 // per-lane SOURCE address: physical 16-B chunk p of row r holds logical chunk p ^ ((r >> 1) & 7),
 // and fragment reads apply the same XOR (conflict-free ds_read_b128, cdna guide rule 21).
-template <int BM, int BN, int WGM, int WGN, bool TRANS_OUT, bool GLDS, int NST, int DBG = 0, bool LNF = false>
+template <int BM, int BN, int WGM, int WGN, bool TRANS_OUT, bool GLDS, int NST, int DBG = 0, bool LNF = false,
+          bool PIPE = false>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
+  static_assert(!PIPE || (GLDS && NST >= 3 && DBG == 0), "the software-pipelined loop is a variant of the LDS-DMA ring");
   static_assert(WGM * WGN == 4, "4 waves");
   static_assert(!(LNF && TRANS_OUT), "LayerNorm fold uses the in-lane row layout of the non-transposed tile");
   constexpr int TM = BM / WGM / 32;   // 32x32 MFMA tiles per wave along m
@@ -354,7 +356,101 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   }
 
   if (prof) prof_t[1] = clock64();
-  if constexpr (GLDS && NST >= 3) {
+  if constexpr (PIPE) {
+    // Software-pipelined ring: while the 16 MFMAs of tile kt run from one fragment register set, the 16 ds_read_b128 of
+    // tile kt+1 fill the other set and the DMA of tile kt+NST-1 is issued - LDS reads, DMA issue and MFMAs of ONE wave
+    // overlap instead of alternating (the plain ring leaves that overlap to a second workgroup on the CU).  Tile kt+1
+    // must therefore have landed when step kt starts: one tile less DMA lead than the plain ring of the same depth.
+    constexpr int PER_TILE = XR + WR;
+    constexpr int DEPTH = NST - 3;      // tiles newer than kt+1 that may still be in flight at the wait of step kt
+    static_assert(DEPTH * PER_TILE <= 63 && (NST - 2) * PER_TILE <= 63, "vmcnt range");
+    half8 xg[BK / 16][TM] = {}, wg[BK / 16][TN] = {};   // the second fragment set
+    const int nk = kt_end - kt_begin;
+    auto wait_tiles = [&](int fly) {    // at most `fly` newer tiles outstanding, then the workgroup barrier
+      if (NST - 2 >= 4 && fly >= 4) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NST - 2 >= 4 ? 4 : 0) * PER_TILE) : "memory");
+      else if (NST - 2 >= 3 && fly == 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NST - 2 >= 3 ? 3 : 0) * PER_TILE) : "memory");
+      else if (NST - 2 >= 2 && fly == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NST - 2 >= 2 ? 2 : 0) * PER_TILE) : "memory");
+      else if (fly == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PER_TILE) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    auto frag_ptrs = [&](int buf, const half_t*& xs, const half_t*& ws) {
+      xs = Xs + buf * BM * ROW + (wm * TM * 32 + frow) * ROW;
+      ws = Ws + buf * BN * ROW + (wn * TN * 32 + frow) * ROW;
+    };
+#pragma unroll
+    for (int p = 0; p < NST - 1; ++p)
+      if (p < nk) load_tile(p);
+    {
+      const int newer = nk - 1 < NST - 2 ? nk - 1 : NST - 2;
+      wait_tiles(newer > 4 ? 4 : newer);              // tile 0 has landed (an under-estimate only waits longer)
+      const half_t *xs, *ws;
+      frag_ptrs(0, xs, ws);
+#pragma unroll
+      for (int kk = 0; kk < BK / 16; ++kk) {
+        const int koff = ((kk * 2 + (lane >> 5)) ^ fsw) * 8;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) xf[kk][i] = *reinterpret_cast<const half8*>(xs + i * 32 * ROW + koff);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wf[kk][j] = *reinterpret_cast<const half8*>(ws + j * 32 * ROW + koff);
+      }
+    }
+    // one step: compute tile `rel` from (cx, cw) while (nx, nw) receive tile rel + 1
+    auto step = [&](int rel, half8 (&cx)[BK / 16][TM], half8 (&cw)[BK / 16][TN], half8 (&nx)[BK / 16][TM],
+                    half8 (&nw)[BK / 16][TN]) {
+      const bool has_next = rel + 1 < nk;
+      const half_t *xs = Xs, *ws = Ws;
+      if (has_next) {
+        const int newer = nk - 2 - rel < DEPTH ? nk - 2 - rel : DEPTH;
+        wait_tiles(newer);                            // tile rel + 1 has landed for every wave; tile rel - 1 is consumed
+        frag_ptrs((rel + 1) % NST, xs, ws);
+      }
+      if (rel + NST - 1 < nk) load_tile((rel + NST - 1) % NST);
+      auto mfma_slice = [&](int kk) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            if constexpr (TRANS_OUT)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cx[kk][i], cw[kk][j], acc[i][j], 0, 0, 0);
+            else
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cw[kk][j], cx[kk][i], acc[i][j], 0, 0, 0);
+          }
+        if constexpr (LNF) {
+          const half2v one2 = {(half_t)1.f, (half_t)1.f};
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const half2v p2 = {cx[kk][i][2 * e], cx[kk][i][2 * e + 1]};
+              ln_s2[i] = __builtin_amdgcn_fdot2(p2, p2, ln_s2[i], false);
+              ln_s1[i] = __builtin_amdgcn_fdot2(p2, one2, ln_s1[i], false);
+            }
+        }
+      };
+      if (has_next) {
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+          const int koff = ((kk * 2 + (lane >> 5)) ^ fsw) * 8;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) nx[kk][i] = *reinterpret_cast<const half8*>(xs + i * 32 * ROW + koff);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) nw[kk][j] = *reinterpret_cast<const half8*>(ws + j * 32 * ROW + koff);
+          mfma_slice(kk);
+          // keep the issue order "reads of the next tile, then this k-slice's MFMAs" (the scheduler would otherwise
+          // cluster all reads or sink them behind the MFMAs)
+          __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+        }
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) mfma_slice(kk);
+      }
+    };
+    for (int rel = 0; rel < nk; rel += 2) {
+      step(rel, xf, wf, xg, wg);
+      if (rel + 1 < nk) step(rel + 1, xg, wg, xf, wf);
+    }
+  } else if constexpr (GLDS && NST >= 3) {
     // NST-stage ring: the DMA of tile kt+NST-1 is issued while tile kt is computed and tiles
     // kt+1 .. kt+NST-2 are still in flight (weight-streaming layers need the bytes in flight: at the
     // 8x8 / 16x16 levels every K step of a two-stage loop is one exposed HBM round trip).
@@ -1309,12 +1405,12 @@ void launch_halo(IgemmArgs a, int splitk, int staging, hipStream_t s) {
   launch_halo_d<BN, 2>(a, s);
 }
 
-template <int BM, int BN, int WGM, int WGN, bool TRANS, bool GLDS, int NST, bool LNF = false>
+template <int BM, int BN, int WGM, int WGN, bool TRANS, bool GLDS, int NST, bool LNF = false, bool PIPE = false>
 void launch_variant(const IgemmArgs& a, hipStream_t s) {
   const size_t lds = (size_t)NST * (BM + BN) * (GLDS ? BK : LDS_ROW) * sizeof(half_t) + 2 * BN * sizeof(float);
   static_assert((size_t)BN * (BM + 8) <= (size_t)NST * (BM + BN) * (GLDS ? BK : LDS_ROW), "transposed staging fits");
   dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), a.splitk);
-  auto k = igemm_kernel<BM, BN, WGM, WGN, TRANS, GLDS, NST, 0, LNF>;
+  auto k = igemm_kernel<BM, BN, WGM, WGN, TRANS, GLDS, NST, 0, LNF, PIPE>;
   static DynLdsOnce once;   // per instantiation, per device
   once.set(k, lds);
   hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
@@ -1342,7 +1438,8 @@ bool launch_debug_mode(const IgemmArgs& a, int dbg, hipStream_t s) {
 }
 
 // staging: 0 = LDS-DMA 2 stages, 1 = register staging (A/B reference), 2 / 3 / 4 / 5 = LDS-DMA ring of
-// 3 / 4 / 6 / 8 stages (a ring that would not fit the 160 KB of LDS falls back to the deepest one that does)
+// 3 / 4 / 6 / 8 stages (a ring that would not fit the 160 KB of LDS falls back to the deepest one that does),
+// 6 / 7 = software-pipelined loop over a ring of 4 / 6 stages
 constexpr size_t kLdsBudget = 160 * 1024;
 template <int BM, int BN>
 constexpr bool ring_fits(int nst) {
@@ -1350,6 +1447,11 @@ constexpr bool ring_fits(int nst) {
 }
 template <int BM, int BN, int WGM, int WGN, bool LNF>
 void launch_ring(const IgemmArgs& a, int staging, hipStream_t s) {
+  // 6 / 7: software-pipelined loop (fragment double buffering) over a ring of 4 / 6 stages
+  if (staging == 7) {
+    if constexpr (ring_fits<BM, BN>(6)) { launch_variant<BM, BN, WGM, WGN, false, true, 6, LNF, true>(a, s); return; }
+  }
+  if (staging >= 6) { launch_variant<BM, BN, WGM, WGN, false, true, 4, LNF, true>(a, s); return; }
   if (staging >= 5) {
     if constexpr (ring_fits<BM, BN>(8)) { launch_variant<BM, BN, WGM, WGN, false, true, 8, LNF>(a, s); return; }
   }

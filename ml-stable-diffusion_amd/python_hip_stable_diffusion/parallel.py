@@ -52,3 +52,39 @@ def gather_arrays(arr, dist, local_rank=0):
     outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(outs, t)
     return torch.cat(outs, dim=0).cpu().numpy()
+
+
+def cfg_batch(ehs_pairs):
+    """(P, 2, C, 1, L) per-prompt [uncond, cond] embeddings -> the UNet batch (2P, C, 1, L) in the reference's
+    order [uncond_0..uncond_{P-1}, cond_0..cond_{P-1}] (pipeline.py:245, batched like the Swift imageCount loop)."""
+    ehs_pairs = np.asarray(ehs_pairs)
+    return np.concatenate([ehs_pairs[:, 0], ehs_pairs[:, 1]])
+
+
+def run_sharded(loop_fn, ehs_pairs, latents, dist=None, local_rank=0):
+    """BASELINE config 3 in one call: rank 0 holds the text embeddings (P, 2, C, 1, L) and the initial latents
+    (P, 4, h, w) of ALL prompts; they are broadcast, each rank runs ``loop_fn(latents_of_its_prompts,
+    cfg_batch(embeddings_of_its_prompts)) -> final latents`` on its contiguous shard (one device-resident loop per
+    rank, no data-path collective), and the final latents are all-gathered in prompt order.  Every rank must own the
+    same number of prompts (static UNet batch per handle, pipeline.py:112-114)."""
+    world = 1 if dist is None else dist.get_world_size()
+    rank = 0 if dist is None else dist.get_rank()
+    if dist is not None:
+        import torch
+        meta = torch.zeros(8, dtype=torch.int64)
+        if rank == 0:
+            e, l = np.asarray(ehs_pairs), np.asarray(latents)
+            meta = torch.tensor(list(e.shape[:1] + e.shape[2:]) + list(l.shape[1:]) + [0], dtype=torch.int64)[:8]
+        meta = meta.to(_device(dist, local_rank))
+        dist.broadcast(meta, src=0)
+        p, c, one, length, lc, lh, lw = [int(v) for v in meta.tolist()[:7]]
+        ehs_pairs = broadcast_array(ehs_pairs if rank == 0 else None, (p, 2, c, one, length), np.float16, dist, local_rank)
+        latents = broadcast_array(latents if rank == 0 else None, (p, lc, lh, lw), np.float32, dist, local_rank)
+    else:
+        ehs_pairs, latents = np.asarray(ehs_pairs, np.float16), np.asarray(latents, np.float32)
+    n = ehs_pairs.shape[0]
+    if n % world:
+        raise ValueError(f"{n} prompts do not split evenly over {world} ranks (static UNet batch per rank)")
+    mine = shard_prompts(n, world)[rank]
+    out = loop_fn(latents[mine], cfg_batch(ehs_pairs[mine]))
+    return gather_arrays(np.asarray(out, np.float32), dist, local_rank)

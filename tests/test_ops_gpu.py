@@ -203,7 +203,7 @@ def test_conv2d_matches_torch(case):
     close(out, conv_ref(x, w, bias, res, stride, ups), f"conv {case}")
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 11, 12, 13, 14, 21, 22, 23, 24, 31, 32, 33, 34, 41, 42, 43, 44, 51, 52, 53, 54])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 11, 12, 13, 14, 21, 22, 23, 24, 31, 32, 33, 34, 41, 42, 43, 44, 51, 52, 53, 54, 61, 62, 63, 64, 71, 72, 73, 74])
 @pytest.mark.parametrize("splitk", [1, 2, 5])
 def test_conv2d_every_tile_and_splitk(tile, splitk):
     rs = np.random.RandomState(tile * 10 + splitk)

@@ -60,6 +60,67 @@ def test_broadcast_shard_gather_world_size_two():
         assert np.array_equal(np.array(got_all, np.float32), want), rank     # rank order == prompt order
 
 
+def _stub_loop(latents, ehs):
+    """CPU stand-in for HipModel.denoise_loop: any function that treats prompts independently, reading the
+    [uncond..., cond...] batch layout the way the UNet does."""
+    n = latents.shape[0]
+    assert ehs.shape[0] == 2 * n
+    u, c = ehs[:n].astype(np.float32), ehs[n:].astype(np.float32)
+    g = (u + 7.5 * (c - u)).mean(axis=(1, 2, 3))
+    return latents * 0.5 + g[:, None, None, None]
+
+
+def _config3_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rs = np.random.RandomState(0)
+        ehs = rs.randn(4, 2, 16, 1, 77).astype(np.float16) if rank == 0 else None
+        lat = rs.randn(4, 4, 8, 8).astype(np.float32) if rank == 0 else None
+        seen = []
+
+        def loop(latents, e):
+            seen.append((latents.shape, e.shape))
+            return _stub_loop(latents, e)
+
+        out = parallel.run_sharded(loop, ehs, lat, dist)
+        q.put((rank, seen, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config3_two_prompts_per_rank_world_size_two():
+    """BASELINE config 3's structure (16 prompts over 8 GPUs = 2 per rank, UNet batch 4) at world size 2 on gloo:
+    broadcast, contiguous sharding, [uncond..., cond...] batch per rank, all-gather in prompt order."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_config3_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rs = np.random.RandomState(0)
+    ehs = rs.randn(4, 2, 16, 1, 77).astype(np.float16)
+    lat = rs.randn(4, 4, 8, 8).astype(np.float32)
+    want = np.concatenate([_stub_loop(lat[i:i + 1], parallel.cfg_batch(ehs[i:i + 1])) for i in range(4)])
+    for rank, seen, out in results:
+        assert seen == [((2, 4, 8, 8), (4, 16, 1, 77))]            # two prompts per rank -> UNet batch 4
+        np.testing.assert_allclose(out, want, rtol=1e-6)
+    single = parallel.run_sharded(_stub_loop, ehs, lat, None)
+    np.testing.assert_allclose(single, want, rtol=1e-6)
+    with pytest.raises(ValueError):
+        parallel.run_sharded(_stub_loop, ehs[:3], lat[:3], type("D", (), {"get_world_size": lambda s: 2, "get_rank": lambda s: 0,
+                                                                         "get_backend": lambda s: "gloo",
+                                                                         "broadcast": lambda s, t, src=0: None})())
+
+
 def test_single_process_degenerate_case():
     a = np.ones((2, 3), np.float32)
     assert np.array_equal(parallel.broadcast_array(a, (2, 3), np.float32, None), a)

@@ -313,3 +313,29 @@ def test_denoise_loop_validates_its_inputs_like_the_boundary():
     out, _ = model.denoise_loop(lat0, ts, coef, 7.5, history=hist, encoder_hidden_states=ehs)
     assert np.isfinite(out).all()
     model.close()
+
+
+def test_config3_sharded_run_with_the_real_device_loop():
+    """parallel.run_sharded (BASELINE config 3's driver: broadcast, shard, one device-resident loop per rank,
+    all-gather) around the real HIP loop at world size 1: two prompts per rank, UNet batch 4, SPLIT_EINSUM_V2.
+    The world-size-2 plumbing is covered on gloo by tests/test_parallel.py."""
+    from python_hip_stable_diffusion import parallel
+    cfg, sd, m4 = _mini(batch=4, impl="SPLIT_EINSUM_V2")
+    _, _, m2 = _mini(batch=2, impl="SPLIT_EINSUM_V2")
+    hw = cfg["sample_size"]
+    rs = np.random.RandomState(11)
+    ehs = rs.randn(2, 2, cfg["cross_attention_dim"], 1, 77).astype(np.float16)
+    lat = rs.randn(2, 4, hw, hw).astype(np.float32)
+    sch = schedulers.DDIMScheduler()
+    sch.set_timesteps(4)
+    ts, coef, hist = sch.device_tables()
+
+    def loop(model):
+        return lambda l, e: model.denoise_loop(l, ts, coef, 7.5, history=hist, encoder_hidden_states=e)[0]
+
+    both = parallel.run_sharded(loop(m4), ehs, lat, None)
+    assert both.shape == (2, 4, hw, hw)
+    for i in range(2):
+        one = parallel.run_sharded(loop(m2), ehs[i:i + 1], lat[i:i + 1], None)
+        assert psnr.compute_psnr(both[i:i + 1], one) >= 60.0
+    m2.close(), m4.close()

@@ -44,7 +44,7 @@ def set_candidate(t, st, sk):
 
 set_candidate(0, 0, 0)
 base = measure(7)
-cands = [(t, st, sk) for t in (1, 2, 3, 4) for st in (0, 2, 3, 4, 5) for sk in (1, 2, 4, 8, 16)]
+cands = [(t, st, sk) for t in (1, 2, 3, 4) for st in (0, 2, 3, 4, 6, 7) for sk in (1, 2, 4, 8, 16)]
 cands += [(5, st, sk) for st in (0, 2, 3) for sk in (1, 2, 4, 8, 16)]          # LDS-halo 3x3 kernel, BN = 128
 cands += [(6, st, sk) for st in (0, 2, 3, 4, 5) for sk in (1, 2, 4, 8, 16)]    # ... BN = 64
 results = {}
