@@ -189,6 +189,13 @@ int sd_controlnet_set_cond(sd_unet* controlnet, const void* controlnet_cond, int
  * ------------------------------------------------------------------------------------------ */
 int sd_vae_decoder_create(const sd_unet_config* cfg, const sd_weights* w, int device, sd_unet** out);
 int sd_vae_decode(sd_unet* vae, const void* z, sd_dtype z_dtype, float* image, int flags);
+/* VAE encoder: latent = quant_conv(encoder(x)) (torch2coreml.py:739-749 `vae_encoder`, output "latent";
+ * Encoder.swift:48-90 samples mean + std * noise from it and multiplies by the scale factor).  Config reuses
+ * sd_unet_config: block_out_channels = the VAE's (128,256,512,512), layers_per_block = 2, in_channels = 3,
+ * out_channels = 2 * latent channels (8), height/width = IMAGE size.  x: (B, 3, H, W) f16 or f32 in [-1, 1];
+ * moments: (B, 8, H/8, W/8) f32 = [mean | logvar]. */
+int sd_vae_encoder_create(const sd_unet_config* cfg, const sd_weights* w, int device, sd_unet** out);
+int sd_vae_encode(sd_unet* vae, const void* x, sd_dtype x_dtype, float* moments, int flags);
 
 /* ------------------------------------------------------------------------------------------
  * CLIP text encoder(s): transformers' CLIPTextModel / CLIPTextModelWithProjection as the reference

@@ -251,6 +251,24 @@ int sd_vae_decoder_create(const sd_unet_config* cfg, const sd_weights* w, int de
     *out = h.release();
   });
 }
+int sd_vae_encoder_create(const sd_unet_config* cfg, const sd_weights* w, int device, sd_unet** out) {
+  return guarded([&] {
+    SD_REQUIRE(cfg && w && out, kInvalidArgument, "NULL argument");
+    require_device();
+    sd_unet_config c = *cfg;
+    c.is_vae_decoder = 2;
+    c.is_controlnet = 0;
+    auto h = std::make_unique<sd_unet>();
+    h->impl = std::make_unique<UNet>(c, w->store, device);
+    *out = h.release();
+  });
+}
+int sd_vae_encode(sd_unet* vae, const void* x, sd_dtype x_dtype, float* moments, int flags) {
+  return guarded([&] {
+    SD_REQUIRE(vae && x && moments, kInvalidArgument, "NULL argument");
+    vae->impl->vae_encode(x, x_dtype == SD_F32, moments, flags);
+  });
+}
 int sd_vae_decode(sd_unet* vae, const void* z, sd_dtype z_dtype, float* image, int flags) {
   return guarded([&] {
     SD_REQUIRE(vae && z && image, kInvalidArgument, "NULL argument");

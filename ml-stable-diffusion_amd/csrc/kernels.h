@@ -29,6 +29,7 @@ struct ConvDesc {
   int B = 1, Hi = 1, Wi = 1;    // source spatial size (before nearest x2 upsampling)
   int Ho = 1, Wo = 1;           // output spatial size
   int ksize = 1, stride = 1, up = 1;
+  int pad = -1;                 // -1: ksize / 2 on every side; 0 with stride 2 = the VAE encoder's (0,1,0,1) padding
   int N = 0;
   int out_mode = kOutHalf;
   int ldT = 0;                  // kOutHalfT: padded token stride

@@ -42,7 +42,9 @@ UNet::UNet(const sd_unet_config& cfg, const WeightStore& ws, int device) : cfg_(
     SD_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
     SD_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
   }
-  if (cfg_.is_vae_decoder)
+  if (cfg_.is_vae_decoder == 2)
+    build_vae_encoder();
+  else if (cfg_.is_vae_decoder)
     build_vae_decoder();
   else
     build_unet();
@@ -122,12 +124,12 @@ float* UNet::upload_vec(const std::string& name, int n, bool geglu) {
 
 Tensor UNet::conv(std::vector<Op>& ops, const std::string& name, const Tensor& x, const Tensor* x2, int cout, int k,
                   int stride, int up, bool bias, const float* temb, const half_t* res, int out_mode, int ldT,
-                  bool silu_out) {
+                  bool silu_out, int pad) {
   const int cin = x.C + (x2 ? x2->C : 0);
   const bool geglu = out_mode == kOutGeglu;
   const half_t* w = upload_conv_weight(name, cout, cin, k, geglu);
   const float* b = bias ? upload_vec(name + ".bias", cout, geglu) : nullptr;
-  return conv_w(ops, name, w, b, x, x2, cout, k, stride, up, temb, res, out_mode, ldT, silu_out);
+  return conv_w(ops, name, w, b, x, x2, cout, k, stride, up, temb, res, out_mode, ldT, silu_out, nullptr, pad);
 }
 
 // Several bias-free 1x1 projections of the same input as ONE GEMM: weights stacked along Cout
@@ -205,7 +207,7 @@ bool UNet::can_fold_ln(const Tensor& x, int cout, bool geglu) const {
 
 Tensor UNet::conv_w(std::vector<Op>& ops, const std::string& name, const half_t* w, const float* bias, const Tensor& x,
                     const Tensor* x2, int cout, int k, int stride, int up, const float* temb, const half_t* res,
-                    int out_mode, int ldT, bool silu_out, ConvExtra* ex) {
+                    int out_mode, int ldT, bool silu_out, ConvExtra* ex, int pad_override) {
   const bool geglu = out_mode == kOutGeglu;
   ConvDesc d;
   d.x0 = x.p;
@@ -224,8 +226,15 @@ Tensor UNet::conv_w(std::vector<Op>& ops, const std::string& name, const half_t*
   d.Hi = x.H;
   d.Wi = x.W;
   const int Hup = x.H * up, Wup = x.W * up, pad = k / 2;
-  d.Ho = (Hup + 2 * pad - k) / stride + 1;
-  d.Wo = (Wup + 2 * pad - k) / stride + 1;
+  if (pad_override >= 0) {   // diffusers Downsample2D(padding=0): F.pad(x, (0, 1, 0, 1)) then a pad-0 stride-2 conv
+    SD_REQUIRE(pad_override == 0 && stride == 2 && k == 3, kUnsupported, "%s: explicit padding %d", name.c_str(), pad_override);
+    d.pad = 0;
+    d.Ho = (Hup + 1 - k) / stride + 1;
+    d.Wo = (Wup + 1 - k) / stride + 1;
+  } else {
+    d.Ho = (Hup + 2 * pad - k) / stride + 1;
+    d.Wo = (Wup + 2 * pad - k) / stride + 1;
+  }
   d.ksize = k;
   d.stride = stride;
   d.up = up;
@@ -704,6 +713,39 @@ void UNet::build_unet() {
 // (SD: 128,256,512,512), layers_per_block = 2 (decoder uses +1), in_channels = latent channels,
 // out_channels = 3, height/width = latent size.
 // ---------------------------------------------------------------------------------------------
+// AutoencoderKL mid-block attention: single head over H*W tokens, d = C (too wide for the streaming kernel's
+// register budget): scores and P are materialised per image (S x S fp16) through the GEMM kernel.
+Tensor UNet::vae_attention(std::vector<Op>& ops, const std::string& p, const Tensor& h) {
+  const int B = h.B, H = h.H, W = h.W, C = h.C, S = H * W;
+  Tensor t0 = group_norm(ops, p + ".group_norm", h, nullptr, 1e-6f, false);
+  Tensor q = conv(ops, p + ".to_q", t0, nullptr, C, 1, 1, 1, true, nullptr, nullptr);
+  Tensor k = conv(ops, p + ".to_k", t0, nullptr, C, 1, 1, 1, true, nullptr, nullptr);
+  const int ldv = round_up(S, 8);
+  Tensor vt = conv(ops, p + ".to_v", t0, nullptr, C, 1, 1, 1, true, nullptr, nullptr, kOutHalfT, ldv);
+  SD_REQUIRE(C % 64 == 0 && S % 64 == 0, kUnsupported, "VAE attention needs C %% 64 == 0 and H*W %% 64 == 0");
+  SD_REQUIRE(ldv == S, kUnsupported, "VAE attention needs H*W %% 8 == 0");
+  half_t* scores = arena_.alloc_n<half_t>((size_t)S * S);
+  Tensor a = new_tensor(B, H, W, C);
+  const float scale = 1.0f / std::sqrt((float)C);
+  for (int b = 0; b < B; ++b) {
+    ConvDesc d1;   // scores[q][k] = sum_c Q[q][c] K[k][c]   (K tokens play the role of the weight matrix)
+    d1.x0 = q.p + (size_t)b * S * C; d1.C0 = C; d1.w = k.p + (size_t)b * S * C;
+    d1.out = scores; d1.B = 1; d1.Hi = 1; d1.Wi = S; d1.Ho = 1; d1.Wo = S; d1.N = S;
+    ConvDesc d2;   // out[q][c] = sum_k P[q][k] V^T[c][k]
+    d2.x0 = scores; d2.C0 = S; d2.w = vt.p + (size_t)b * C * ldv;
+    d2.out = a.p + (size_t)b * S * C; d2.B = 1; d2.Hi = 1; d2.Wi = S; d2.Ho = 1; d2.Wo = S; d2.N = C;
+    ws_need_ = std::max(ws_need_, std::max(conv_workspace_bytes(d1), conv_workspace_bytes(d2)));
+    ops.push_back([this, d1, d2, scores, S, scale](hipStream_t s) {
+      launch_conv(d1, ws_conv_, s);
+      launch_row_softmax(scores, S, S, scale, s);
+      launch_conv(d2, ws_conv_, s);
+    });
+    ops.back().label = "VAE attention: QK^T GEMM + row softmax + PV GEMM, S=" + std::to_string(S);
+    ops.back().flop = 4.0 * (double)S * S * C;
+  }
+  return conv(ops, p + ".to_out.0", a, nullptr, C, 1, 1, 1, true, nullptr, h.p);
+}
+
 void UNet::build_vae_decoder() {
   const int B = cfg_.batch, H = cfg_.height, W = cfg_.width, n = cfg_.n_levels;
   const int Cz = cfg_.in_channels;
@@ -718,39 +760,7 @@ void UNet::build_vae_decoder() {
   const int Ctop = cfg_.block_out_channels[n - 1];
   h = conv(main_ops_, "decoder.conv_in", h, nullptr, Ctop, 3, 1, 1, true, nullptr, nullptr);
   h = resnet(main_ops_, "decoder.mid_block.resnets.0", h, nullptr, Ctop, false);
-  {  // single-head self-attention over H*W tokens, d = C (too wide for the streaming kernel's
-     // register budget): scores and P are materialised per image (S x S fp16) through the GEMM kernel.
-    const std::string p = "decoder.mid_block.attentions.0";
-    const int C = Ctop, S = H * W;
-    Tensor t0 = group_norm(main_ops_, p + ".group_norm", h, nullptr, 1e-6f, false);
-    Tensor q = conv(main_ops_, p + ".to_q", t0, nullptr, C, 1, 1, 1, true, nullptr, nullptr);
-    Tensor k = conv(main_ops_, p + ".to_k", t0, nullptr, C, 1, 1, 1, true, nullptr, nullptr);
-    const int ldv = round_up(S, 8);
-    Tensor vt = conv(main_ops_, p + ".to_v", t0, nullptr, C, 1, 1, 1, true, nullptr, nullptr, kOutHalfT, ldv);
-    SD_REQUIRE(C % 64 == 0 && S % 64 == 0, kUnsupported, "VAE attention needs C %% 64 == 0 and H*W %% 64 == 0");
-    half_t* scores = arena_.alloc_n<half_t>((size_t)S * S);
-    Tensor a = new_tensor(B, H, W, C);
-    const float scale = 1.0f / std::sqrt((float)C);
-    ws_need_ = std::max<size_t>(ws_need_, 0);
-    for (int b = 0; b < B; ++b) {
-      ConvDesc d1;   // scores[q][k] = sum_c Q[q][c] K[k][c]   (K tokens play the role of the weight matrix)
-      d1.x0 = q.p + (size_t)b * S * C; d1.C0 = C; d1.w = k.p + (size_t)b * S * C;
-      d1.out = scores; d1.B = 1; d1.Hi = 1; d1.Wi = S; d1.Ho = 1; d1.Wo = S; d1.N = S;
-      ConvDesc d2;   // out[q][c] = sum_k P[q][k] V^T[c][k]
-      d2.x0 = scores; d2.C0 = S; d2.w = vt.p + (size_t)b * C * ldv;
-      d2.out = a.p + (size_t)b * S * C; d2.B = 1; d2.Hi = 1; d2.Wi = S; d2.Ho = 1; d2.Wo = S; d2.N = C;
-      SD_REQUIRE(ldv == S, kUnsupported, "VAE attention needs H*W %% 8 == 0");
-      ws_need_ = std::max(ws_need_, std::max(conv_workspace_bytes(d1), conv_workspace_bytes(d2)));
-      main_ops_.push_back([this, d1, d2, scores, S, scale](hipStream_t s) {
-        launch_conv(d1, ws_conv_, s);
-        launch_row_softmax(scores, S, S, scale, s);
-        launch_conv(d2, ws_conv_, s);
-      });
-      main_ops_.back().label = "VAE attention: QK^T GEMM + row softmax + PV GEMM, S=" + std::to_string(S);
-      main_ops_.back().flop = 4.0 * (double)S * S * C;
-    }
-    h = conv(main_ops_, p + ".to_out.0", a, nullptr, C, 1, 1, 1, true, nullptr, h.p);
-  }
+  h = vae_attention(main_ops_, "decoder.mid_block.attentions.0", h);
   h = resnet(main_ops_, "decoder.mid_block.resnets.1", h, nullptr, Ctop, false);
   for (int i = 0; i < n; ++i) {
     const int cout = cfg_.block_out_channels[n - 1 - i];
@@ -786,7 +796,7 @@ void UNet::build_vae_decoder() {
 // pipeline.py:313-320 hands z = latents / scaling_factor (fp16 or fp32); returns image in [-1, 1]
 void UNet::vae_decode(const void* z, int z_is_f32, float* image, int flags) {
   SD_HIP(hipSetDevice(device_));
-  SD_REQUIRE(cfg_.is_vae_decoder, kInvalidArgument, "handle is not a VAE decoder");
+  SD_REQUIRE(cfg_.is_vae_decoder == 1, kInvalidArgument, "handle is not a VAE decoder");
   const bool dev = (flags & SD_FLAG_DEVICE_PTRS) != 0;
   const size_t n = (size_t)cfg_.batch * cfg_.in_channels * cfg_.height * cfg_.width;
   if (z_is_f32) {
@@ -796,6 +806,14 @@ void UNet::vae_decode(const void* z, int z_is_f32, float* image, int flags) {
     SD_HIP(hipMemcpyAsync(z_half_, z, n * 2, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream_));
     launch_half_to_float(z_half_, in_z_, n, stream_);
   }
+  run_vae_graph();
+  SD_HIP(hipMemcpyAsync(image, image_, image_elems_ * sizeof(float),
+                        dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream_));
+  SD_HIP(hipStreamSynchronize(stream_));
+  have_inputs_ = true;
+}
+
+void UNet::run_vae_graph() {
   if (cfg_.use_graph) {
     if (!graph_) {
       run_ops(main_ops_);
@@ -806,8 +824,85 @@ void UNet::vae_decode(const void* z, int z_is_f32, float* image, int flags) {
   } else {
     run_ops(main_ops_);
   }
-  SD_HIP(hipMemcpyAsync(image, image_, image_elems_ * sizeof(float),
-                        dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream_));
+}
+
+// ---------------------------------------------------------------------------------------------
+// VAE encoder (diffusers AutoencoderKL.encode up to the moments; the reference wraps it as
+// latent = quant_conv(encoder(x)), torch2coreml.py:739-749, and samples / scales in Encoder.swift:48-90).
+// Third-party arithmetic restated from the public architecture:
+//   conv_in 3x3 (3 -> C0) -> down blocks (layers_per_block ResNets, then conv3x3 stride 2 on F.pad(x, (0,1,0,1)) in
+//   all but the last) -> mid [ResNet, 1-head self-attention, ResNet] -> GroupNorm(32, 1e-6) -> SiLU -> conv_out 3x3
+//   (-> 2 * latent channels) -> quant_conv 1x1.   Config: block_out_channels in encoder order, in_channels = 3,
+//   out_channels = 2 * latent channels, height / width = IMAGE size.  Output: moments (B, 2*Cz, H/8, W/8) f32.
+// ---------------------------------------------------------------------------------------------
+void UNet::build_vae_encoder() {
+  const int B = cfg_.batch, H = cfg_.height, W = cfg_.width, n = cfg_.n_levels;
+  const int Cm = cfg_.out_channels;
+  cfg_.norm_eps = 1e-6f;
+  SD_REQUIRE(cfg_.in_channels == 3 && Cm >= 2 && Cm <= 8, kUnsupported, "VAE encoder: %d -> %d channels", cfg_.in_channels, Cm);
+  in_x_ = arena_.alloc((size_t)B * 3 * H * W * 4);
+  Tensor x = new_tensor(B, H, W, 3);
+  {
+    void* src = in_x_;
+    UNet* self = this;
+    main_ops_.push_back([=](hipStream_t s) { launch_nchw_to_nhwc(src, self->vae_in_f32_, x.p, B, 3, H, W, s); });
+    main_ops_.back().label = "boundary: image NCHW -> NHWC fp16";
+  }
+  Tensor h = conv(main_ops_, "encoder.conv_in", x, nullptr, cfg_.block_out_channels[0], 3, 1, 1, true, nullptr, nullptr);
+  for (int i = 0; i < n; ++i) {
+    const int cout = cfg_.block_out_channels[i];
+    const std::string p = "encoder.down_blocks." + std::to_string(i);
+    for (int j = 0; j < cfg_.layers_per_block; ++j)
+      h = resnet(main_ops_, p + ".resnets." + std::to_string(j), h, nullptr, cout, false);
+    if (i != n - 1)
+      h = conv(main_ops_, p + ".downsamplers.0.conv", h, nullptr, cout, 3, 2, 1, true, nullptr, nullptr, kOutHalf, 0, false, 0);
+  }
+  const int Ctop = cfg_.block_out_channels[n - 1];
+  h = resnet(main_ops_, "encoder.mid_block.resnets.0", h, nullptr, Ctop, false);
+  h = vae_attention(main_ops_, "encoder.mid_block.attentions.0", h);
+  h = resnet(main_ops_, "encoder.mid_block.resnets.1", h, nullptr, Ctop, false);
+  Tensor t = group_norm(main_ops_, "encoder.conv_norm_out", h, nullptr, 1e-6f, true);
+  SD_REQUIRE(t.C % 8 == 0, kUnsupported, "VAE encoder conv_out: %d input channels", t.C);
+  Tensor m = new_tensor(t.B, t.H, t.W, Cm);
+  {
+    ConvDesc d;
+    d.x0 = t.p;
+    d.C0 = t.C;
+    d.w = upload_conv_weight("encoder.conv_out", Cm, t.C, 3, false);
+    d.bias = upload_vec("encoder.conv_out.bias", Cm);
+    d.out = m.p;
+    d.B = t.B; d.Hi = t.H; d.Wi = t.W; d.Ho = t.H; d.Wo = t.W;
+    d.ksize = 3; d.stride = 1; d.up = 1; d.N = Cm;
+    main_ops_.push_back([=](hipStream_t s) { launch_conv_small_n(d, nullptr, s); });
+    main_ops_.back().label = "conv3x3 small-N encoder.conv_out";
+  }
+  Tensor q = conv(main_ops_, "quant_conv", m, nullptr, Cm, 1, 1, 1, true, nullptr, nullptr);
+  image_elems_ = q.numel();
+  image_ = arena_.alloc_n<float>(image_elems_);
+  {
+    float* dst = image_;
+    main_ops_.push_back([=](hipStream_t s) { launch_nhwc_to_nchw_f32(q.p, dst, q.B, q.C, q.H, q.W, s); });
+    main_ops_.back().label = "boundary: moments NHWC fp16 -> NCHW fp32";
+  }
+  if (ws_need_ > 0) {
+    ws_conv_.partial = reinterpret_cast<float*>(arena_.alloc(ws_need_));
+    ws_conv_.partial_bytes = ws_need_;
+  }
+}
+
+void UNet::vae_encode(const void* x, int x_is_f32, float* moments, int flags) {
+  SD_HIP(hipSetDevice(device_));
+  SD_REQUIRE(cfg_.is_vae_decoder == 2, kInvalidArgument, "handle is not a VAE encoder");
+  const bool dev = (flags & SD_FLAG_DEVICE_PTRS) != 0;
+  const size_t n = (size_t)cfg_.batch * 3 * cfg_.height * cfg_.width;
+  if ((x_is_f32 != 0) != (vae_in_f32_ != 0)) {   // the captured boundary kernel bakes the input dtype in
+    vae_in_f32_ = x_is_f32 ? 1 : 0;
+    invalidate_graphs();
+  }
+  SD_HIP(hipMemcpyAsync(in_x_, x, n * (x_is_f32 ? 4 : 2), dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream_));
+  run_vae_graph();
+  SD_HIP(hipMemcpyAsync(moments, image_, image_elems_ * sizeof(float), dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                        stream_));
   SD_HIP(hipStreamSynchronize(stream_));
   have_inputs_ = true;
 }

@@ -52,6 +52,7 @@ class UNet {
   void set_controlnet_cond(const void* cond, int flags);
   void set_attention(int impl);
   void vae_decode(const void* z, int z_is_f32, float* image, int flags);
+  void vae_encode(const void* x, int x_is_f32, float* moments, int flags);
   int num_residuals() const { return (int)res_shapes_.size(); }
   size_t device_bytes() const { return arena_.bytes(); }
   const sd_unet_config& config() const { return cfg_; }
@@ -60,12 +61,14 @@ class UNet {
   // ---- build ----
   void build_unet();
   void build_vae_decoder();
+  void build_vae_encoder();
+  void run_vae_graph();
   Tensor new_tensor(int B, int H, int W, int C);
   half_t* upload_conv_weight(const std::string& name, int cout, int cin, int k, bool geglu);
   float* upload_vec(const std::string& name, int n, bool geglu = false);
   Tensor conv(std::vector<Op>& ops, const std::string& name, const Tensor& x, const Tensor* x2, int cout, int k,
               int stride, int up, bool bias, const float* temb, const half_t* res, int out_mode = kOutHalf,
-              int ldT = 0, bool silu_out = false);
+              int ldT = 0, bool silu_out = false, int pad = -1);
   // optional extras of conv_w: LayerNorm fold (ln_colsum) and the fused q|k|v split (n_trans > 0:
   // columns >= n_trans leave token-transposed in *vt, [B][cout - n_trans][ldT])
   struct ConvExtra {
@@ -75,7 +78,7 @@ class UNet {
   };
   Tensor conv_w(std::vector<Op>& ops, const std::string& name, const half_t* w, const float* bias, const Tensor& x,
                 const Tensor* x2, int cout, int k, int stride, int up, const float* temb, const half_t* res,
-                int out_mode, int ldT, bool silu_out, ConvExtra* ex = nullptr);
+                int out_mode, int ldT, bool silu_out, ConvExtra* ex = nullptr, int pad = -1);
   // LayerNorm `ln` folded into the bias-free/biased 1x1 projections `names` (stacked along Cout) that
   // consume it: returns w' = W*gamma (fp16), colsum of w', bias' = b + W.beta
   struct LnFold {
@@ -94,6 +97,7 @@ class UNet {
                 bool has_temb = true);
   Tensor transformer(std::vector<Op>& ops, const std::string& p, const Tensor& x, int heads, int depth);
   Tensor transformer_block(std::vector<Op>& ops, const std::string& b, const Tensor& h, int heads);
+  Tensor vae_attention(std::vector<Op>& ops, const std::string& p, const Tensor& h);
   Tensor attention(std::vector<Op>& ops, const Tensor& q, const half_t* k, const half_t* vt, int heads, int Sq,
                    int Sk, int ldk, int ldv, int ldq);
   void down_and_mid(std::vector<Op>& ops, Tensor& h, std::vector<Tensor>& skips);
@@ -138,7 +142,9 @@ class UNet {
   float* noise_pred_ = nullptr;     // NCHW f32
   float* in_z_ = nullptr;           // VAE: latent input NCHW f32
   half_t* z_half_ = nullptr;
-  float* image_ = nullptr;          // VAE: decoded image NCHW f32
+  float* image_ = nullptr;          // VAE: decoded image NCHW f32 (encoder: the moments NCHW f32)
+  void* in_x_ = nullptr;            // VAE encoder: input image NCHW (f16 or f32)
+  int vae_in_f32_ = 0;
   size_t image_elems_ = 0;
   std::vector<float*> res_out_;     // ControlNet outputs NCHW f32
   std::vector<Tensor> cn_out_;      // ControlNet outputs NHWC f16

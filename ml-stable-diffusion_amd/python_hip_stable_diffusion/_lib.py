@@ -80,6 +80,8 @@ SYMBOLS = [
     ("sd_controlnet_set_cond", _I, [_P, _P, _I]),
     ("sd_vae_decoder_create", _I, [C.POINTER(UNetConfig), _P, _I, C.POINTER(_P)]),
     ("sd_vae_decode", _I, [_P, _P, _I, _FP, _I]),
+    ("sd_vae_encoder_create", _I, [C.POINTER(UNetConfig), _P, _I, C.POINTER(_P)]),
+    ("sd_vae_encode", _I, [_P, _P, _I, _FP, _I]),
     ("sd_text_encoder_create", _I, [_P, _P, _I, C.POINTER(_P)]),
     ("sd_text_encoder_destroy", None, [_P]),
     ("sd_text_encoder_device_bytes", C.c_size_t, [_P]),

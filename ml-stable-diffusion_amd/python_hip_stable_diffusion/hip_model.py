@@ -486,3 +486,60 @@ class HipVaeDecoder:
             self.close()
         except Exception:
             pass
+
+
+class HipVaeEncoder:
+    """``vae_encoder`` model runner: ``quant_conv(encoder(x))`` (torch2coreml.py:739-749) behind the CoreMLModel
+    interface: ``model(x=...)["latent"]`` = the posterior moments (B, 2*latent_channels, H/8, W/8) fp32,
+    [mean | logvar]; sampling and the scale factor stay with the caller (Encoder.swift:48-90)."""
+
+    def __init__(self, config, weights, batch=1, height=512, width=512, device=0, use_graph=True, dtype=np.float16):
+        if isinstance(config, str):
+            if config not in VAE_CONFIGS:
+                raise ValueError(f"unknown VAE config {config!r}")
+            config = VAE_CONFIGS[config]
+        self.config = dict(config)
+        boc = tuple(config["block_out_channels"])
+        c = _lib.UNetConfig()
+        c.batch, c.in_channels, c.out_channels = batch, 3, 2 * config["latent_channels"]
+        c.height, c.width, c.n_levels = height, width, len(boc)
+        _fill(c.block_out_channels, boc)
+        c.layers_per_block = config["layers_per_block"]
+        c.norm_num_groups, c.norm_eps = 32, 1e-6
+        c.use_graph = int(use_graph)
+        own = not isinstance(weights, Weights)
+        wstore = weights if not own else (Weights(safetensors_path=weights) if isinstance(weights, (str, bytes))
+                                          else Weights(tensors=weights))
+        self._h = C.c_void_p()
+        try:
+            _lib.check(_lib.lib().sd_vae_encoder_create(C.byref(c), wstore._h, device, C.byref(self._h)))
+        finally:
+            if own:
+                wstore.close()
+        down = 2 ** (len(boc) - 1)
+        self.latent_shape = (batch, 2 * config["latent_channels"], height // down, width // down)
+        self.expected_inputs = {"x": {"shape": (batch, 3, height, width), "dtype": np.dtype(dtype)}}
+
+    _verify_inputs = HipModel._verify_inputs
+
+    def __call__(self, **kwargs):
+        self._verify_inputs(**kwargs)
+        x = np.ascontiguousarray(kwargs["x"])
+        out = np.empty(self.latent_shape, np.float32)
+        _lib.check(_lib.lib().sd_vae_encode(self._h, _lib.ptr(x), 1 if x.dtype == np.float32 else 0, _lib.fptr(out), 0))
+        return {"latent": out}
+
+    @property
+    def device_bytes(self):
+        return _lib.lib().sd_unet_device_bytes(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().sd_unet_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -105,3 +105,79 @@ def vae_decode(sd, cfg, z):
             x = _conv(sd, f"decoder.up_blocks.{i}.upsamplers.0.conv", x, 1)
     x = F.silu(_gn(sd, "decoder.conv_norm_out", x))
     return _conv(sd, "decoder.conv_out", x, 1)
+
+
+def vae_encoder_param_shapes(cfg):
+    """AutoencoderKL encoder + quant_conv (diffusers key names): conv_in, down_blocks.{i}.resnets.{j},
+    downsamplers.0.conv, mid_block, conv_norm_out, conv_out (-> 2 * latent channels), quant_conv."""
+    sh = OrderedDict()
+
+    def conv(name, cin, cout, k):
+        sh[name + ".weight"] = (cout, cin, k, k)
+        sh[name + ".bias"] = (cout,)
+
+    def norm(name, c):
+        sh[name + ".weight"] = (c,)
+        sh[name + ".bias"] = (c,)
+
+    def resnet(p, cin, cout):
+        norm(p + ".norm1", cin)
+        conv(p + ".conv1", cin, cout, 3)
+        norm(p + ".norm2", cout)
+        conv(p + ".conv2", cout, cout, 3)
+        if cin != cout:
+            conv(p + ".conv_shortcut", cin, cout, 1)
+
+    boc = cfg["block_out_channels"]
+    cz = cfg["latent_channels"]
+    conv("encoder.conv_in", 3, boc[0], 3)
+    cin = boc[0]
+    for i, cout in enumerate(boc):
+        for j in range(cfg["layers_per_block"]):
+            resnet(f"encoder.down_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout)
+        if i != len(boc) - 1:
+            conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", cout, cout, 3)
+        cin = cout
+    top = boc[-1]
+    resnet("encoder.mid_block.resnets.0", top, top)
+    a = "encoder.mid_block.attentions.0"
+    norm(a + ".group_norm", top)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        sh[f"{a}.{n}.weight"] = (top, top)
+        sh[f"{a}.{n}.bias"] = (top,)
+    resnet("encoder.mid_block.resnets.1", top, top)
+    norm("encoder.conv_norm_out", top)
+    conv("encoder.conv_out", top, 2 * cz, 3)
+    conv("quant_conv", 2 * cz, 2 * cz, 1)
+    return sh
+
+
+def _attention(sd, a, x):
+    b, c, h, w = x.shape
+    t = _gn(sd, a + ".group_norm", x).reshape(b, c, h * w).transpose(1, 2)
+    q = F.linear(t, sd[a + ".to_q.weight"], sd[a + ".to_q.bias"])
+    k = F.linear(t, sd[a + ".to_k.weight"], sd[a + ".to_k.bias"])
+    v = F.linear(t, sd[a + ".to_v.weight"], sd[a + ".to_v.bias"])
+    p = torch.softmax(q @ k.transpose(1, 2) * c ** -0.5, dim=-1)
+    o = F.linear(p @ v, sd[a + ".to_out.0.weight"], sd[a + ".to_out.0.bias"])
+    return x + o.transpose(1, 2).reshape(b, c, h, w)
+
+
+@torch.no_grad()
+def vae_encode(sd, cfg, x):
+    """x (B, 3, H, W) in [-1, 1] -> moments quant_conv(encoder(x)) (B, 2*Cz, H/8, W/8); the wrapper of
+    python_coreml_stable_diffusion/torch2coreml.py:739-749.  Downsample = F.pad(x, (0, 1, 0, 1)) + stride-2 conv
+    (diffusers Downsample2D with padding=0).  PARITY UNPINNED like the decoder."""
+    x = _conv(sd, "encoder.conv_in", x.float(), 1)
+    n = len(cfg["block_out_channels"])
+    for i in range(n):
+        for j in range(cfg["layers_per_block"]):
+            x = _resnet(sd, f"encoder.down_blocks.{i}.resnets.{j}", x)
+        if i != n - 1:
+            p = f"encoder.down_blocks.{i}.downsamplers.0.conv"
+            x = F.conv2d(F.pad(x, (0, 1, 0, 1)), sd[p + ".weight"], sd[p + ".bias"], stride=2)
+    x = _resnet(sd, "encoder.mid_block.resnets.0", x)
+    x = _attention(sd, "encoder.mid_block.attentions.0", x)
+    x = _resnet(sd, "encoder.mid_block.resnets.1", x)
+    x = F.silu(_gn(sd, "encoder.conv_norm_out", x))
+    return _conv(sd, "quant_conv", _conv(sd, "encoder.conv_out", x, 1))

@@ -254,3 +254,21 @@ def test_timestep_embedding_reference_golden():
     assert np.mean(np.abs(out - g["out"]) > 2e-6) < 0.02
     ts = np.array([951, 901, 1, 999, 0], np.float32)
     np.testing.assert_allclose(_lib.timestep_embedding(ts, 256), unet_ref.timestep_embedding(torch.from_numpy(ts), 256).numpy(), atol=1e-4)
+
+
+@pytest.mark.parametrize("tile,splitk", [(3, 8), (33, 16), (6, 4), (26, 2), (1, 4)])
+def test_splitk_in_kernel_combine_is_complete_and_bit_reproducible(tile, splitk):
+    """Split-K slabs are combined inside the conv launch by the K slice that arrives last (release / ticket /
+    acquire, csrc/igemm.hip splitk_publish_and_elect).  Whatever the arrival order, the sum runs in slice order:
+    repeated launches must agree bit for bit, and with torch.  A weight-streaming shape (M = 128 rows, K = 11520) so
+    that slices of one tile land on different XCDs and finish at different times."""
+    rs = np.random.RandomState(tile * 100 + splitk)
+    x = h16(rs.randn(2, 1280, 8, 8))
+    w = h16(rs.randn(320, 1280, 3, 3) / np.sqrt(1280 * 9))
+    bias = (0.1 * rs.randn(320)).astype(np.float32)
+    res = h16(rs.randn(2, 320, 8, 8))
+    first, _ = _lib.conv2d(x, w, bias, res, tile=tile, splitk=splitk)
+    close(first, conv_ref(x, w, bias, res, 1, False), f"split-K conv tile {tile} splitk {splitk}")
+    for _ in range(10):
+        again, _ = _lib.conv2d(x, w, bias, res, tile=tile, splitk=splitk, iters=5)
+        assert np.array_equal(first, again)

@@ -339,3 +339,25 @@ def test_config3_sharded_run_with_the_real_device_loop():
         one = parallel.run_sharded(loop(m2), ehs[i:i + 1], lat[i:i + 1], None)
         assert psnr.compute_psnr(both[i:i + 1], one) >= 60.0
     m2.close(), m4.close()
+
+
+@pytest.mark.parametrize("name,hw", [("mini", 64), ("sd", 128)])
+def test_vae_encoder_matches_oracle(name, hw):
+    """quant_conv(encoder(x)) (torch2coreml.py:739-749; Encoder.swift): asymmetric (0,1,0,1) padding in the
+    stride-2 downsamplers, 3-channel conv_in, 8-channel moments.  Oracle PARITY UNPINNED (diffusers absent)."""
+    from python_hip_stable_diffusion import HipVaeEncoder
+    cfg = vae_ref.VAE_CONFIGS[name]
+    sd16 = weights.make_state_dict(vae_ref.vae_encoder_param_shapes(cfg), seed=71, dtype=np.float16, gain=1.4)
+    sd = weights.to_torch({k: v.astype(np.float32) for k, v in sd16.items()})
+    enc = HipVaeEncoder(cfg, sd16, batch=1, height=hw, width=hw)
+    x = np.tanh(weights.seeded_normal((1, 3, hw, hw), 72)).astype(np.float16)            # an "image" in [-1, 1]
+    out = enc(x=x)["latent"]
+    ref = vae_ref.vae_encode(sd, cfg, torch.from_numpy(x.astype(np.float32))).numpy()
+    assert out.shape == ref.shape == (1, 8, hw // 8, hw // 8)
+    p = psnr.compute_psnr(out, ref)
+    assert p >= 45.0, f"VAE encoder {name}: PSNR {p:.1f} dB"
+    again = enc(x=x.astype(np.float16))["latent"]
+    assert np.array_equal(out, again)
+    with pytest.raises(TypeError):
+        enc(x=x.astype(np.float32))
+    enc.close()
