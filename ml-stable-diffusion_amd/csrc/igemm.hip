@@ -24,7 +24,6 @@ namespace sd {
 namespace {
 
 constexpr int BK = 64;            // K step (halves)
-constexpr size_t kTicketBytes = 64 * 1024;   // split-K arrival counters at the head of the workspace: 16384 tiles
 constexpr int LDS_ROW = BK + 8;   // padded row stride in halves (144 B): 16 rows -> 16 distinct 16-B slots
 
 struct IgemmArgs {
@@ -36,7 +35,6 @@ struct IgemmArgs {
   const half_t* res;
   half_t* out;
   float* partial;
-  unsigned* tickets;   // split-K: one arrival counter per output tile (0 between launches)
   int C0, C1, Ctot;
   int B, Hi, Wi, Ho, Wo, HoWo;
   int ksize, stride, up, pad;
@@ -83,56 +81,6 @@ __device__ __forceinline__ float xor32_sum(float v) {
   const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
   const unsigned r0 = r[0], r1 = r[1];   // scalars first: bit-casting the vector-element lvalue reads lane 0 twice
   return __uint_as_float(r0) + __uint_as_float(r1);
-}
-
-// Split-K without a second launch: every K slice stores its fp32 slab tile, PUBLISHES it (all stores drained,
-// workgroup barrier, one agent-scope release fence, then a relaxed agent-scope ticket on the tile's counter -
-// cdna guide section 5, "in-launch split-K reduction") and the slice that draws the last ticket acquires and combines
-// all slabs in slice order, so the sum does not depend on which slice arrives last (bit-reproducible).  Returns true
-// in every thread of the electing workgroup.  `flag` is a word of the workgroup's own LDS.
-__device__ __forceinline__ bool splitk_publish_and_elect(unsigned* ticket, int nsplit, int* flag, int tid) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the compiler may drop the wait behind buffer_wbl2 (guide G16)
-    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = t == (unsigned)nsplit - 1u;
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      *ticket = 0;                                      // every slice has arrived: ready for the next launch
-    }
-    *flag = last;
-  }
-  __syncthreads();
-  return *flag != 0;
-}
-
-// combine the slabs of one output tile in slice order + bias / timestep embedding / residual -> fp16
-// (the arithmetic and its order are those of the former stand-alone reduce kernel)
-template <class RowFn>
-__device__ __forceinline__ void splitk_combine_tile(const IgemmArgs& a, int rows, int n_blk, int bn, int tid, RowFn row_of) {
-  const int c4n = bn >> 2;
-  for (int idx = tid; idx < rows * c4n; idx += 256) {
-    const int r = idx / c4n, c4 = idx - r * c4n;
-    const long m = row_of(r);
-    const int n = n_blk + c4 * 4;
-    if (m < 0 || n >= a.N) continue;
-    floatx4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int z = 0; z < a.splitk; ++z) s += *reinterpret_cast<const floatx4*>(a.partial + ((size_t)z * a.M + m) * a.N + n);
-    if (a.bias) s += *reinterpret_cast<const floatx4*>(a.bias + n);
-    if (a.temb) s += *reinterpret_cast<const floatx4*>(a.temb + (size_t)(m / a.HoWo) * a.temb_stride + n);
-    const size_t e0 = (size_t)m * a.N + n;
-    if (a.res) {
-      const half4 rr = *reinterpret_cast<const half4*>(a.res + e0);
-      s[0] += (float)rr[0];
-      s[1] += (float)rr[1];
-      s[2] += (float)rr[2];
-      s[3] += (float)rr[3];
-    }
-    const half4 o = {(half_t)s[0], (half_t)s[1], (half_t)s[2], (half_t)s[3]};
-    *reinterpret_cast<half4*>(a.out + e0) = o;
-  }
 }
 
 // One 256-thread workgroup = 4 wavefronts laid out WGM x WGN over a BM x BN tile.
@@ -611,7 +559,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     return;
   } else {
     // acc[i][j][r]: n = n0 + (r&3) + 8*(r>>2) + 4*hi ; m = m0 + (lane&31)
-    if (a.splitk > 1) {   // fp32 partial slabs; the last-arriving K slice combines them and applies bias / temb / residual
+    if (a.splitk > 1) {   // fp32 partial slabs; bias/temb/residual are applied by splitk_reduce_kernel
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int m = m_blk + (wm * TM + i) * 32 + frow;
@@ -628,8 +576,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
             }
           }
       }
-      if (splitk_publish_and_elect(a.tickets + bid, a.splitk, reinterpret_cast<int*>(sconst), tid))
-        splitk_combine_tile(a, BM, n_blk, BN, tid, [&](int r) { return (m_blk + r < a.M) ? (long)(m_blk + r) : -1L; });
     } else {
       // Stage the finished tile through LDS (free after the K loop) so that the global stores - and
       // the residual loads - are whole 16-B-per-lane row segments instead of 32 scattered 16-B pieces
@@ -1005,11 +951,6 @@ __global__ __launch_bounds__(256, halo_lds_bytes(BN, D) <= 80 * 1024 ? 2 : 1) vo
           }
         }
     }
-    if (splitk_publish_and_elect(a.tickets + bid, a.splitk, reinterpret_cast<int*>(sconst), tid))
-      splitk_combine_tile(a, BM, n_blk, BN, tid, [&](int r) {
-        const int y = y0 + (r >> 4), x = x0 + (r & 15);
-        return (y < H && x < W) ? (long)((b * H + y) * W + x) : -1L;
-      });
     return;
   }
   constexpr int OROW = BN + 8;
@@ -1054,6 +995,36 @@ __global__ __launch_bounds__(256, halo_lds_bytes(BN, D) <= 80 * 1024 ? 2 : 1) vo
         for (int e = 0; e < a.N - n; ++e) dst[e] = a.res ? (half_t)((float)v[e] + (float)a.res[m * a.N + n + e]) : v[e];
       }
     }
+  }
+}
+
+// split-K combine + the same epilogue (bias, temb broadcast, residual) -> fp16
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmArgs a) {
+  const size_t total4 = (size_t)a.M * a.N / 4;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total4;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t e0 = idx * 4;
+    const int m = (int)(e0 / a.N);
+    const int n = (int)(e0 - (size_t)m * a.N);
+    floatx4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < a.splitk; ++z) {
+      floatx4 p = *reinterpret_cast<const floatx4*>(a.partial + ((size_t)z * a.M + m) * a.N + n);
+      s += p;
+    }
+    if (a.bias) s += *reinterpret_cast<const floatx4*>(a.bias + n);
+    if (a.temb) {
+      const int b = m / a.HoWo;
+      s += *reinterpret_cast<const floatx4*>(a.temb + (size_t)b * a.temb_stride + n);
+    }
+    if (a.res) {
+      half4 rr = *reinterpret_cast<const half4*>(a.res + e0);
+      s[0] += (float)rr[0];
+      s[1] += (float)rr[1];
+      s[2] += (float)rr[2];
+      s[3] += (float)rr[3];
+    }
+    half4 o = {(half_t)s[0], (half_t)s[1], (half_t)s[2], (half_t)s[3]};
+    *reinterpret_cast<half4*>(a.out + e0) = o;
   }
 }
 
@@ -1400,7 +1371,7 @@ Plan choose_plan(const ConvDesc& d, const IgemmArgs& a) {
     const int ms = max_split(p.tile);
     while (blocks_of(p.tile) * p.splitk < 384 && p.splitk < ms) p.splitk *= 2;
   }
-  if (!can_split || blocks_of(p.tile) > (long)(kTicketBytes / sizeof(unsigned))) p.splitk = 1;   // one ticket per tile
+  if (!can_split) p.splitk = 1;
   if (p.splitk > ksteps(p.tile)) p.splitk = ksteps(p.tile);
   if (p.splitk < 1) p.splitk = 1;
   return p;
@@ -1530,7 +1501,7 @@ size_t conv_workspace_bytes(const ConvDesc& d) {
   static const bool tuning = getenv("SD_TUNE") != nullptr;
   const bool can_split = d.out_mode == kOutHalf && !d.ln_colsum && !d.out_t;
   const int splits = (tuning && can_split) ? std::max(p.splitk, 16) : p.splitk;
-  return splits > 1 ? kTicketBytes + (size_t)splits * a.M * a.N * sizeof(float) : 0;   // upper bound (fewer splits may run)
+  return splits > 1 ? (size_t)splits * a.M * a.N * sizeof(float) : 0;   // upper bound (launch may use fewer splits)
 }
 
 void conv_tune_set_candidate(int tile, int staging, int splitk) {
@@ -1560,12 +1531,10 @@ void launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
     a.splitk = cdiv(a.nk_total, a.nk_per_split);   // no empty splits
   }
   if (a.splitk > 1) {
-    // workspace = [kTicketBytes of per-tile arrival counters (zero between launches)] [fp32 slabs]
-    const size_t need = kTicketBytes + (size_t)a.splitk * a.M * a.N * sizeof(float);
+    size_t need = (size_t)a.splitk * a.M * a.N * sizeof(float);
     SD_REQUIRE(ws.partial && ws.partial_bytes >= need, kInternal, "split-K workspace too small (%zu < %zu)",
                ws.partial_bytes, need);
-    a.tickets = reinterpret_cast<unsigned*>(ws.partial);
-    a.partial = ws.partial + kTicketBytes / sizeof(float);
+    a.partial = ws.partial;
   }
   const bool trans = d.out_mode == kOutHalfT;
   const int st = p.staging;
@@ -1587,6 +1556,11 @@ void launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
       case 3: launch_tile<64, 64, 2, 2>(a, trans, st, s); break;
       default: launch_tile<64, 128, 2, 2>(a, trans, st, s); break;
     }
+  }
+  if (a.splitk > 1) {
+    size_t total4 = (size_t)a.M * a.N / 4;
+    int blocks = (int)std::min<size_t>((total4 + 255) / 256, 2048);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a);
   }
   SD_HIP(hipGetLastError());
 }

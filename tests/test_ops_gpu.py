@@ -257,11 +257,11 @@ def test_timestep_embedding_reference_golden():
 
 
 @pytest.mark.parametrize("tile,splitk", [(3, 8), (33, 16), (6, 4), (26, 2), (1, 4)])
-def test_splitk_in_kernel_combine_is_complete_and_bit_reproducible(tile, splitk):
-    """Split-K slabs are combined inside the conv launch by the K slice that arrives last (release / ticket /
-    acquire, csrc/igemm.hip splitk_publish_and_elect).  Whatever the arrival order, the sum runs in slice order:
-    repeated launches must agree bit for bit, and with torch.  A weight-streaming shape (M = 128 rows, K = 11520) so
-    that slices of one tile land on different XCDs and finish at different times."""
+def test_splitk_is_complete_and_bit_reproducible(tile, splitk):
+    """Split-K: fp32 slabs per K slice, combined in slice order by the reduce kernel (no atomics): repeated launches
+    must agree bit for bit, and with torch.  A weight-streaming shape (M = 128 rows, K = 11520), up to 16 slices.
+    (An in-launch last-arriver combine was built and measured in round 2: correct, but 1.5-3x slower on these shapes
+    - one workgroup per tile re-reading 256-512 KB of slabs behind a release fence - and was dropped, DESIGN.md.)"""
     rs = np.random.RandomState(tile * 100 + splitk)
     x = h16(rs.randn(2, 1280, 8, 8))
     w = h16(rs.randn(320, 1280, 3, 3) / np.sqrt(1280 * 9))
