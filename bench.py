@@ -280,7 +280,7 @@ def cpu_baseline(ckpt, ehs, latents, n_steps, guidance):
     x = np.concatenate([latents, latents]).astype(np.float16)
     ts = np.array([951, 951], np.float16)
     sweep = {}
-    for th in [c for c in (16, 32, 64) if c <= ncpu] or [ncpu]:
+    for th in [c for c in (8, 16, 32) if c <= ncpu] or [ncpu]:
         torch.set_num_threads(th)
         if not sweep:
             unet(x, ts, ehs)             # one warm-up forward (allocator, oneDNN primitive caches)

@@ -177,30 +177,6 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const half_t* __re
   const int cpg = C / G;
   const int b = blockIdx.y;
   const int t = threadIdx.x;
-  const int p0 = blockIdx.x * pix_per_block;
-  const int p1 = min(p0 + pix_per_block, HW);
-  // The kernel is latency-, not bandwidth-bound (a few hundred KB per launch): everything that does not depend on
-  // the statistics - the slab partials, this thread's affine parameters and its first pixels of the first column
-  // block - is requested before the first wait, so the launch pays one memory round trip instead of three.
-  const int cols0 = min(256, ncol), rows0 = 256 / cols0;
-  const int col0 = t % cols0, r00 = t / cols0;
-  const bool act0 = r00 < rows0;
-  const int c00 = col0 * 8;
-  const half_t* src0 = (c00 < C0) ? x0 + c00 : x1 + (c00 - C0);
-  const int Cs0 = (c00 < C0) ? C0 : C1;
-  half8 pre[4];
-  floatx4 g_lo = {0.f, 0.f, 0.f, 0.f}, g_hi = g_lo, b_lo = g_lo, b_hi = g_lo;
-  if (act0) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int pp = p0 + r00 + u * rows0;
-      if (pp < p1) pre[u] = *reinterpret_cast<const half8*>(src0 + ((size_t)b * HW + pp) * Cs0);
-    }
-    g_lo = *reinterpret_cast<const floatx4*>(gamma + c00);
-    g_hi = *reinterpret_cast<const floatx4*>(gamma + c00 + 4);
-    b_lo = *reinterpret_cast<const floatx4*>(beta + c00);
-    b_hi = *reinterpret_cast<const floatx4*>(beta + c00 + 4);
-  }
   {
     // fold the slabs: LPG lanes per group, each sums a contiguous run of kGnMaxSlabs/LPG slab entries
     // (unused entries are zero) loaded as independent float4s, then a fixed-order shuffle tree.
@@ -232,6 +208,8 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const half_t* __re
     }
   }
   __syncthreads();
+  const int p0 = blockIdx.x * pix_per_block;
+  const int p1 = min(p0 + pix_per_block, HW);
   for (int cb = 0; cb < ncol; cb += 256) {
     const int cols = min(256, ncol - cb);
     const int rows = 256 / cols;
@@ -240,28 +218,20 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const half_t* __re
     if (r0 >= rows) continue;
     const int c = col * 8;
     float sc[8], sh[8];
-    if (cb != 0) {   // later column blocks (C > 2048) fetch their own parameters
-      g_lo = *reinterpret_cast<const floatx4*>(gamma + c);
-      g_hi = *reinterpret_cast<const floatx4*>(gamma + c + 4);
-      b_lo = *reinterpret_cast<const floatx4*>(beta + c);
-      b_hi = *reinterpret_cast<const floatx4*>(beta + c + 4);
-    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int g = (c + e) / cpg;
-      sc[e] = s_rstd[g] * (e < 4 ? g_lo[e] : g_hi[e - 4]);
-      sh[e] = (e < 4 ? b_lo[e] : b_hi[e - 4]) - s_mean[g] * sc[e];
+      sc[e] = s_rstd[g] * gamma[c + e];
+      sh[e] = beta[c + e] - s_mean[g] * sc[e];
     }
     const half_t* src = (c < C0) ? x0 + c : x1 + (c - C0);
     const int Cs = (c < C0) ? C0 : C1;
     for (int p = p0 + r0; p < p1; p += 4 * rows) {
       half8 h[4];
-      const bool first = cb == 0 && p == p0 + r0;       // these were fetched at kernel entry
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int pp = p + u * rows;
-        if (first) h[u] = pre[u];
-        else if (pp < p1) h[u] = *reinterpret_cast<const half8*>(src + ((size_t)b * HW + pp) * Cs);
+        if (pp < p1) h[u] = *reinterpret_cast<const half8*>(src + ((size_t)b * HW + pp) * Cs);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -286,7 +256,7 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const half_t* __re
 // reduction, then affine (+SiLU) and the concatenated store.  Replaces the two dependent launches of
 // the slab version - a UNet step is launch-latency-bound on its ~60 GroupNorms (~4 us per dependent
 // launch), not bandwidth-bound.  VW = halves per vector access (alignment of the group's channel run).
-template <int VW, int MAXV>
+template <int VW>
 __global__ __launch_bounds__(256) void groupnorm_fused_kernel(const half_t* __restrict__ x0, int C0,
                                                               const half_t* __restrict__ x1, int C1,
                                                               const float* __restrict__ gamma,
@@ -301,50 +271,17 @@ __global__ __launch_bounds__(256) void groupnorm_fused_kernel(const half_t* __re
   const int c0 = g * cpg;
   const int nv = cpg / VW;                       // vectors per pixel
   const int items = HW * nv;
-  // MAXV > 0: the (sample, group) slice fits the registers of the workgroup (items <= 256 * MAXV): it is read ONCE,
-  // all loads - and the affine parameters - in flight before the first wait; the statistics and the normalised
-  // output come from the registers.  MAXV == 0: two passes over memory (second one from L2).
-  vec_t xr[MAXV > 0 ? MAXV : 1];
-  float gam = 0.f, bet = 0.f;
-  if (t < cpg) {
-    gam = gamma[c0 + t];
-    bet = beta[c0 + t];
-  }
   float s = 0.f, q = 0.f;
-  if constexpr (MAXV > 0) {
+  for (int it = t; it < items; it += 256) {
+    const int p = it / nv, v = it - p * nv;
+    const int c = c0 + v * VW;
+    const half_t* src = (c < C0) ? x0 + ((size_t)b * HW + p) * C0 + c : x1 + ((size_t)b * HW + p) * C1 + (c - C0);
+    const vec_t h = *reinterpret_cast<const vec_t*>(src);
 #pragma unroll
-    for (int k = 0; k < MAXV; ++k) {
-      const int it = t + 256 * k;
-      if (it < items) {
-        const int p = it / nv, v = it - p * nv;
-        const int c = c0 + v * VW;
-        const half_t* src = (c < C0) ? x0 + ((size_t)b * HW + p) * C0 + c : x1 + ((size_t)b * HW + p) * C1 + (c - C0);
-        xr[k] = *reinterpret_cast<const vec_t*>(src);
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < MAXV; ++k) {
-      if (t + 256 * k < items) {
-#pragma unroll
-        for (int e = 0; e < VW; ++e) {
-          const float f = (float)xr[k][e];
-          s += f;
-          q += f * f;
-        }
-      }
-    }
-  } else {
-    for (int it = t; it < items; it += 256) {
-      const int p = it / nv, v = it - p * nv;
-      const int c = c0 + v * VW;
-      const half_t* src = (c < C0) ? x0 + ((size_t)b * HW + p) * C0 + c : x1 + ((size_t)b * HW + p) * C1 + (c - C0);
-      const vec_t h = *reinterpret_cast<const vec_t*>(src);
-#pragma unroll
-      for (int e = 0; e < VW; ++e) {
-        const float f = (float)h[e];
-        s += f;
-        q += f * f;
-      }
+    for (int e = 0; e < VW; ++e) {
+      const float f = (float)h[e];
+      s += f;
+      q += f * f;
     }
   }
   s = wave_sum(s);
@@ -360,14 +297,16 @@ __global__ __launch_bounds__(256) void groupnorm_fused_kernel(const half_t* __re
   const float mean = s * inv_n;
   const float rstd = rsqrtf(fmaxf(q * inv_n - mean * mean, 0.f) + eps);
   if (t < cpg) {
-    const float sc = rstd * gam;
+    const float sc = rstd * gamma[c0 + t];
     s_sc[t] = sc;
-    s_sh[t] = bet - mean * sc;
+    s_sh[t] = beta[c0 + t] - mean * sc;
   }
   __syncthreads();
-  auto emit = [&](int it, const vec_t& h) {
+  for (int it = t; it < items; it += 256) {
     const int p = it / nv, v = it - p * nv;
     const int c = c0 + v * VW;
+    const half_t* src = (c < C0) ? x0 + ((size_t)b * HW + p) * C0 + c : x1 + ((size_t)b * HW + p) * C1 + (c - C0);
+    const vec_t h = *reinterpret_cast<const vec_t*>(src);
     vec_t o;
 #pragma unroll
     for (int e = 0; e < VW; ++e) {
@@ -376,18 +315,6 @@ __global__ __launch_bounds__(256) void groupnorm_fused_kernel(const half_t* __re
       o[e] = (half_t)f;
     }
     *reinterpret_cast<vec_t*>(y + ((size_t)b * HW + p) * C + c) = o;
-  };
-  if constexpr (MAXV > 0) {
-#pragma unroll
-    for (int k = 0; k < MAXV; ++k)
-      if (t + 256 * k < items) emit(t + 256 * k, xr[k]);
-  } else {
-    for (int it = t; it < items; it += 256) {
-      const int p = it / nv, v = it - p * nv;
-      const int c = c0 + v * VW;
-      const half_t* src = (c < C0) ? x0 + ((size_t)b * HW + p) * C0 + c : x1 + ((size_t)b * HW + p) * C1 + (c - C0);
-      emit(it, *reinterpret_cast<const vec_t*>(src));
-    }
   }
 }
 
@@ -479,22 +406,12 @@ void launch_groupnorm(const half_t* x0, int C0, const half_t* x1, int C1, float*
   static const long fused_max_hw = getenv("SD_GN_FUSED_MAX_HW") ? atol(getenv("SD_GN_FUSED_MAX_HW")) : 256;
   if (HW <= fused_max_hw && cpg <= 128 && cpg % 2 == 0) {
     dim3 grid(G, B);
-    const int vw = cpg % 8 == 0 ? 8 : (cpg % 4 == 0 ? 4 : 2);
-    const int per_thread = cdiv(HW * (cpg / vw), 256);     // vectors each thread would hold
-#define SD_GN_FUSED(VW, MAXV) \
-  hipLaunchKernelGGL((groupnorm_fused_kernel<VW, MAXV>), grid, dim3(256), 0, s, x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu)
-    if (vw == 8) {
-      if (per_thread <= 4) SD_GN_FUSED(8, 4);
-      else if (per_thread <= 12) SD_GN_FUSED(8, 12);
-      else SD_GN_FUSED(8, 0);
-    } else if (vw == 4) {
-      if (per_thread <= 8) SD_GN_FUSED(4, 8);
-      else SD_GN_FUSED(4, 0);
-    } else {
-      if (per_thread <= 8) SD_GN_FUSED(2, 8);
-      else SD_GN_FUSED(2, 0);
-    }
-#undef SD_GN_FUSED
+    if (cpg % 8 == 0)
+      hipLaunchKernelGGL(groupnorm_fused_kernel<8>, grid, dim3(256), 0, s, x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu);
+    else if (cpg % 4 == 0)
+      hipLaunchKernelGGL(groupnorm_fused_kernel<4>, grid, dim3(256), 0, s, x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu);
+    else
+      hipLaunchKernelGGL(groupnorm_fused_kernel<2>, grid, dim3(256), 0, s, x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu);
     SD_HIP(hipGetLastError());
     return;
   }
