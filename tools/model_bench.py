@@ -54,4 +54,5 @@ if "--quick" not in sys.argv:
     run("SD1.5 control-UNet 512x512 (13 residual inputs)", ctrl, 64, extra=True)
     run("SD1.5 ControlNet 512x512", UNET_CONFIGS["runwayml/stable-diffusion-v1-5"], 64, kind="controlnet", impl="ORIGINAL", extra=True)
     run("SDXL-base UNet 768x768", "stabilityai/stable-diffusion-xl-base-1.0", 96)
+    run("SDXL-refiner UNet 768x768", "stabilityai/stable-diffusion-xl-refiner-1.0", 96)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "model_bench.json"), "w"), indent=1)

@@ -2,7 +2,8 @@
 """Measure the plan table of the conv / GEMM kernels IN SEQUENCE: every candidate (tile, LDS-DMA ring depth, split-K)
 is forced on all layers at once (sd_tune_set_candidate) and one profiled eager forward of the real SD2.1-base UNet
 (sd_unet_profile) times it on every layer shape with the caches as cold as they are inside the step.
-usage: SD_TUNE=1 python tools/tune_plans.py <out_table.inc> [<out_report.json>] [batch]
+usage: SD_TUNE=1 python tools/tune_plans.py <out_table.inc> [<out_report.json>] [batch] [model] [latent_size]
+       model: sd21 (default) | sdxl (SDXL-base UNet, text_time inputs) | sd15 (SD1.5 control-UNet + ControlNet shapes)
 The table lists, per shape key, the best candidate when it beats the current plan by more than 3 %."""
 import json
 import os
@@ -20,12 +21,19 @@ from python_hip_stable_diffusion import HipModel, _lib, checkpoint  # noqa: E402
 out_table = sys.argv[1]
 out_report = sys.argv[2] if len(sys.argv) > 2 else None
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-MODEL = "stabilityai/stable-diffusion-2-1-base"
+WHICH = sys.argv[4] if len(sys.argv) > 4 else "sd21"
+MODEL = {"sd21": "stabilityai/stable-diffusion-2-1-base", "sdxl": "stabilityai/stable-diffusion-xl-base-1.0",
+         "sd15": "runwayml/stable-diffusion-v1-5"}[WHICH]
+HW = int(sys.argv[5]) if len(sys.argv) > 5 else (96 if WHICH == "sdxl" else 64)
 ck = checkpoint.random_checkpoint(checkpoint.unet_param_shapes(MODEL), seed=0)
-m = HipModel(MODEL, ck, batch=B, attention_implementation="ORIGINAL", use_graph=False)
-x = np.random.RandomState(1).randn(B, 4, 64, 64).astype(np.float16)
-e = np.random.RandomState(2).randn(B, 1024, 1, 77).astype(np.float16)
+m = HipModel(MODEL, ck, batch=B, latent_height=HW, latent_width=HW, attention_implementation="ORIGINAL", use_graph=False)
+ctx = m.expected_inputs["encoder_hidden_states"]["shape"][1]
+x = np.random.RandomState(1).randn(B, 4, HW, HW).astype(np.float16)
+e = np.random.RandomState(2).randn(B, ctx, 1, 77).astype(np.float16)
 kw = dict(sample=x, timestep=np.full((B,), 951, np.float16), encoder_hidden_states=e)
+if "time_ids" in m.expected_inputs:
+    kw["time_ids"] = np.tile(np.array([[HW * 8, HW * 8, 0, 0, HW * 8, HW * 8]], np.float16), (B, 1))
+    kw["text_embeds"] = np.random.RandomState(3).randn(*m.expected_inputs["text_embeds"]["shape"]).astype(np.float16)
 ref = m(**kw)["noise_pred"]
 lib = _lib.lib()
 
@@ -77,8 +85,9 @@ for key, b_ms in sorted(base.items(), key=lambda kv: -kv[1]):
     report[key] = {"base_ms": b_ms, "best_ms": b_ms, "plan": None}
 with open(out_table, "w") as f:
     f.write("// Plan table: {kind, ksize, stride, up, Ctot, N, M, tile, staging, splitk}  (kind / staging: igemm.hip choose_plan,\n"
-            "// launch_tile).  Measured IN SEQUENCE on MI355X by tools/tune_plans.py (per-op HIP events of the eager SD2.1-base\n"
-            "// CFG-batch-%d step, caches as cold as in the step): entries beat the previous plan by more than 3 %%.\n" % B)
+            "// launch_tile).  Measured IN SEQUENCE on MI355X by tools/tune_plans.py (per-op HIP events of the eager\n"
+            "// CFG-batch-%d step of %s at %dx%d latents, caches as cold as in the step): entries beat the previous plan by > 3 %%.\n"
+            % (B, WHICH, HW, HW))
     f.write("\n".join(lines) + "\n")
 print(f"conv/GEMM ops per step: {total_base:.3f} ms with the current plans -> {total_best:.3f} ms with {len(lines)} new entries")
 if out_report:
