@@ -16,6 +16,7 @@
 // vector accesses with no cross-lane traffic.
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -755,7 +756,9 @@ constexpr size_t halo_lds_bytes(int bn, int d) {
   return ((size_t)2 * HALO_LDS_ROWS * BK + (size_t)d * bn * BK) * sizeof(half_t) + bn * sizeof(float);
 }
 // two workgroups per CU (two waves per SIMD, <= 256 VGPRs) wherever the LDS footprint allows it
-template <int BN, int D>
+// DBG (microbench-only instantiations, tools/ablate_halo.py): bit 0 no MFMAs, bit 1 no fragment reads, bit 2 no weight DMA
+// after the prologue, bit 3 no halo DMA after the prologue (results are garbage; only the time is read)
+template <int BN, int D, int DBG = 0>
 __global__ __launch_bounds__(256, halo_lds_bytes(BN, D) <= 80 * 1024 ? 2 : 1) void conv3x3_halo_kernel(IgemmArgs a) {
   constexpr int BM = 128, TM = 2, TN = BN / 64, WR = BN / 32;
   static_assert(halo_wait_count<D, WR>(1) <= 63 && (D - 2) * WR + 6 <= 63, "vmcnt range");
@@ -911,14 +914,19 @@ __global__ __launch_bounds__(256, halo_lds_bytes(BN, D) <= 80 * 1024 ? 2 : 1) vo
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           const int hr = hr0[i] + toff;
-          xf[kk][i] = *reinterpret_cast<const half8*>(xs + hr * BK + ((kc ^ ((hr >> 1) & 7)) * 8));
+          if constexpr ((DBG & 2) != 0) asm volatile("" : "=v"(xf[kk][i]));
+          else xf[kk][i] = *reinterpret_cast<const half8*>(xs + hr * BK + ((kc ^ ((hr >> 1) & 7)) * 8));
         }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) wf[kk][j] = *reinterpret_cast<const half8*>(ws + j * 32 * BK + ((kc ^ fsw) * 8));
+        for (int j = 0; j < TN; ++j) {
+          if constexpr ((DBG & 2) != 0) asm volatile("" : "=v"(wf[kk][j]));
+          else wf[kk][j] = *reinterpret_cast<const half8*>(ws + j * 32 * BK + ((kc ^ fsw) * 8));
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
-      issue_next_w();                                              // weight tile of step + D - 1
-      if (tap < HALO_PPW) issue_x_piece(tap, next_chunk ? ch + 1 : ch, xst ^ 1);   // always issued: uniform op count
+      if constexpr ((DBG & 4) == 0) issue_next_w();                // weight tile of step + D - 1
+      if constexpr ((DBG & 8) == 0)
+        if (tap < HALO_PPW) issue_x_piece(tap, next_chunk ? ch + 1 : ch, xst ^ 1);   // always issued: uniform op count
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // fragments in registers before the MFMAs (and before
       __builtin_amdgcn_sched_barrier(0);                           // the next barrier lets a DMA overwrite their stage)
 #pragma unroll
@@ -926,8 +934,10 @@ __global__ __launch_bounds__(256, halo_lds_bytes(BN, D) <= 80 * 1024 ? 2 : 1) vo
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kk][j], xf[kk][i], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j) {
+            if constexpr ((DBG & 1) != 0) asm volatile("" ::"v"(wf[kk][j]), "v"(xf[kk][i]));
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kk][j], xf[kk][i], acc[i][j], 0, 0, 0);
+          }
     }
   }
 
@@ -997,6 +1007,404 @@ __global__ __launch_bounds__(256, halo_lds_bytes(BN, D) <= 80 * 1024 ? 2 : 1) vo
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Software-pipelined, K-split variant of the halo kernel (plan tile 7).  Measured on the kernel above
+// (tools/ablate_halo.py, profiles/r02_ablate_halo.txt): ONE workgroup alone on a CU needs 23 us for its 45 tap
+// steps and every phase of a step is exposed - fragment reads 9-11 us, MFMAs 5 us, DMA issue 3 us, barriers and
+// launch 6.5 us - because a wave reads its fragments, waits for them and only then issues its MFMAs; overlap
+// exists only between two co-resident workgroups.  Here
+//   * the four waves are 2 (pixel halves) x 2 (K halves: 32 of the chunk's 64 channels each), so a wave owns a
+//     64-pixel x 64-channel accumulator tile: 8 ds_read_b128 per 8 MFMAs instead of 12 (every weight byte in LDS
+//     is read by two waves instead of four), the K halves are summed through LDS once, in the epilogue;
+//   * the fragments are double-buffered in registers: the reads of tap step s+1 and the DMA of step s+D are
+//     issued between the MFMAs of step s (one barrier per step, placed where every wave has drained its reads of
+//     step s, so the DMA may refill that ring stage at once: D-1 steps of lead);
+//   * the LDS swizzle is keyed on the halo COLUMN ((hx >> 1) & 7) instead of the linear halo row: the 16 lanes of a
+//     ds_read_b128 group then cover 16 consecutive columns under every tap shift - conflict-free (the row-keyed
+//     swizzle of the kernel above measures 40 % bank-conflict cycles, profiles/r02_sq_counters.json);
+//   * the DMA is buffer_load ... lds with a loop-invariant per-lane offset and a scalar running offset, the final chunk
+//     of the K range is a separate instantiation (no DMA past the end), and nothing in a tap step is conditional: one
+//     basic block per nine steps, so the interleaving above is what the scheduler emits.
+// ---------------------------------------------------------------------------------------------
+template <int D, int WR>
+constexpr int halo_ks_wait_count(int tap) {
+  // VMEM ops a wave has issued after the weight tile of step s+1 when it waits in step s (tap `tap`): per step, in
+  // order, [WR weight pieces of step s'+D] [one halo piece of the next chunk when tap(s') < HALO_PPW]
+  // (the halo piece issued in the same step as the awaited tile is waited for too: the count then does not depend on
+  // the order of the DMA instructions inside one step)
+  int n = 0;
+  for (int i = 2; i <= D - 1; ++i) n += WR + halo_x_issued(tap - D + i);
+  if (tap == 8 && n > 2 * WR) n = 2 * WR;   // the next chunk's halo (last piece went out at tap 5) is read right after
+  return n;
+}
+template <int D, int WR>
+__device__ __forceinline__ void halo_ks_wait(int tap) {
+  switch (tap) {
+    case 0: wait_vmcnt_barrier<halo_ks_wait_count<D, WR>(0)>(); break;
+    case 1: wait_vmcnt_barrier<halo_ks_wait_count<D, WR>(1)>(); break;
+    case 2: wait_vmcnt_barrier<halo_ks_wait_count<D, WR>(2)>(); break;
+    case 3: wait_vmcnt_barrier<halo_ks_wait_count<D, WR>(3)>(); break;
+    case 4: wait_vmcnt_barrier<halo_ks_wait_count<D, WR>(4)>(); break;
+    case 5: wait_vmcnt_barrier<halo_ks_wait_count<D, WR>(5)>(); break;
+    case 6: wait_vmcnt_barrier<halo_ks_wait_count<D, WR>(6)>(); break;
+    case 7: wait_vmcnt_barrier<halo_ks_wait_count<D, WR>(7)>(); break;
+    default: wait_vmcnt_barrier<halo_ks_wait_count<D, WR>(8)>(); break;
+  }
+}
+
+// ... in the final chunk of a workgroup's K range: weight tiles are issued only while they exist (tap + D < 9), no halo
+// pieces; steps before the chunk (u < 0) count as one full weight tile each (conservative: their halo pieces are waited for)
+template <int D, int WR>
+constexpr int halo_ks_wait_count_last(int tap) {
+  int n = 0;
+  for (int u = tap - D + 2; u <= tap - 1; ++u) n += (u < 0 || u + D < 9) ? WR : 0;
+  return n;
+}
+template <int D, int WR>
+__device__ __forceinline__ void halo_ks_wait_last(int tap) {
+  switch (tap) {
+    case 0: wait_vmcnt_barrier<halo_ks_wait_count_last<D, WR>(0)>(); break;
+    case 1: wait_vmcnt_barrier<halo_ks_wait_count_last<D, WR>(1)>(); break;
+    case 2: wait_vmcnt_barrier<halo_ks_wait_count_last<D, WR>(2)>(); break;
+    case 3: wait_vmcnt_barrier<halo_ks_wait_count_last<D, WR>(3)>(); break;
+    case 4: wait_vmcnt_barrier<halo_ks_wait_count_last<D, WR>(4)>(); break;
+    case 5: wait_vmcnt_barrier<halo_ks_wait_count_last<D, WR>(5)>(); break;
+    case 6: wait_vmcnt_barrier<halo_ks_wait_count_last<D, WR>(6)>(); break;
+    default: wait_vmcnt_barrier<halo_ks_wait_count_last<D, WR>(7)>(); break;
+  }
+}
+
+template <int D, int DBG = 0>
+__global__ __launch_bounds__(256, halo_lds_bytes(64, D) <= 80 * 1024 ? 2 : 1) void conv3x3_halo_ks_kernel(IgemmArgs a) {
+  constexpr int BN = 64, BM = 128, WR = 2, ROWB = BK * 2;   // ROWB: bytes per LDS row
+  static_assert(halo_ks_wait_count<D, WR>(1) <= 63 && (D - 1) * WR <= 63, "vmcnt range");
+  static_assert(halo_lds_bytes(64, D) >= 32 * 1024 + BM * (BN + 8) * 2 + BN * 4, "epilogue buffers fit the K-loop buffers");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Xh = smem;                                          // [2][HALO_LDS_ROWS][BK] halves
+  char* const Ws = smem + 2 * HALO_LDS_ROWS * ROWB;               // [D][BN][BK]
+  float* sconst = reinterpret_cast<float*>(Ws + D * BN * ROWB);   // [BN] bias + timestep-embedding row
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wk = wave & 1;
+  const int H = a.Hi, W = a.Wi;
+
+  const int n_tiles = (a.N + BN - 1) / BN;
+  const int m_tiles = a.B * a.tiles_y * a.tiles_x;
+  const int nwg = m_tiles * n_tiles;
+  int bid = blockIdx.x;
+  {
+    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    bid = base + idx;
+  }
+  const int bn_idx = bid / m_tiles, mt = bid % m_tiles;
+  const int b = mt / (a.tiles_y * a.tiles_x);
+  const int trem = mt - b * (a.tiles_y * a.tiles_x);
+  const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+  const int y0 = ty * 8, x0 = tx * 16;
+  const int n_blk = bn_idx * BN;
+
+  const int nch = a.Ctot / BK;
+  const int split = blockIdx.y;
+  const int ch_begin = split * a.nk_per_split;
+  int ch_end = ch_begin + a.nk_per_split;
+  if (ch_end > nch) ch_end = nch;
+
+  // DMA through buffer_load_dwordx4 ... lds: the per-lane part of an address is a loop-invariant 32-bit VGPR offset, the
+  // part that advances per tap / chunk is the scalar soffset, so a DMA instruction costs NO vector ALU work inside the
+  // tap loop (the 64-bit global_load_lds form needs ~6 VALU per piece; measured, tools/ablate_halo.py: DMA issue was
+  // the largest exposed cost of the loop, 4.4 of 16.8 us).  Rows outside the image read as zeros through the buffer
+  // range check (offset >= num_records -> 0); weight rows past N are clamped to row N-1 (their outputs are not stored).
+  constexpr unsigned kOob = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rs_w =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.w), 0, (int)((size_t)a.N * a.K * 2), 0x00020000);
+  const size_t xpix = (size_t)a.B * H * W;
+  unsigned hoff0[HALO_PPW], hoff1[HALO_PPW];            // byte offset of this lane's 16 bytes of halo piece j at channel 0
+#pragma unroll
+  for (int j = 0; j < HALO_PPW; ++j) {
+    const int p = (wave + 4 * j < HALO_PIECES) ? wave + 4 * j : HALO_PIECES - 1;
+    const int hr = 8 * p + (lane >> 3);
+    const int hy = hr / HALO_W, hx = hr - hy * HALO_W;
+    const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+    const bool ok = (hr < HALO_ROWS) && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    const unsigned pix = (unsigned)((b * H + iy) * W + ix);
+    const unsigned sw = (unsigned)(((lane & 7) ^ ((hx >> 1) & 7)) * 16);   // column-keyed swizzle
+    hoff0[j] = ok ? pix * (unsigned)a.C0 * 2u + sw : kOob;
+    hoff1[j] = ok ? pix * (unsigned)a.C1 * 2u + sw : kOob;
+  }
+  const int pchunk = tid & 7, lrow = tid >> 3;
+  const int wchunk = pchunk ^ ((lrow >> 1) & 7);
+  unsigned woff[WR];
+#pragma unroll
+  for (int i = 0; i < WR; ++i) {
+    int n = n_blk + lrow + 32 * i;
+    if (n > a.N - 1) n = a.N - 1;
+    woff[i] = (unsigned)n * (unsigned)a.K * 2u + (unsigned)wchunk * 16u;
+  }
+
+  // the halo of one channel chunk: which of the two concatenated sources it comes from is decided once per chunk
+  // (HALO_SRC declares rs / off[] / soff for chunk `ch`; a struct cannot hold the buffer resource type on the host pass)
+#define HALO_SRC(rs, off, soff, ch)                                                                                        \
+  const bool rs##_second = (ch) * BK >= a.C0; /* wave-uniform */                                                           \
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(                                                     \
+      const_cast<half_t*>(rs##_second ? a.x1 : a.x0), 0, (int)(xpix * (rs##_second ? a.C1 : a.C0) * 2), 0x00020000);       \
+  const int soff = (rs##_second ? (ch) * BK - a.C0 : (ch) * BK) * 2;                                                       \
+  unsigned off[HALO_PPW];                                                                                                  \
+  _Pragma("unroll") for (int j_ = 0; j_ < HALO_PPW; ++j_) off[j_] = rs##_second ? hoff1[j_] : hoff0[j_];
+  auto issue_x_piece = [&](int j, const __amdgpu_buffer_rsrc_t& rs, unsigned off, int soff, int xstage) {
+    if constexpr ((DBG & 8) != 0) return;
+    const int p = wave + 4 * j;
+    char* dst = Xh + xstage * (HALO_LDS_ROWS * ROWB) + (p < HALO_PIECES ? p : HALO_PIECES - 1) * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, off, soff, 0, 0);
+  };
+  const int total_steps = (ch_end - ch_begin) * 9;
+  int iw_koff = ch_begin * BK * 2, iw_tap = 0, iw_step = 0;   // issue cursor of the weight ring (koff in bytes)
+  auto issue_next_w = [&]() {
+    if constexpr ((DBG & 4) != 0) return;
+    char* ws = Ws + ((unsigned)iw_step % D) * (BN * ROWB) + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < WR; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(ws + i * 4096), 16, woff[i], iw_koff, 0, 0);
+    ++iw_step;
+    iw_koff += a.Ctot * 2;                                // next tap, same chunk
+    if (++iw_tap == 9) {
+      iw_tap = 0;
+      iw_koff += (BK - 9 * a.Ctot) * 2;                   // tap 0 of the next chunk
+    }
+  };
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frow = lane & 31, hi = lane >> 5;
+  // fragment byte offsets: this wave reads the 16-B chunks kc = 2 * (2 * wk + s) + hi, s = 0, 1 of every row
+  int hrb[2];                                             // halo row of this lane's pixel (tap (0,0)), in bytes
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ml = (wm * 2 + i) * 32 + frow;
+    hrb[i] = ((ml >> 4) * HALO_W + (ml & 15)) * ROWB;
+  }
+  const int hx0 = frow & 15;
+  int xsw[3][2], wsw[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int kc = 2 * (2 * wk + s) + hi;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) xsw[kx][s] = (kc ^ (((hx0 + kx) >> 1) & 7)) * 16;
+    wsw[s] = frow * ROWB + (kc ^ ((frow >> 1) & 7)) * 16;
+  }
+
+  float const_b = 0.f, const_t = 0.f;
+  if (a.splitk == 1 && tid < BN && n_blk + tid < a.N) {
+    if (a.bias) const_b = a.bias[n_blk + tid];
+    if (a.temb) const_t = a.temb[(size_t)b * a.temb_stride + n_blk + tid];
+  }
+
+  auto read_step = [&](half8 (&xf)[2][2], half8 (&wf)[2][2], const char* xs, const char* ws, int tap) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int toffb = (ky * HALO_W + kx) * ROWB;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if constexpr ((DBG & 2) != 0) asm volatile("" : "=v"(xf[s][i]));
+        else xf[s][i] = *reinterpret_cast<const half8*>(xs + hrb[i] + toffb + xsw[kx][s]);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if constexpr ((DBG & 2) != 0) asm volatile("" : "=v"(wf[s][j]));
+        else wf[s][j] = *reinterpret_cast<const half8*>(ws + j * 32 * ROWB + wsw[s]);
+      }
+    }
+  };
+  auto mfma_step = [&](half8 (&xf)[2][2], half8 (&wf)[2][2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if constexpr ((DBG & 1) != 0) asm volatile("" ::"v"(wf[s][j]), "v"(xf[s][i]));
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s][j], xf[s][i], acc[i][j], 0, 0, 0);
+        }
+  };
+
+  half8 xfA[2][2], wfA[2][2], xfB[2][2], wfB[2][2];
+  if (ch_begin < ch_end) {
+    HALO_SRC(rs0, off0, soff0, ch_begin)
+#pragma unroll
+    for (int j = 0; j < HALO_PPW; ++j) issue_x_piece(j, rs0, off0[j], soff0, 0);
+#pragma unroll
+    for (int p = 0; p < D; ++p) {
+      asm volatile("" ::: "memory");                      // keep the DMA issue order: the counted wait below relies on it
+      if (p < total_steps) issue_next_w();
+    }
+    if (total_steps >= D) wait_vmcnt_barrier<(D - 1) * WR>();   // the first halo and weight tile 0 have landed
+    else wait_vmcnt_barrier<0>();
+    read_step(xfA, wfA, Xh, Ws, 0);
+  }
+  int st = 0;
+  // One chunk = nine tap steps.  PAR = parity of the chunk's first step (which register set holds its fragments); LAST = the
+  // final chunk of this workgroup's K range: no next halo, no weight tiles past the end, the waits count what is left.
+  auto chunk = [&](auto par, auto last, int ch) {
+    constexpr int PAR = decltype(par)::value;
+    constexpr bool LAST = decltype(last)::value;
+    const int xst = (ch - ch_begin) & 1;
+    const bool first_chunk = ch == ch_begin;
+    HALO_SRC(rsn, offn, soffn, (LAST ? ch : ch + 1))
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap, ++st) {
+      auto body = [&](half8 (&cx)[2][2], half8 (&cw)[2][2], half8 (&nx)[2][2], half8 (&nw)[2][2]) {
+        if (LAST && tap == 8) {                           // the final step: nothing left to fetch
+          mfma_step(cx, cw);
+          return;
+        }
+        // this wave's fragment reads of step st are in registers: after the barrier NO wave reads ring stage st % D any more
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // weight tile st+1 (at tap 8: and the next halo) has landed
+        if constexpr (LAST) halo_ks_wait_last<D, WR>(tap);
+        else if (D > 4 && first_chunk) wait_vmcnt_barrier<(D - 2) * WR>();   // fewer halo pieces behind the tiles than in steady state
+        else halo_ks_wait<D, WR>(tap);
+        const int tapn = tap == 8 ? 0 : tap + 1;
+        const char* xs = Xh + (tap == 8 ? xst ^ 1 : xst) * (HALO_LDS_ROWS * ROWB);
+        const char* ws = Ws + ((unsigned)(st + 1) % D) * (BN * ROWB);
+        read_step(nx, nw, xs, ws, tapn);                  // fragments of step st+1 -> the other register set
+        const bool w_live = !LAST || tap + D < 9;
+        if (w_live) issue_next_w();                       // weight tile st+D -> stage st % D
+        const bool x_live = !LAST && tap < HALO_PPW;
+        if (x_live) issue_x_piece(tap, rsn, offn[tap < HALO_PPW ? tap : 0], soffn, xst ^ 1);
+        mfma_step(cx, cw);
+        // issue order: an MFMA, then two of the next step's reads ... the DMA pieces behind the later MFMAs
+        if constexpr (DBG == 0) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          }
+#pragma unroll
+          for (int g = 0; g < 3; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+      };
+      if (((tap + PAR) & 1) == 0) body(xfA, wfA, xfB, wfB);
+      else body(xfB, wfB, xfA, wfA);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  {
+    using T = std::true_type;
+    using F = std::false_type;
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    int ch = ch_begin;
+    for (; ch + 2 < ch_end; ch += 2) {
+      chunk(P0{}, F{}, ch);
+      chunk(P1{}, F{}, ch + 1);
+    }
+    if (ch + 2 == ch_end) {
+      chunk(P0{}, F{}, ch);
+      chunk(P1{}, T{}, ch + 1);
+    } else if (ch + 1 == ch_end) {
+      chunk(P0{}, T{}, ch);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();                                        // every wave is out of the K loop: LDS is free
+
+  // ---- epilogue.  acc[i][j][r]: n = j*32 + (r&3) + 8*(r>>2) + 4*hi ; pixel block 2*wm + i, pixel frow ----
+  // sum the two K halves: wave (wm, wk) keeps pixel block 2*wm + wk and hands the other one to its partner
+  {
+    floatx4* red = reinterpret_cast<floatx4*>(smem);      // [4 waves][2 j][4 q][64 lanes] = 32 KB
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        floatx4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = wk ? acc[0][j][4 * q + e] : acc[1][j][4 * q + e];
+        red[((wave * 2 + j) * 4 + q) * 64 + lane] = v;
+      }
+    if (tid < BN) sconst[tid] = const_b + const_t;
+    __syncthreads();
+  }
+  floatx16 fin[2];
+  {
+    const floatx4* red = reinterpret_cast<const floatx4*>(smem);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const floatx4 v = red[(((wave ^ 1) * 2 + j) * 4 + q) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fin[j][4 * q + e] = (wk ? acc[1][j][4 * q + e] : acc[0][j][4 * q + e]) + v[e];
+      }
+  }
+  const int ml = (wm * 2 + wk) * 32 + frow;               // tile-local pixel of this lane
+  if (a.splitk > 1) {
+    const int y = y0 + (ml >> 4), x = x0 + (ml & 15);
+    if (y < H && x < W) {
+      const int m = (b * H + y) * W + x;
+      float* prow = a.partial + ((size_t)split * a.M + m) * a.N;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n_blk + j * 32 + 8 * q + 4 * hi;
+          if (n < a.N) {
+            floatx4 v = {fin[j][4 * q], fin[j][4 * q + 1], fin[j][4 * q + 2], fin[j][4 * q + 3]};
+            *reinterpret_cast<floatx4*>(prow + n) = v;
+          }
+        }
+    }
+    return;
+  }
+  constexpr int OROW = BN + 8;
+  half_t* ot = reinterpret_cast<half_t*>(smem + 32 * 1024);   // [BM][OROW], behind the reduction buffer
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int nl = j * 32 + 8 * q + 4 * hi;
+      const floatx4 bb = *reinterpret_cast<const floatx4*>(sconst + nl);   // 0 beyond N
+      half4 o = {(half_t)(fin[j][4 * q] + bb[0]), (half_t)(fin[j][4 * q + 1] + bb[1]), (half_t)(fin[j][4 * q + 2] + bb[2]),
+                 (half_t)(fin[j][4 * q + 3] + bb[3])};
+      *reinterpret_cast<half4*>(ot + ml * OROW + nl) = o;
+    }
+  __syncthreads();
+  constexpr int WC = BN / 8;
+  for (int idx = tid; idx < BM * WC; idx += 256) {
+    const int r = idx / WC, c = idx - r * WC;
+    const int y = y0 + (r >> 4), x = x0 + (r & 15);
+    const int n = n_blk + c * 8;
+    if (y < H && x < W && n < a.N) {
+      const size_t m = (size_t)(b * H + y) * W + x;
+      half8 v = *reinterpret_cast<const half8*>(ot + r * OROW + c * 8);
+      half_t* dst = a.out + m * a.N + n;
+      if (n + 8 <= a.N) {
+        if (a.res) {
+          const half8 rr = *reinterpret_cast<const half8*>(a.res + m * a.N + n);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
+        }
+        *reinterpret_cast<half8*>(dst) = v;
+      } else {
+        for (int e = 0; e < a.N - n; ++e) dst[e] = a.res ? (half_t)((float)v[e] + (float)a.res[m * a.N + n + e]) : v[e];
+      }
+    }
+  }
+}
+
+#undef HALO_SRC
 
 // split-K combine + the same epilogue (bias, temb broadcast, residual) -> fp16
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmArgs a) {
@@ -1241,6 +1649,7 @@ void tile_dims(int tile, int& bm, int& bn) {
   switch (tile) {
     case 5: bm = 128; bn = 128; break;   // halo kernel, 8x16-pixel tile
     case 6: bm = 128; bn = 64; break;
+    case 7: bm = 128; bn = 64; break;    // halo, K-split waves + register double buffering
     case 1: bm = 128; bn = 128; break;
     case 2: bm = 128; bn = 64; break;
     case 3: bm = 64; bn = 64; break;
@@ -1310,9 +1719,9 @@ Plan choose_plan(const ConvDesc& d, const IgemmArgs& a) {
   const bool geglu = d.out_mode == kOutGeglu;
   // the LayerNorm fold needs whole rows per workgroup, the fused q|k|v epilogue has no slab path
   const bool can_split = d.out_mode == kOutHalf && !d.ln_colsum && !d.out_t;
-  auto is_halo = [](int c) { return c == 5 || c == 6; };
+  auto is_halo = [](int c) { return c == 5 || c == 6 || c == 7; };
   auto tile_ok = [&](int c) {
-    if (c < 1 || c > 6) return false;
+    if (c < 1 || c > 7) return false;
     if (is_halo(c)) return halo_ok(d) && !d.ln_colsum && !d.out_t && !geglu;
     int bm, bn;
     tile_dims(c, bm, bn);
@@ -1390,6 +1799,15 @@ void launch_halo_d(const IgemmArgs& a, hipStream_t s) {
 
 // staging (the table's ring code): 0 = 2 weight stages (two workgroups per CU), 2 / 3 = 3 / 4 stages,
 // 4 / 5 = 6 / 8 stages (BN = 64 only: 8-KB stages); deeper rings keep more weight bytes in flight per CU
+template <int DBG>
+void launch_halo_dbg(const IgemmArgs& a, hipStream_t s) {
+  const size_t lds = halo_lds_bytes(64, 4);
+  auto k = conv3x3_halo_kernel<64, 4, DBG>;
+  SD_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  dim3 grid(a.B * a.tiles_x * a.tiles_y * cdiv(a.N, 64), a.splitk);
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+}
+
 template <int BN>
 void launch_halo(IgemmArgs a, int splitk, int staging, hipStream_t s) {
   const int nch = a.Ctot / BK;
@@ -1397,12 +1815,66 @@ void launch_halo(IgemmArgs a, int splitk, int staging, hipStream_t s) {
   a.nk_per_split = cdiv(nch, splitk);
   a.splitk = cdiv(nch, a.nk_per_split);
   if constexpr (BN == 64) {
+    if (a.debug >= 32) {   // ablation builds of the BN = 64, 4-stage kernel: debug = 32 + DBG bits
+      switch (a.debug - 32) {
+        case 1: launch_halo_dbg<1>(a, s); return;
+        case 2: launch_halo_dbg<2>(a, s); return;
+        case 3: launch_halo_dbg<3>(a, s); return;
+        case 4: launch_halo_dbg<4>(a, s); return;
+        case 8: launch_halo_dbg<8>(a, s); return;
+        case 12: launch_halo_dbg<12>(a, s); return;
+        case 13: launch_halo_dbg<13>(a, s); return;
+        case 14: launch_halo_dbg<14>(a, s); return;
+        case 15: launch_halo_dbg<15>(a, s); return;
+        default: break;
+      }
+    }
+  }
+  if constexpr (BN == 64) {
     if (staging >= 5) { launch_halo_d<BN, 8>(a, s); return; }
     if (staging >= 4) { launch_halo_d<BN, 6>(a, s); return; }
   }
   if (staging >= 3) { launch_halo_d<BN, 4>(a, s); return; }
   if (staging >= 2) { launch_halo_d<BN, 3>(a, s); return; }
   launch_halo_d<BN, 2>(a, s);
+}
+
+template <int D, int DBG = 0>
+void launch_halo_ks_d(const IgemmArgs& a, hipStream_t s) {
+  const size_t lds = halo_lds_bytes(64, D);
+  static_assert(halo_lds_bytes(64, D) <= 160 * 1024, "LDS");
+  auto k = conv3x3_halo_ks_kernel<D, DBG>;
+  static DynLdsOnce once;
+  once.set(k, lds);
+  dim3 grid(a.B * a.tiles_x * a.tiles_y * cdiv(a.N, 64), a.splitk);
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+}
+
+// plan tile 7; ring code as launch_halo (0 / 2 / 3 / 4 / 5 = 2 / 3 / 4 / 6 / 8 weight stages)
+void launch_halo_ks(IgemmArgs a, int splitk, int staging, hipStream_t s) {
+  const int nch = a.Ctot / BK;
+  a.nk_total = nch;
+  a.nk_per_split = cdiv(nch, splitk);
+  a.splitk = cdiv(nch, a.nk_per_split);
+  if (a.debug >= 32) {   // ablation builds of the 4-stage kernel: debug = 32 + DBG bits
+    switch (a.debug - 32) {
+      case 1: launch_halo_ks_d<4, 1>(a, s); return;
+      case 2: launch_halo_ks_d<4, 2>(a, s); return;
+      case 3: launch_halo_ks_d<4, 3>(a, s); return;
+      case 4: launch_halo_ks_d<4, 4>(a, s); return;
+      case 8: launch_halo_ks_d<4, 8>(a, s); return;
+      case 12: launch_halo_ks_d<4, 12>(a, s); return;
+      case 13: launch_halo_ks_d<4, 13>(a, s); return;
+      case 14: launch_halo_ks_d<4, 14>(a, s); return;
+      case 15: launch_halo_ks_d<4, 15>(a, s); return;
+      default: break;
+    }
+  }
+  if (staging >= 5) { launch_halo_ks_d<8>(a, s); return; }
+  if (staging >= 4) { launch_halo_ks_d<6>(a, s); return; }
+  if (staging >= 3) { launch_halo_ks_d<4>(a, s); return; }
+  if (staging >= 2) { launch_halo_ks_d<3>(a, s); return; }
+  launch_halo_ks_d<2>(a, s);
 }
 
 template <int BM, int BN, int WGM, int WGN, bool TRANS, bool GLDS, int NST, bool LNF = false, bool PIPE = false>
@@ -1520,7 +1992,7 @@ void launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
              kInvalidArgument, "fused q|k|v: n_trans %d N %d HoWo %d ldT %d", d.n_trans, d.N, d.Ho * d.Wo, d.ldT);
   IgemmArgs a = make_args(d);
   Plan p = choose_plan(d, a);
-  const bool halo = p.tile == 5 || p.tile == 6;
+  const bool halo = p.tile == 5 || p.tile == 6 || p.tile == 7;
   if (halo) {
     const int nch = a.Ctot / BK;
     a.nk_per_split = cdiv(nch, p.splitk);
@@ -1544,6 +2016,7 @@ void launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
             a.C0, a.C1, a.M, a.N, a.K, d.out_mode, p.tile, a.splitk);
   if (halo) {
     if (p.tile == 5) launch_halo<128>(a, a.splitk, st, s);
+    else if (p.tile == 7) launch_halo_ks(a, a.splitk, st, s);
     else launch_halo<64>(a, a.splitk, st, s);
   } else if (d.debug) {   // ablation builds exist for two tiles only (tools/prof_conv.py)
     const bool ok = p.tile == 1 ? launch_debug_mode<128, 128>(a, d.debug, s) : launch_debug_mode<64, 64>(a, d.debug, s);

@@ -217,7 +217,8 @@ def test_conv2d_every_tile_and_splitk(tile, splitk):
     close(gen, conv_ref(x, w, bias, res, 1, False), "generic conv")
 
 
-@pytest.mark.parametrize("tile", [5, 6, 25, 26, 35, 36, 46, 56])      # tile // 10 = weight-ring code (3 / 4 / 6 / 8 stages)
+# tile % 10: 5 / 6 = halo BN 128 / 64, 7 = K-split software-pipelined halo; tile // 10 = weight-ring code (3 / 4 / 6 / 8 stages)
+@pytest.mark.parametrize("tile", [5, 6, 25, 26, 35, 36, 46, 56, 7, 27, 37, 47, 57])
 @pytest.mark.parametrize("splitk", [0, 1, 2, 3])
 @pytest.mark.parametrize("shape", [(2, 128, 16, 16, 128), (1, 64, 24, 40, 96), (2, 320, 32, 32, 320), (1, 192, 9, 17, 68)],
                          ids=lambda s: "x".join(map(str, s)))
@@ -256,7 +257,7 @@ def test_timestep_embedding_reference_golden():
     np.testing.assert_allclose(_lib.timestep_embedding(ts, 256), unet_ref.timestep_embedding(torch.from_numpy(ts), 256).numpy(), atol=1e-4)
 
 
-@pytest.mark.parametrize("tile,splitk", [(3, 8), (33, 16), (6, 4), (26, 2), (1, 4)])
+@pytest.mark.parametrize("tile,splitk", [(3, 8), (33, 16), (6, 4), (26, 2), (1, 4), (37, 2), (7, 1)])
 def test_splitk_is_complete_and_bit_reproducible(tile, splitk):
     """Split-K: fp32 slabs per K slice, combined in slice order by the reduce kernel (no atomics): repeated launches
     must agree bit for bit, and with torch.  A weight-streaming shape (M = 128 rows, K = 11520), up to 16 slices.
