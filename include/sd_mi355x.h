@@ -145,6 +145,11 @@ int sd_unet_profile(sd_unet* u, int iters, int cap, float* ms, double* flop, cha
  * forward measures a candidate on every layer shape in sequence (tools/tune_plans.py).  tile = 0 switches it off.
  * Process-global; never set in production. */
 int sd_tune_set_candidate(int tile, int staging, int splitk);
+/* Measurement hook: replace the run-time plan table (consulted before the compiled-in one; same rows as
+ * csrc/tuned_convs.inc, one "{kind, ksize, stride, up, Ctot, N, M, tile, staging, splitk}" per line; NULL = empty) and, when
+ * `u` is given, drop its captured HIP graphs so that the next forward re-captures with the new plans.  tools/tune_e2e.py
+ * uses it to judge a plan by the graph-replay time of the WHOLE step instead of a per-kernel timing.  Process-global. */
+int sd_tune_set_plan_table(const char* rows, sd_unet* u, int* n_plans);
 
 /* Device-resident denoising loop (pipeline.py:500-573 with latents, CFG combine and scheduler
  * update never leaving HBM; Swift twin StableDiffusionPipeline.swift:233-333 incl. imageCount > 1).

@@ -173,6 +173,13 @@ int sd_unet_set_attention(sd_unet* u, int impl) {
     u->impl->set_attention(impl);
   });
 }
+int sd_tune_set_plan_table(const char* rows, sd_unet* u, int* n_plans) {
+  return guarded([&] {
+    const int n = conv_plan_table_set(rows);
+    if (n_plans) *n_plans = n;
+    if (u) u->impl->drop_graphs();   // the captured launches bake the old plans in
+  });
+}
 int sd_unet_num_residuals(const sd_unet* u) { return u ? u->impl->num_residuals() : 0; }
 size_t sd_unet_device_bytes(const sd_unet* u) { return u ? u->impl->device_bytes() : 0; }
 
@@ -200,7 +207,7 @@ int sd_unet_denoise_loop(sd_unet* u, const sd_unet_io* io, float* latents, int n
 
 int sd_tune_set_candidate(int tile, int staging, int splitk) {
   return guarded([&] {
-    SD_REQUIRE(tile >= 0 && tile <= 7 && staging >= 0 && staging <= 7 && splitk >= 0 && splitk <= 64, kInvalidArgument,
+    SD_REQUIRE(tile >= 0 && tile <= 7 && staging >= 0 && staging <= 8 && splitk >= 0 && splitk <= 64, kInvalidArgument,
                "tune candidate (tile %d, staging %d, splitk %d)", tile, staging, splitk);
     conv_tune_set_candidate(tile, staging, splitk);
   });

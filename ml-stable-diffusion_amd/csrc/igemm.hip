@@ -16,6 +16,8 @@
 // vector accesses with no cross-lane traffic.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <string>
 #include <type_traits>
 
 #include "kernels.h"
@@ -84,16 +86,174 @@ __device__ __forceinline__ float xor32_sum(float v) {
   return __uint_as_float(r0) + __uint_as_float(r1);
 }
 
+// buffer_load_dwordx4 ... lds (16 bytes per lane straight into LDS; M0 carries the wave-uniform LDS base).  hipcc's HOST pass
+// checks the 16-byte form against a target without the gfx950 feature and then silently drops the enclosing kernel's stub,
+// so the builtin is only visible to the device pass.
+__device__ __forceinline__ void dma16_to_lds(const __amdgpu_buffer_rsrc_t& rs, char* lds, unsigned voffset, int soffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, voffset, soffset, 0, 0);
+#endif
+}
+
+// Tile epilogue shared by the GEMM kernels: acc[i][j] is the 32x32 block (pixel block (wm*TM+i), channel block (wn*TN+j)) of
+// a BM x BN tile owned by wave (wm, wn) of a WGM x WGN wave grid, in the transposed MFMA layout
+// n = n0 + (r&3) + 8*(r>>2) + 4*hi ; m = m0 + (lane&31).  Split-K slabs, or bias / timestep embedding / LayerNorm fold /
+// GEGLU / residual / fused q|k|v write-out staged through LDS (`smem` is free: the caller's K loop is over and every wave
+// has passed a barrier after its last fragment read - this function starts with its own barrier for that).
+template <int BM, int BN, int WGM, int WGN, int TM, int TN, bool LNF>
+__device__ __forceinline__ void tile_epilogue(const IgemmArgs& a, floatx16 (&acc)[TM][TN], const float (&ln_a)[TM],
+                                              const float (&ln_b)[TM], char* smem, float* sconst, float const_b, float const_t,
+                                              float const_c, int m_blk, int n_blk, int wave, int split, bool temb_uniform) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int frow = lane & 31, hi = lane >> 5;
+  // acc[i][j][r]: n = n0 + (r&3) + 8*(r>>2) + 4*hi ; m = m0 + (lane&31)
+  if (a.splitk > 1) {   // fp32 partial slabs; bias/temb/residual are applied by splitk_reduce_kernel
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m_blk + (wm * TM + i) * 32 + frow;
+      if (m >= a.M) continue;
+      float* prow = a.partial + ((size_t)split * a.M + m) * a.N;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n_blk + (wn * TN + j) * 32 + 8 * q + 4 * hi;
+          if (n < a.N) {
+            floatx4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            *reinterpret_cast<floatx4*>(prow + n) = v;
+          }
+        }
+    }
+  } else {
+    // Stage the finished tile through LDS (free after the K loop) so that the global stores - and
+    // the residual loads - are whole 16-B-per-lane row segments instead of 32 scattered 16-B pieces
+    // per instruction (the scattered form cost ~11k cycles per 128x128 tile, prof_conv).
+    const bool geglu = a.out_mode == kOutGeglu;
+    constexpr int OW = BN;                 // staged tile width in halves (GEGLU uses the first BN/2)
+    constexpr int OROW = OW + 8;           // +16 B pad: conflict-free 16-B reads
+    constexpr int TROW = BM + 8;           // transposed staging (fused q|k|v: the V^T columns), [BN][TROW]
+    half_t* ot = reinterpret_cast<half_t*>(smem);   // [BM][OROW] or [BN][TROW]  (<= the K-loop buffers)
+    const bool tblock = n_blk >= a.n_trans;         // block-uniform
+    if (tid < BN) {
+      sconst[tid] = const_b + const_t;
+      if constexpr (LNF) sconst[BN + tid] = const_c;
+    }
+    __syncthreads();                       // every wave is done with its last fragment reads; sconst is visible
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int ml = (wm * TM + i) * 32 + frow;
+      const int m = m_blk + ml;
+      const int b = (m < a.M) ? m / a.HoWo : 0;
+      if (geglu) {
+        if constexpr (TN % 2 == 0) {
+#pragma unroll
+          for (int j = 0; j < TN; j += 2)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int nl = (wn * TN + j) * 32 + 8 * q + 4 * hi;          // value rows (interleaved W)
+              half4 o;
+              const floatx4 bv4 = *reinterpret_cast<const floatx4*>(sconst + nl);        // 0 beyond N
+              const floatx4 bg4 = *reinterpret_cast<const floatx4*>(sconst + nl + 32);
+              floatx4 cv4 = {0.f, 0.f, 0.f, 0.f}, cg4 = {0.f, 0.f, 0.f, 0.f};
+              if constexpr (LNF) {
+                cv4 = *reinterpret_cast<const floatx4*>(sconst + BN + nl);
+                cg4 = *reinterpret_cast<const floatx4*>(sconst + BN + nl + 32);
+              }
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float v, g;
+                if constexpr (LNF) {
+                  v = fmaf(acc[i][j][4 * q + e], ln_a[i], fmaf(ln_b[i], cv4[e], bv4[e]));
+                  g = fmaf(acc[i][j + 1][4 * q + e], ln_a[i], fmaf(ln_b[i], cg4[e], bg4[e]));
+                } else {
+                  v = acc[i][j][4 * q + e] + bv4[e];
+                  g = acc[i][j + 1][4 * q + e] + bg4[e];
+                }
+                o[e] = (half_t)(v * gelu_erf(g));
+              }
+              *reinterpret_cast<half4*>(ot + ml * OROW + (wn * TN + j) * 16 + 8 * q + 4 * hi) = o;
+            }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int nl = (wn * TN + j) * 32 + 8 * q + 4 * hi;
+            const int n = n_blk + nl;
+            float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            const floatx4 bb = *reinterpret_cast<const floatx4*>(sconst + nl);            // bias (+ temb), 0 beyond N
+            if constexpr (LNF) {
+              const floatx4 cs = *reinterpret_cast<const floatx4*>(sconst + BN + nl);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], ln_a[i], fmaf(ln_b[i], cs[e], bb[e]));
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += bb[e];
+            }
+            if (a.temb && !temb_uniform && n < a.N) {   // tile straddles samples (HoWo < BM): per-row sample index
+              floatx4 tt = *reinterpret_cast<const floatx4*>(a.temb + (size_t)b * a.temb_stride + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += tt[e];
+            }
+            half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            if (tblock) {   // V^T columns: staged [n][m] so the write-out rows are token-contiguous
+#pragma unroll
+              for (int e = 0; e < 4; ++e) ot[(nl + e) * TROW + ml] = o[e];
+            } else {
+              *reinterpret_cast<half4*>(ot + ml * OROW + nl) = o;
+            }
+          }
+      }
+    }
+    __syncthreads();
+    if (tblock) {   // out_t[b][n - n_trans][s]: 8 consecutive tokens of one image per 16-B store
+      const int NV = a.N - a.n_trans;
+      for (int idx = tid; idx < BN * (BM / 8); idx += 256) {
+        const int r = idx / (BM / 8), c = idx - r * (BM / 8);
+        const int nv = n_blk + r - a.n_trans, m = m_blk + c * 8;
+        if (nv < NV && m < a.M) {
+          const int b = m / a.HoWo, sp = m - b * a.HoWo;
+          *reinterpret_cast<half8*>(a.out_t + ((size_t)b * NV + nv) * a.ldT + sp) =
+              *reinterpret_cast<const half8*>(ot + r * TROW + c * 8);
+        }
+      }
+      return;
+    }
+    const int NO = geglu ? (a.N >> 1) : a.ldo;            // output row length
+    const int nb0 = geglu ? (n_blk >> 1) : n_blk;         // first output column of this tile
+    constexpr int OWC = OW / 8;                           // 16-B chunks per staged row (GEGLU: first half used)
+    const int wc = geglu ? OWC / 2 : OWC;
+    for (int idx = tid; idx < BM * wc; idx += 256) {
+      const int r = idx / wc, c = idx - r * wc;
+      const int m = m_blk + r, n = nb0 + c * 8;
+      if (m < a.M && n < NO) {
+        half8 v = *reinterpret_cast<const half8*>(ot + r * OROW + c * 8);
+        half_t* dst = a.out + (size_t)m * NO + n;
+        if (n + 8 <= NO) {
+          if (a.res) {
+            const half8 rr = *reinterpret_cast<const half8*>(a.res + (size_t)m * NO + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
+          }
+          *reinterpret_cast<half8*>(dst) = v;
+        } else {   // ragged last chunk (N % 8 == 4)
+          for (int e = 0; e < NO - n; ++e) dst[e] = a.res ? (half_t)((float)v[e] + (float)a.res[(size_t)m * NO + n + e]) : v[e];
+        }
+      }
+    }
+  }
+}
+
 // One 256-thread workgroup = 4 wavefronts laid out WGM x WGN over a BM x BN tile.
 // GLDS = true: tiles go HBM -> LDS directly (global_load_lds_dwordx4, no VGPR round trip and no
 // ds_write pass: the write pass was ~60 % of the LDS-pipe time of the register-staged version).
 // The DMA writes lane-linear 1-KiB pieces (8 rows x 128 B), so the bank swizzle lives on the
 // per-lane SOURCE address: physical 16-B chunk p of row r holds logical chunk p ^ ((r >> 1) & 7),
 // and fragment reads apply the same XOR (conflict-free ds_read_b128, cdna guide rule 21).
-template <int BM, int BN, int WGM, int WGN, bool TRANS_OUT, bool GLDS, int NST, int DBG = 0, bool LNF = false,
-          bool PIPE = false>
+template <int BM, int BN, int WGM, int WGN, bool TRANS_OUT, bool GLDS, int NST, int DBG = 0, bool LNF = false>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
-  static_assert(!PIPE || (GLDS && NST >= 3 && DBG == 0), "the software-pipelined loop is a variant of the LDS-DMA ring");
   static_assert(WGM * WGN == 4, "4 waves");
   static_assert(!(LNF && TRANS_OUT), "LayerNorm fold uses the in-lane row layout of the non-transposed tile");
   constexpr int TM = BM / WGM / 32;   // 32x32 MFMA tiles per wave along m
@@ -357,101 +517,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   }
 
   if (prof) prof_t[1] = clock64();
-  if constexpr (PIPE) {
-    // Software-pipelined ring: while the 16 MFMAs of tile kt run from one fragment register set, the 16 ds_read_b128 of
-    // tile kt+1 fill the other set and the DMA of tile kt+NST-1 is issued - LDS reads, DMA issue and MFMAs of ONE wave
-    // overlap instead of alternating (the plain ring leaves that overlap to a second workgroup on the CU).  Tile kt+1
-    // must therefore have landed when step kt starts: one tile less DMA lead than the plain ring of the same depth.
-    constexpr int PER_TILE = XR + WR;
-    constexpr int DEPTH = NST - 3;      // tiles newer than kt+1 that may still be in flight at the wait of step kt
-    static_assert(DEPTH * PER_TILE <= 63 && (NST - 2) * PER_TILE <= 63, "vmcnt range");
-    half8 xg[BK / 16][TM] = {}, wg[BK / 16][TN] = {};   // the second fragment set
-    const int nk = kt_end - kt_begin;
-    auto wait_tiles = [&](int fly) {    // at most `fly` newer tiles outstanding, then the workgroup barrier
-      if (NST - 2 >= 4 && fly >= 4) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NST - 2 >= 4 ? 4 : 0) * PER_TILE) : "memory");
-      else if (NST - 2 >= 3 && fly == 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NST - 2 >= 3 ? 3 : 0) * PER_TILE) : "memory");
-      else if (NST - 2 >= 2 && fly == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NST - 2 >= 2 ? 2 : 0) * PER_TILE) : "memory");
-      else if (fly == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PER_TILE) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    };
-    auto frag_ptrs = [&](int buf, const half_t*& xs, const half_t*& ws) {
-      xs = Xs + buf * BM * ROW + (wm * TM * 32 + frow) * ROW;
-      ws = Ws + buf * BN * ROW + (wn * TN * 32 + frow) * ROW;
-    };
-#pragma unroll
-    for (int p = 0; p < NST - 1; ++p)
-      if (p < nk) load_tile(p);
-    {
-      const int newer = nk - 1 < NST - 2 ? nk - 1 : NST - 2;
-      wait_tiles(newer > 4 ? 4 : newer);              // tile 0 has landed (an under-estimate only waits longer)
-      const half_t *xs, *ws;
-      frag_ptrs(0, xs, ws);
-#pragma unroll
-      for (int kk = 0; kk < BK / 16; ++kk) {
-        const int koff = ((kk * 2 + (lane >> 5)) ^ fsw) * 8;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) xf[kk][i] = *reinterpret_cast<const half8*>(xs + i * 32 * ROW + koff);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) wf[kk][j] = *reinterpret_cast<const half8*>(ws + j * 32 * ROW + koff);
-      }
-    }
-    // one step: compute tile `rel` from (cx, cw) while (nx, nw) receive tile rel + 1
-    auto step = [&](int rel, half8 (&cx)[BK / 16][TM], half8 (&cw)[BK / 16][TN], half8 (&nx)[BK / 16][TM],
-                    half8 (&nw)[BK / 16][TN]) {
-      const bool has_next = rel + 1 < nk;
-      const half_t *xs = Xs, *ws = Ws;
-      if (has_next) {
-        const int newer = nk - 2 - rel < DEPTH ? nk - 2 - rel : DEPTH;
-        wait_tiles(newer);                            // tile rel + 1 has landed for every wave; tile rel - 1 is consumed
-        frag_ptrs((rel + 1) % NST, xs, ws);
-      }
-      if (rel + NST - 1 < nk) load_tile((rel + NST - 1) % NST);
-      auto mfma_slice = [&](int kk) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            if constexpr (TRANS_OUT)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cx[kk][i], cw[kk][j], acc[i][j], 0, 0, 0);
-            else
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cw[kk][j], cx[kk][i], acc[i][j], 0, 0, 0);
-          }
-        if constexpr (LNF) {
-          const half2v one2 = {(half_t)1.f, (half_t)1.f};
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const half2v p2 = {cx[kk][i][2 * e], cx[kk][i][2 * e + 1]};
-              ln_s2[i] = __builtin_amdgcn_fdot2(p2, p2, ln_s2[i], false);
-              ln_s1[i] = __builtin_amdgcn_fdot2(p2, one2, ln_s1[i], false);
-            }
-        }
-      };
-      if (has_next) {
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-          const int koff = ((kk * 2 + (lane >> 5)) ^ fsw) * 8;
-#pragma unroll
-          for (int i = 0; i < TM; ++i) nx[kk][i] = *reinterpret_cast<const half8*>(xs + i * 32 * ROW + koff);
-#pragma unroll
-          for (int j = 0; j < TN; ++j) nw[kk][j] = *reinterpret_cast<const half8*>(ws + j * 32 * ROW + koff);
-          mfma_slice(kk);
-          // keep the issue order "reads of the next tile, then this k-slice's MFMAs" (the scheduler would otherwise
-          // cluster all reads or sink them behind the MFMAs)
-          __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
-        }
-      } else {
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) mfma_slice(kk);
-      }
-    };
-    for (int rel = 0; rel < nk; rel += 2) {
-      step(rel, xf, wf, xg, wg);
-      if (rel + 1 < nk) step(rel + 1, xg, wg, xf, wf);
-    }
-  } else if constexpr (GLDS && NST >= 3) {
+  if constexpr (GLDS && NST >= 3) {
     // NST-stage ring: the DMA of tile kt+NST-1 is issued while tile kt is computed and tiles
     // kt+1 .. kt+NST-2 are still in flight (weight-streaming layers need the bytes in flight: at the
     // 8x8 / 16x16 levels every K step of a two-stage loop is one exposed HBM round trip).
@@ -559,143 +625,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
       }
     return;
   } else {
-    // acc[i][j][r]: n = n0 + (r&3) + 8*(r>>2) + 4*hi ; m = m0 + (lane&31)
-    if (a.splitk > 1) {   // fp32 partial slabs; bias/temb/residual are applied by splitk_reduce_kernel
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int m = m_blk + (wm * TM + i) * 32 + frow;
-        if (m >= a.M) continue;
-        float* prow = a.partial + ((size_t)split * a.M + m) * a.N;
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int n = n_blk + (wn * TN + j) * 32 + 8 * q + 4 * hi;
-            if (n < a.N) {
-              floatx4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-              *reinterpret_cast<floatx4*>(prow + n) = v;
-            }
-          }
-      }
-    } else {
-      // Stage the finished tile through LDS (free after the K loop) so that the global stores - and
-      // the residual loads - are whole 16-B-per-lane row segments instead of 32 scattered 16-B pieces
-      // per instruction (the scattered form cost ~11k cycles per 128x128 tile, prof_conv).
-      const bool geglu = a.out_mode == kOutGeglu;
-      constexpr int OW = BN;                 // staged tile width in halves (GEGLU uses the first BN/2)
-      constexpr int OROW = OW + 8;           // +16 B pad: conflict-free 16-B reads
-      constexpr int TROW = BM + 8;           // transposed staging (fused q|k|v: the V^T columns), [BN][TROW]
-      half_t* ot = reinterpret_cast<half_t*>(smem);   // [BM][OROW] or [BN][TROW]  (<= the K-loop buffers)
-      const bool tblock = n_blk >= a.n_trans;         // block-uniform
-      if (tid < BN) {
-        sconst[tid] = const_b + const_t;
-        if constexpr (LNF) sconst[BN + tid] = const_c;
-      }
-      __syncthreads();                       // every wave is done with its last fragment reads; sconst is visible
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int ml = (wm * TM + i) * 32 + frow;
-        const int m = m_blk + ml;
-        const int b = (m < a.M) ? m / a.HoWo : 0;
-        if (geglu) {
-          if constexpr (TN % 2 == 0) {
-#pragma unroll
-            for (int j = 0; j < TN; j += 2)
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const int nl = (wn * TN + j) * 32 + 8 * q + 4 * hi;          // value rows (interleaved W)
-                half4 o;
-                const floatx4 bv4 = *reinterpret_cast<const floatx4*>(sconst + nl);        // 0 beyond N
-                const floatx4 bg4 = *reinterpret_cast<const floatx4*>(sconst + nl + 32);
-                floatx4 cv4 = {0.f, 0.f, 0.f, 0.f}, cg4 = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (LNF) {
-                  cv4 = *reinterpret_cast<const floatx4*>(sconst + BN + nl);
-                  cg4 = *reinterpret_cast<const floatx4*>(sconst + BN + nl + 32);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  float v, g;
-                  if constexpr (LNF) {
-                    v = fmaf(acc[i][j][4 * q + e], ln_a[i], fmaf(ln_b[i], cv4[e], bv4[e]));
-                    g = fmaf(acc[i][j + 1][4 * q + e], ln_a[i], fmaf(ln_b[i], cg4[e], bg4[e]));
-                  } else {
-                    v = acc[i][j][4 * q + e] + bv4[e];
-                    g = acc[i][j + 1][4 * q + e] + bg4[e];
-                  }
-                  o[e] = (half_t)(v * gelu_erf(g));
-                }
-                *reinterpret_cast<half4*>(ot + ml * OROW + (wn * TN + j) * 16 + 8 * q + 4 * hi) = o;
-              }
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int nl = (wn * TN + j) * 32 + 8 * q + 4 * hi;
-              const int n = n_blk + nl;
-              float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-              const floatx4 bb = *reinterpret_cast<const floatx4*>(sconst + nl);            // bias (+ temb), 0 beyond N
-              if constexpr (LNF) {
-                const floatx4 cs = *reinterpret_cast<const floatx4*>(sconst + BN + nl);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], ln_a[i], fmaf(ln_b[i], cs[e], bb[e]));
-              } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += bb[e];
-              }
-              if (a.temb && !temb_uniform && n < a.N) {   // tile straddles samples (HoWo < BM): per-row sample index
-                floatx4 tt = *reinterpret_cast<const floatx4*>(a.temb + (size_t)b * a.temb_stride + n);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += tt[e];
-              }
-              half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-              if (tblock) {   // V^T columns: staged [n][m] so the write-out rows are token-contiguous
-#pragma unroll
-                for (int e = 0; e < 4; ++e) ot[(nl + e) * TROW + ml] = o[e];
-              } else {
-                *reinterpret_cast<half4*>(ot + ml * OROW + nl) = o;
-              }
-            }
-        }
-      }
-      __syncthreads();
-      if (tblock) {   // out_t[b][n - n_trans][s]: 8 consecutive tokens of one image per 16-B store
-        const int NV = a.N - a.n_trans;
-        for (int idx = tid; idx < BN * (BM / 8); idx += 256) {
-          const int r = idx / (BM / 8), c = idx - r * (BM / 8);
-          const int nv = n_blk + r - a.n_trans, m = m_blk + c * 8;
-          if (nv < NV && m < a.M) {
-            const int b = m / a.HoWo, sp = m - b * a.HoWo;
-            *reinterpret_cast<half8*>(a.out_t + ((size_t)b * NV + nv) * a.ldT + sp) =
-                *reinterpret_cast<const half8*>(ot + r * TROW + c * 8);
-          }
-        }
-        return;
-      }
-      const int NO = geglu ? (a.N >> 1) : a.ldo;            // output row length
-      const int nb0 = geglu ? (n_blk >> 1) : n_blk;         // first output column of this tile
-      constexpr int OWC = OW / 8;                           // 16-B chunks per staged row (GEGLU: first half used)
-      const int wc = geglu ? OWC / 2 : OWC;
-      for (int idx = tid; idx < BM * wc; idx += 256) {
-        const int r = idx / wc, c = idx - r * wc;
-        const int m = m_blk + r, n = nb0 + c * 8;
-        if (m < a.M && n < NO) {
-          half8 v = *reinterpret_cast<const half8*>(ot + r * OROW + c * 8);
-          half_t* dst = a.out + (size_t)m * NO + n;
-          if (n + 8 <= NO) {
-            if (a.res) {
-              const half8 rr = *reinterpret_cast<const half8*>(a.res + (size_t)m * NO + n);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
-            }
-            *reinterpret_cast<half8*>(dst) = v;
-          } else {   // ragged last chunk (N % 8 == 4)
-            for (int e = 0; e < NO - n; ++e) dst[e] = a.res ? (half_t)((float)v[e] + (float)a.res[(size_t)m * NO + n + e]) : v[e];
-          }
-        }
-      }
-    }
+    tile_epilogue<BM, BN, WGM, WGN, TM, TN, LNF>(a, acc, ln_a, ln_b, smem, sconst, const_b, const_t, const_c, m_blk, n_blk, wave, split,
+                                                 temb_uniform);
   }
   if (prof) {
     prof_t[3] = clock64();
@@ -1088,7 +1019,8 @@ __global__ __launch_bounds__(256, halo_lds_bytes(64, D) <= 80 * 1024 ? 2 : 1) vo
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wk = wave & 1;
-  const int H = a.Hi, W = a.Wi;
+  const int H = a.Ho, W = a.Wo;                 // output (= upsampled input) image; nearest-x2 is folded into the halo gather
+  const int ush = a.up >> 1;
 
   const int n_tiles = (a.N + BN - 1) / BN;
   const int m_tiles = a.B * a.tiles_y * a.tiles_x;
@@ -1120,7 +1052,7 @@ __global__ __launch_bounds__(256, halo_lds_bytes(64, D) <= 80 * 1024 ? 2 : 1) vo
   constexpr unsigned kOob = 0x80000000u;
   const __amdgpu_buffer_rsrc_t rs_w =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.w), 0, (int)((size_t)a.N * a.K * 2), 0x00020000);
-  const size_t xpix = (size_t)a.B * H * W;
+  const size_t xpix = (size_t)a.B * a.Hi * a.Wi;
   unsigned hoff0[HALO_PPW], hoff1[HALO_PPW];            // byte offset of this lane's 16 bytes of halo piece j at channel 0
 #pragma unroll
   for (int j = 0; j < HALO_PPW; ++j) {
@@ -1129,7 +1061,7 @@ __global__ __launch_bounds__(256, halo_lds_bytes(64, D) <= 80 * 1024 ? 2 : 1) vo
     const int hy = hr / HALO_W, hx = hr - hy * HALO_W;
     const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
     const bool ok = (hr < HALO_ROWS) && iy >= 0 && iy < H && ix >= 0 && ix < W;
-    const unsigned pix = (unsigned)((b * H + iy) * W + ix);
+    const unsigned pix = (unsigned)((b * a.Hi + (iy >> ush)) * a.Wi + (ix >> ush));   // unet.py:498-500 nearest upsample
     const unsigned sw = (unsigned)(((lane & 7) ^ ((hx >> 1) & 7)) * 16);   // column-keyed swizzle
     hoff0[j] = ok ? pix * (unsigned)a.C0 * 2u + sw : kOob;
     hoff1[j] = ok ? pix * (unsigned)a.C1 * 2u + sw : kOob;
@@ -1157,7 +1089,7 @@ __global__ __launch_bounds__(256, halo_lds_bytes(64, D) <= 80 * 1024 ? 2 : 1) vo
     if constexpr ((DBG & 8) != 0) return;
     const int p = wave + 4 * j;
     char* dst = Xh + xstage * (HALO_LDS_ROWS * ROWB) + (p < HALO_PIECES ? p : HALO_PIECES - 1) * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, off, soff, 0, 0);
+    dma16_to_lds(rs, dst, off, soff);
   };
   const int total_steps = (ch_end - ch_begin) * 9;
   int iw_koff = ch_begin * BK * 2, iw_tap = 0, iw_step = 0;   // issue cursor of the weight ring (koff in bytes)
@@ -1166,7 +1098,7 @@ __global__ __launch_bounds__(256, halo_lds_bytes(64, D) <= 80 * 1024 ? 2 : 1) vo
     char* ws = Ws + ((unsigned)iw_step % D) * (BN * ROWB) + wave * 1024;
 #pragma unroll
     for (int i = 0; i < WR; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(ws + i * 4096), 16, woff[i], iw_koff, 0, 0);
+      dma16_to_lds(rs_w, ws + i * 4096, woff[i], iw_koff);
     ++iw_step;
     iw_koff += a.Ctot * 2;                                // next tap, same chunk
     if (++iw_tap == 9) {
@@ -1623,8 +1555,8 @@ IgemmArgs make_args(const ConvDesc& d) {
   a.debug = d.debug;
   a.prof = d.prof;
   a.zeros = device_zero_chunk();
-  a.tiles_x = cdiv(d.Wi, 16);
-  a.tiles_y = cdiv(d.Hi, 8);
+  a.tiles_x = cdiv(d.Wo, 16);   // halo kernels: stride 1, so output = (upsampled) input extent
+  a.tiles_y = cdiv(d.Ho, 8);
   a.ln_colsum = d.ln_colsum;
   a.ln_eps = d.ln_eps;
   a.n_trans = d.out_t ? d.n_trans : 0x7fffffff;
@@ -1642,6 +1574,14 @@ struct Plan {
 bool halo_ok(const ConvDesc& d) {
   const int c1 = d.x1 ? d.C1 : 0;
   return d.ksize == 3 && d.stride == 1 && d.up == 1 && d.pad < 0 && d.out_mode == kOutHalf && d.Wi >= 16 && d.Hi >= 8 &&
+         d.C0 % BK == 0 && c1 % BK == 0 && d.N % 4 == 0;
+}
+
+// the K-split halo kernel also folds the nearest-x2 upsample into its gather and takes 8-pixel-wide images (half of each
+// 8x16 tile is then padding: the 8x8 level streams weights, MFMA work is not what bounds it)
+bool halo_ks_ok(const ConvDesc& d) {
+  const int c1 = d.x1 ? d.C1 : 0;
+  return d.ksize == 3 && d.stride == 1 && (d.up == 1 || d.up == 2) && d.pad < 0 && d.out_mode == kOutHalf && d.Wo >= 8 && d.Ho >= 8 &&
          d.C0 % BK == 0 && c1 % BK == 0 && d.N % 4 == 0;
 }
 
@@ -1678,8 +1618,12 @@ static const int kNumTuned = 0;
 // SD_PLAN_TABLE=<file>: rows "{kind, ksize, stride, up, Ctot, N, M, tile, staging, splitk}" (the format of
 // tuned_convs.inc) read at first use and consulted BEFORE the compiled-in table - how tools/tune_plans.py
 // validates a freshly measured table in the same GPU session without a rebuild.
-const std::vector<TunedConv>& runtime_table() {
-  static const std::vector<TunedConv> table = [] {
+bool parse_plan_row(const char* line, TunedConv& r) {
+  return sscanf(line, " {%d, %d, %d, %d, %d, %d, %d, %d, %d, %d}", &r.kind, &r.ksize, &r.stride, &r.up, &r.ctot, &r.n, &r.m, &r.tile,
+                &r.staging, &r.splitk) == 10;
+}
+std::vector<TunedConv>& runtime_table() {
+  static std::vector<TunedConv> table = [] {
     std::vector<TunedConv> t;
     const char* path = getenv("SD_PLAN_TABLE");
     if (!path) return t;
@@ -1691,9 +1635,7 @@ const std::vector<TunedConv>& runtime_table() {
     char line[512];
     while (fgets(line, sizeof(line), f)) {
       TunedConv r;
-      if (sscanf(line, " {%d, %d, %d, %d, %d, %d, %d, %d, %d, %d}", &r.kind, &r.ksize, &r.stride, &r.up, &r.ctot, &r.n, &r.m,
-                 &r.tile, &r.staging, &r.splitk) == 10)
-        t.push_back(r);
+      if (parse_plan_row(line, r)) t.push_back(r);
     }
     fclose(f);
     fprintf(stderr, "[sd] SD_PLAN_TABLE=%s: %zu plans\n", path, t.size());
@@ -1722,7 +1664,7 @@ Plan choose_plan(const ConvDesc& d, const IgemmArgs& a) {
   auto is_halo = [](int c) { return c == 5 || c == 6 || c == 7; };
   auto tile_ok = [&](int c) {
     if (c < 1 || c > 7) return false;
-    if (is_halo(c)) return halo_ok(d) && !d.ln_colsum && !d.out_t && !geglu;
+    if (is_halo(c)) return (c == 7 ? halo_ks_ok(d) : halo_ok(d)) && !d.ln_colsum && !d.out_t && !geglu;
     int bm, bn;
     tile_dims(c, bm, bn);
     if (geglu && c != 1 && c != 4) return false;       // GEGLU value/gate pairs need 64 n-columns per wave
@@ -1877,12 +1819,12 @@ void launch_halo_ks(IgemmArgs a, int splitk, int staging, hipStream_t s) {
   launch_halo_ks_d<2>(a, s);
 }
 
-template <int BM, int BN, int WGM, int WGN, bool TRANS, bool GLDS, int NST, bool LNF = false, bool PIPE = false>
+template <int BM, int BN, int WGM, int WGN, bool TRANS, bool GLDS, int NST, bool LNF = false>
 void launch_variant(const IgemmArgs& a, hipStream_t s) {
   const size_t lds = (size_t)NST * (BM + BN) * (GLDS ? BK : LDS_ROW) * sizeof(half_t) + 2 * BN * sizeof(float);
   static_assert((size_t)BN * (BM + 8) <= (size_t)NST * (BM + BN) * (GLDS ? BK : LDS_ROW), "transposed staging fits");
   dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), a.splitk);
-  auto k = igemm_kernel<BM, BN, WGM, WGN, TRANS, GLDS, NST, 0, LNF, PIPE>;
+  auto k = igemm_kernel<BM, BN, WGM, WGN, TRANS, GLDS, NST, 0, LNF>;
   static DynLdsOnce once;   // per instantiation, per device
   once.set(k, lds);
   hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
@@ -1911,7 +1853,7 @@ bool launch_debug_mode(const IgemmArgs& a, int dbg, hipStream_t s) {
 
 // staging: 0 = LDS-DMA 2 stages, 1 = register staging (A/B reference), 2 / 3 / 4 / 5 = LDS-DMA ring of
 // 3 / 4 / 6 / 8 stages (a ring that would not fit the 160 KB of LDS falls back to the deepest one that does),
-// 6 / 7 = software-pipelined loop over a ring of 4 / 6 stages
+// (codes 6-8 belonged to a software-pipelined 1x1 GEMM kernel that was measured and dropped; they run the 4-stage ring)
 constexpr size_t kLdsBudget = 160 * 1024;
 template <int BM, int BN>
 constexpr bool ring_fits(int nst) {
@@ -1919,11 +1861,7 @@ constexpr bool ring_fits(int nst) {
 }
 template <int BM, int BN, int WGM, int WGN, bool LNF>
 void launch_ring(const IgemmArgs& a, int staging, hipStream_t s) {
-  // 6 / 7: software-pipelined loop (fragment double buffering) over a ring of 4 / 6 stages
-  if (staging == 7) {
-    if constexpr (ring_fits<BM, BN>(6)) { launch_variant<BM, BN, WGM, WGN, false, true, 6, LNF, true>(a, s); return; }
-  }
-  if (staging >= 6) { launch_variant<BM, BN, WGM, WGN, false, true, 4, LNF, true>(a, s); return; }
+  if (staging >= 6) staging = 3;
   if (staging >= 5) {
     if constexpr (ring_fits<BM, BN>(8)) { launch_variant<BM, BN, WGM, WGN, false, true, 8, LNF>(a, s); return; }
   }
@@ -1974,6 +1912,24 @@ size_t conv_workspace_bytes(const ConvDesc& d) {
   const bool can_split = d.out_mode == kOutHalf && !d.ln_colsum && !d.out_t;
   const int splits = (tuning && can_split) ? std::max(p.splitk, 16) : p.splitk;
   return splits > 1 ? (size_t)splits * a.M * a.N * sizeof(float) : 0;   // upper bound (launch may use fewer splits)
+}
+
+// sd_tune_set_plan_table: replace the run-time table by the rows of `text` (tuned_convs.inc format, one per line) - how
+// tools/tune_e2e.py tries one plan after another against the graph replay time of the whole step in ONE process
+int conv_plan_table_set(const char* text) {
+  std::vector<TunedConv>& t = runtime_table();
+  t.clear();
+  if (!text) return 0;
+  const char* p = text;
+  while (*p) {
+    const char* e = strchr(p, '\n');
+    std::string line(p, e ? (size_t)(e - p) : strlen(p));
+    TunedConv r;
+    if (parse_plan_row(line.c_str(), r)) t.push_back(r);
+    if (!e) break;
+    p = e + 1;
+  }
+  return (int)t.size();
 }
 
 void conv_tune_set_candidate(int tile, int staging, int splitk) {

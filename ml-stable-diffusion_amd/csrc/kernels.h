@@ -60,6 +60,7 @@ void launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s);
 bool conv_fast_path_ok(const ConvDesc& d);
 // tuning hook: plan (tile 1-6, staging 0-5, splitk) forced on every conv that admits it; tile 0 = off
 void conv_tune_set_candidate(int tile, int staging, int splitk);
+int conv_plan_table_set(const char* text);   // rows of tuned_convs.inc format; returns the number of plans read
 
 // direct conv for tiny / odd shapes (any Cin, any N): fp32 accumulate, one thread per output
 void launch_conv_generic(const ConvDesc& d, int act_silu_out, hipStream_t s);

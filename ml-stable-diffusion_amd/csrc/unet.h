@@ -40,6 +40,7 @@ class UNet {
 
   void forward(const sd_unet_io& io);
   float time_forward(int warmup, int iters);
+  void drop_graphs() { invalidate_graphs(); }   // measurement hook: the next forward re-captures (sd_tune_set_plan_table)
   // HIP-event time of every op of one forward, in launch order (eager launches, cold caches between
   // dependent kernels exactly as inside the graph); median over `iters` passes
   std::vector<OpTime> profile(int iters);

@@ -75,6 +75,7 @@ SYMBOLS = [
     ("sd_unet_time_forward", _I, [_P, _I, _I, _FP]),
     ("sd_unet_denoise_loop", _I, [_P, C.POINTER(UNetIO), _FP, _I, _I, _FP, _FP, _FP, _I, _F, _FP, _FP]),
     ("sd_tune_set_candidate", _I, [_I, _I, _I]),
+    ("sd_tune_set_plan_table", _I, [C.c_char_p, C.c_void_p, C.POINTER(C.c_int)]),
     ("sd_unet_profile", _I, [_P, _I, _I, _FP, C.POINTER(C.c_double), C.c_char_p, _I, C.POINTER(_I)]),
     ("sd_unet_attach_controlnets", _I, [_P, C.POINTER(_P), _I]),
     ("sd_controlnet_set_cond", _I, [_P, _P, _I]),

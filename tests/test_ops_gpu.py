@@ -234,6 +234,25 @@ def test_conv3x3_halo_kernel(tile, splitk, shape):
     close(out, conv_ref(x, w, bias, res, 1, False), f"halo conv tile {tile} splitk {splitk} {shape}")
 
 
+@pytest.mark.parametrize("tile", [7, 27, 37, 47])
+@pytest.mark.parametrize("splitk", [1, 2, 3])
+@pytest.mark.parametrize("shape,up", [((2, 128, 8, 8, 128), False), ((1, 192, 8, 12, 72), False), ((2, 128, 8, 8, 64), True),
+                                      ((1, 64, 12, 20, 96), True), ((2, 320, 16, 16, 320), True), ((1, 64, 9, 5, 68), True)],
+                         ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else ("up" if v else "plain"))
+def test_conv3x3_halo_ks_upsample_and_narrow_images(tile, splitk, shape, up):
+    """K-split halo kernel beyond the other halo kernels' domain: images only 8 pixels wide (the 8x8 level: half of every 8x16
+    tile is padding) and the nearest-x2 upsample of unet.py:498-500 folded into the halo gather."""
+    b, cin, hh, ww, cout = shape
+    rs = np.random.RandomState(cin + ww + int(up))
+    x = h16(rs.randn(b, cin, hh, ww))
+    w = h16(rs.randn(cout, cin, 3, 3) / np.sqrt(cin * 9))
+    bias = (0.1 * rs.randn(cout)).astype(np.float32)
+    f = 2 if up else 1
+    res = h16(rs.randn(b, cout, hh * f, ww * f))
+    out, _ = _lib.conv2d(x, w, bias, res, upsample=up, tile=tile, splitk=splitk)
+    close(out, conv_ref(x, w, bias, res, 1, up), f"halo-ks conv tile {tile} splitk {splitk} {shape} up={up}")
+
+
 @pytest.mark.parametrize("m,c", [(512, 320), (77, 64), (128, 1280), (40, 32)])
 def test_geglu_matches_oracle(m, c):
     rs = np.random.RandomState(m + c)

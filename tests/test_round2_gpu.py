@@ -361,3 +361,4 @@ def test_vae_encoder_matches_oracle(name, hw):
     with pytest.raises(TypeError):
         enc(x=x.astype(np.float32))
     enc.close()
+

@@ -52,10 +52,13 @@ def set_candidate(t, st, sk):
 
 set_candidate(0, 0, 0)
 base = measure(7)
-cands = [(t, st, sk) for t in (1, 2, 3, 4) for st in (0, 2, 3, 4, 6, 7) for sk in (1, 2, 4, 8, 16)]
+cands = [(t, st, sk) for t in (1, 2, 3, 4) for st in (0, 2, 3, 4) for sk in (1, 2, 4, 8, 16)]
 cands += [(5, st, sk) for st in (0, 2, 3) for sk in (1, 2, 4, 8, 16)]          # LDS-halo 3x3 kernel, BN = 128
 cands += [(6, st, sk) for st in (0, 2, 3, 4, 5) for sk in (1, 2, 4, 8, 16)]    # ... BN = 64
-cands += [(7, st, sk) for st in (2, 3, 4) for sk in (1, 2, 3, 4, 5, 8)]        # ... K-split waves, software-pipelined
+cands += [(7, st, sk) for st in (2, 3, 4) for sk in (1, 2, 3, 4, 5, 8, 10)]    # ... K-split waves, software-pipelined
+if os.environ.get("TUNE_STAGINGS"):                                            # e.g. TUNE_STAGINGS=6,7,8 with TUNE_TILES=1,2,3,4,7
+    keep_st = {int(t) for t in os.environ["TUNE_STAGINGS"].split(",")}
+    cands = [c for c in cands if c[1] in keep_st or c[0] == 7]
 if os.environ.get("TUNE_TILES"):                                               # e.g. TUNE_TILES=7: only the new kernel
     keep = {int(t) for t in os.environ["TUNE_TILES"].split(",")}
     cands = [c for c in cands if c[0] in keep]
