@@ -3,7 +3,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=$PWD/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
-SD_TUNE=1 timeout 900 python tools/tune_e2e.py tools/tables/shortlist_l.json $OUT/tuned_e2e.inc $OUT/tune_e2e_report.json > $OUT/tune_e2e.log 2>&1
+SD_TUNE=1 timeout 900 python tools/tune_e2e.py tools/tables/shortlist_2.json $OUT/tuned_e2e.inc $OUT/tune_e2e_report.json > $OUT/tune_e2e.log 2>&1
 grep -v amdgpu.ids $OUT/tune_e2e.log | tail -n 60
 cat $OUT/tuned_e2e.inc
 timeout 300 python bench.py --cpu-steps 0 --repeats 5 > $OUT/bench_n_before.log 2>/dev/null; tail -n 1 $OUT/bench_n_before.log | cut -c1-330
