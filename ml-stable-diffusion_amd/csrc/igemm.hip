@@ -1202,7 +1202,12 @@ __global__ __launch_bounds__(256, halo_lds_bytes(64, D) <= 80 * 1024 ? 2 : 1) vo
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // weight tile st+1 (at tap 8: and the next halo) has landed
         if constexpr (LAST) halo_ks_wait_last<D, WR>(tap);
-        else if (D > 4 && first_chunk) wait_vmcnt_barrier<(D - 2) * WR>();   // fewer halo pieces behind the tiles than in steady state
+        else if (D > 4 && first_chunk) {
+          // fewer halo pieces behind the weight tiles than in steady state: count the tiles only - but at tap 8 the next
+          // chunk's halo (last piece issued at tap 5, two steps = 2 * WR weight pieces ago) must have landed as well
+          if (tap == 8) wait_vmcnt_barrier<((D - 2) * WR < 2 * WR ? (D - 2) * WR : 2 * WR)>();
+          else wait_vmcnt_barrier<(D - 2) * WR>();
+        }
         else halo_ks_wait<D, WR>(tap);
         const int tapn = tap == 8 ? 0 : tap + 1;
         const char* xs = Xh + (tap == 8 ? xst ^ 1 : xst) * (HALO_LDS_ROWS * ROWB);
@@ -1709,6 +1714,12 @@ Plan choose_plan(const ConvDesc& d, const IgemmArgs& a) {
       p.splitk = hit->splitk;
     }
   }
+  if (p.tile == 0 && tile_ok(7)) {
+    // no measured plan for this shape: the K-split halo kernel with the 4-stage ring won every 3x3 / stride-1 shape that was
+    // tuned (SD2.1-base, SDXL-base, SD1.5: tuned_convs.inc); split-K below as for the other kernels
+    p.tile = 7;
+    if (p.staging == 0) p.staging = 3;
+  }
   if (p.tile == 0) {
     p.tile = 3;
     for (int c : {1, 2, 4, 3}) {
@@ -1720,7 +1731,8 @@ Plan choose_plan(const ConvDesc& d, const IgemmArgs& a) {
   if (p.splitk == 0) {
     p.splitk = 1;
     const int ms = max_split(p.tile);
-    while (blocks_of(p.tile) * p.splitk < 384 && p.splitk < ms) p.splitk *= 2;
+    const long want = p.tile == 7 ? 192 : 384;   // the pipelined halo kernel is at its best from ~160 workgroups (1 per CU)
+    while (blocks_of(p.tile) * p.splitk < want && p.splitk < ms) p.splitk *= 2;
   }
   if (!can_split) p.splitk = 1;
   if (p.splitk > ksteps(p.tile)) p.splitk = ksteps(p.tile);
