@@ -23,7 +23,7 @@ Timing: the K-step timed region (barrier + synchronize on both sides, max over r
 Extra objects on the JSON line:
   roofline     MFMA roofline of the step graph: algorithmic FLOP per step (SURVEY.md section 8d:
                1.6085e12 per CFG-batch-2 step) / HIP-event time per step on the handle's stream;
-               `traffic` = HBM bytes per step from rocprofv3 PMC passes (profiles/r02_hbm_traffic.json,
+               `traffic` = HBM bytes per step from rocprofv3 PMC passes (profiles/r02_final_hbm_traffic.json,
                tools/gpu_pmc_traffic.sh), `dominant_kernel` = the largest conv family timed IN SEQUENCE
                (sd_unet_profile: HIP events around every op of the eager step) next to its stand-alone time
   cpu_baseline the oracle (CPU restatement of the reference UNet + loop) timed on this box's host
@@ -177,16 +177,16 @@ def main():
 
 def hbm_traffic(step_ms):
     """HBM bytes per step from the committed rocprofv3 PMC passes (bench.py cannot run under the profiler
-    itself): profiles/r02_hbm_traffic.json is written by tools/pmc_traffic.py from separate --pmc
+    itself): profiles/r02_final_hbm_traffic.json is written by tools/pmc_traffic.py from separate --pmc
     FETCH_SIZE / WRITE_SIZE runs of the same step, corrected as MI355X_MICROARCH.md prescribes."""
-    path = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_final_hbm_traffic.json")
     if not os.path.exists(path):
         return {}
     with open(path) as f:
         t = json.load(f)
     total = float(t["bytes_per_step"])
     return {"traffic": total, "traffic_detail": {
-        "source": "profiles/r02_hbm_traffic.json (rocprofv3 --pmc, eager launches of the same step)",
+        "source": "profiles/r02_final_hbm_traffic.json (rocprofv3 --pmc, eager launches of the same step)",
         "read_bytes": t.get("read_bytes_per_step"), "write_bytes": t.get("write_bytes_per_step"),
         "algorithmic_min_bytes": t.get("algorithmic_min_bytes"),
         "hbm_gb_per_s_at_this_run": round(total / (step_ms * 1e-3) / 1e9, 1), "hbm_peak_gb_per_s": 8000.0,
@@ -216,7 +216,7 @@ def dominant_kernel(model, ehs, latents, ppg):
     tf = flop / (ms * 1e-3) / 1e12
     total_ms = float(sum(m for _, _, m in ops))
     mfma_ms = float(sum(m for _, fl, m in ops if fl > 0))
-    return {"kernel": f"3x3 conv 320->320 @64x64, UNet batch {B} (implicit-GEMM / LDS-halo MFMA kernel, plan from "
+    return {"kernel": f"3x3 conv 320->320 @64x64, UNet batch {B} (K-split software-pipelined LDS-halo MFMA kernel, plan from "
                       "tuned_convs.inc), 7 launches per step",
             "flop_per_launch": flop, "launch_ms": round(ms_in, 5), "achieved": round(tf_in, 1), "peak": MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": round(tf_in / MFMA_PEAK_TFLOPS, 4),
@@ -224,7 +224,8 @@ def dominant_kernel(model, ehs, latents, ppg):
             "standalone": {"launch_ms": round(ms, 5), "achieved": round(tf, 1), "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
                            "timing": "same kernel alone, 50 back-to-back launches, operands L2-warm"},
             "step_ops": len(ops), "step_ops_ms_sum": round(total_ms, 4), "step_mfma_ops_ms_sum": round(mfma_ms, 4),
-            "bound": "L2->LDS operand fill (DESIGN.md section 3)"}
+            "bound": "per-workgroup serial phases: of the 14.5 us a 256-workgroup launch takes, MFMA issue is 5.6 us, exposed fragment reads "
+                     "2.3 us, exposed DMA issue 2.1 us, launch + prologue + epilogue 4.5 us (profiles/r02_ablate_halo_ks_warm.txt)"}
 
 
 def e2e_latency(model, checkpoint, ehs, latents, guidance, device):
