@@ -1464,6 +1464,79 @@ __global__ __launch_bounds__(256) void conv_small_cin_kernel(IgemmArgs a, int si
   }
 }
 
+// ---- 4 input channels (conv_in 4->320, VAE conv_in 4->512): K = 36 on the MFMA ----
+// The scalar kernel above spends 30-40 us on SD2.1's conv_in (profiles/r02_final_op_profile.txt) for 0.2 GFLOP.  Here a
+// workgroup builds the im2col rows of 128 output pixels (9 taps x 4 channels = 72 B each, zero-padded to three 16-deep
+// MFMA steps) and 64 weight rows in LDS - same row swizzle as igemm_kernel - runs 6 MFMAs per wave and leaves through
+// the shared tile epilogue (bias, residual = the ControlNet conditioning embedding, coalesced fp16 stores).
+__global__ __launch_bounds__(256) void conv3x3_cin4_kernel(IgemmArgs a) {
+  constexpr int BM = 128, BN = 64, ROWB = BK * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Xs = smem;                       // [BM][64 halves]; only k < 48 is read
+  char* const Ws = smem + BM * ROWB;           // [BN][64 halves]
+  float* sconst = reinterpret_cast<float*>(smem + (BM + BN) * ROWB);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nbm = (a.M + BM - 1) / BM;
+  const int bn_idx = blockIdx.x / nbm, bm_idx = blockIdx.x % nbm;
+  const int m_blk = bm_idx * BM, n_blk = bn_idx * BN;
+  typedef unsigned long long u64;
+  // one thread per LDS row: threads 0..127 an im2col row, 128..191 a weight row; 8-B pieces at k = 4t, t = 0..11
+  if (tid < BM + BN) {
+    const bool is_x = tid < BM;
+    const int r = is_x ? tid : tid - BM;
+    char* row = (is_x ? Xs : Ws) + r * ROWB;
+    const int sw = (r >> 1) & 7;
+    u64 v[12];
+#pragma unroll
+    for (int t = 0; t < 12; ++t) v[t] = 0ull;
+    if (is_x) {
+      const int m = m_blk + r;
+      if (m < a.M) {
+        const int b = m / a.HoWo, rem = m - b * a.HoWo;
+        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int iy = oy - 1 + t / 3, ix = ox - 1 + t % 3;
+          if (iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi)
+            v[t] = *reinterpret_cast<const u64*>(a.x0 + ((size_t)(b * a.Hi + iy) * a.Wi + ix) * 4);
+        }
+      }
+    } else {
+      const int n = n_blk + r;
+      if (n < a.N) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) v[t] = *reinterpret_cast<const u64*>(a.w + (size_t)n * 36 + t * 4);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 12; ++t)   // logical 16-B chunk t/2 lives in physical slot (t/2) ^ sw
+      *reinterpret_cast<u64*>(row + (((t >> 1) ^ sw) * 16) + (t & 1) * 8) = v[t];
+  }
+  float const_b = 0.f;
+  if (tid < BN && n_blk + tid < a.N && a.bias) const_b = a.bias[n_blk + tid];
+  __syncthreads();
+  const int wm = wave >> 1, wn = wave & 1;
+  const int frow = lane & 31, hi = lane >> 5, fsw = (frow >> 1) & 7;
+  floatx16 acc[2][1];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) {
+    const int koff = ((2 * ks + hi) ^ fsw) * 16;
+    const half8 wf = *reinterpret_cast<const half8*>(Ws + (wn * 32 + frow) * ROWB + koff);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const half8 xf = *reinterpret_cast<const half8*>(Xs + ((wm * 2 + i) * 32 + frow) * ROWB + koff);
+      acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xf, acc[i][0], 0, 0, 0);
+    }
+  }
+  const float ln0[2] = {0.f, 0.f};
+  tile_epilogue<BM, BN, 2, 2, 2, 1, false>(a, acc, ln0, ln0, smem, sconst, const_b, 0.f, 0.f, m_blk, n_blk, wave, 0, false);
+}
+
 // ---- N <= 8 output channels (conv_out 320->4): one wavefront per output pixel ----
 template <int NMAX>
 __global__ __launch_bounds__(256) void conv_small_n_kernel(IgemmArgs a, float* out_nchw) {
@@ -2008,6 +2081,14 @@ void launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
 
 void launch_conv_generic(const ConvDesc& d, int act_silu_out, hipStream_t s) {
   IgemmArgs a = make_args(d);
+  if (a.ksize == 3 && a.stride == 1 && a.up == 1 && a.Ctot == 4 && !d.x1 && d.pad < 0 && d.out_mode == kOutHalf && a.N % 8 == 0 &&
+      !d.temb && !act_silu_out) {
+    const size_t lds = (size_t)(128 + 64) * BK * 2 + 2 * 64 * sizeof(float);
+    a.splitk = 1;
+    hipLaunchKernelGGL(conv3x3_cin4_kernel, dim3(cdiv(a.M, 128) * cdiv(a.N, 64)), dim3(256), lds, s, a);
+    SD_HIP(hipGetLastError());
+    return;
+  }
   if (a.K <= SC_KMAX && d.out_mode == kOutHalf && a.N >= 64) {
     hipLaunchKernelGGL(conv_small_cin_kernel, dim3(cdiv(a.M, SC_PIX)), dim3(256), 0, s, a, act_silu_out);
     SD_HIP(hipGetLastError());

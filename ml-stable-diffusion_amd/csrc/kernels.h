@@ -132,6 +132,11 @@ struct LoopTables {
   int* step;                // device scalar
   const float* in_scale;    // [n_steps] scale_model_input factor (sigma-space schedulers), or null
   unsigned* ticket;         // device scalar (0 between launches): arrival counter of cfg_sched_step_kernel
+  // time-embedding table of the whole schedule (or null): [n_steps][temb_rows][temb_ld] rows precomputed by the UNet's time
+  // path for every timestep; loop_prep copies row block `step` to temb_dst, so the step itself launches no time-path kernel
+  const float* temb_tab;
+  float* temb_dst;
+  int temb_rows, temb_ld, temb_n;
 };
 // latents fp32 NCHW [Bimg][4][H][W] -> UNet sample fp16 NHWC [cfg*Bimg][H][W][4], timestep buffer
 void launch_loop_prep(const float* latents, half_t* sample, float* tbuf, LoopTables t, int Bimg, int C, int H,

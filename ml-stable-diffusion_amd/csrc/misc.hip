@@ -220,6 +220,15 @@ __global__ void loop_prep_kernel(const float* __restrict__ latents, half_t* __re
     for (int r = 0; r < cfg; ++r) sample[((size_t)(r * Bimg + b) * HW + p) * C + c] = v;   // [uncond..., cond...]
   }
   if (blockIdx.x == 0 && threadIdx.x < cfg * Bimg) tbuf[threadIdx.x] = t.timesteps[step];
+  if (t.temb_tab) {   // this step's time_emb_proj rows (unet.py:703-728 + :454-456 for every resnet), computed before the loop
+    const size_t rowsz = (size_t)t.temb_ld, blk = (size_t)t.temb_rows * rowsz;
+    const float* src = t.temb_tab + (size_t)step * blk;
+    const size_t n4 = (size_t)t.temb_rows * (t.temb_n / 4);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+      const size_t r = i / (t.temb_n / 4), c = i - r * (t.temb_n / 4);
+      reinterpret_cast<floatx4*>(t.temb_dst + r * rowsz)[c] = reinterpret_cast<const floatx4*>(src + r * rowsz)[c];
+    }
+  }
 }
 
 // pipeline.py:539, 561-569.  noise_pred fp32 NCHW [cfg*Bimg][CHW]; rows [0,Bimg) uncond, [Bimg,2Bimg) text.

@@ -536,6 +536,7 @@ void UNet::build_unet() {
       launch_gemv(w2, b2, e1, tdim, emb, tdim, B, tdim, tdim, 0, 0, 0, s);
     });
     time_ops_.back().label = "time embedding: sinusoid + 2 GEMV (time_embedding.linear_1/2)";
+    tpath_ = TimePath{freq, w1, w2, b1, b2, C0, tdim, !xl};
     if (xl) {
       const int nt = cfg_.num_time_ids, adim = cfg_.addition_time_embed_dim;
       const int pin = cfg_.projection_class_embeddings_input_dim;
@@ -1250,16 +1251,48 @@ void UNet::denoise_loop(const sd_unet_io& io, float* latents, int n_images, int 
                             hipMemcpyHostToDevice, stream_));
   if (sample_scale)
     SD_HIP(hipMemcpyAsync(tab_scale_, sample_scale, (size_t)n_steps * sizeof(float), hipMemcpyHostToDevice, stream_));
+  // Time path out of the step (unet.py:703-728, :454-456): without added conditioning the embedding MLP and the batched
+  // time_emb_proj depend on the timestep only, so their outputs for ALL steps of this call are computed here in one batched
+  // pass (rows = steps x batch through the same GEMV kernels) and each step copies its rows inside loop_prep - four
+  // dependent launches (~65 us) less per step for ~0.5 ms once per call.  Recomputed on every call: nothing is cached
+  // across generations.  SDXL's text_time conditioning enters the same MLP: it keeps the in-step path.
+  static const bool hoist_off = getenv("SD_NO_TEMB_TABLE") != nullptr;   // A/B switch
+  const bool hoist = !hoist_off && tpath_.ok && temb_w_all_ && temb_used_ > 0 && temb_used_ % 4 == 0;
+  if (hoist) {
+    const int Bt = cfg_.batch, rows = n_steps * Bt;
+    if (temb_tab_cap_ < n_steps) {
+      temb_tab_cap_ = std::max(n_steps, 64);
+      const size_t r = (size_t)temb_tab_cap_ * Bt;
+      temb_tab_ = arena_.alloc_n<float>(r * kTembCap);
+      tt_tab_ = arena_.alloc_n<float>(r);
+      tsin_tab_ = arena_.alloc_n<float>(r * tpath_.c0);
+      e1_tab_ = arena_.alloc_n<float>(r * tpath_.tdim);
+      emb_tab_ = arena_.alloc_n<float>(r * tpath_.tdim);
+      if (loop_graph_) { (void)hipGraphExecDestroy(loop_graph_); loop_graph_ = nullptr; }   // the table address is baked in
+    }
+    // every call recomputes the table (no caching across generations): one batched pass over all steps' timesteps
+    std::vector<float> tt((size_t)rows);
+    for (int i = 0; i < n_steps; ++i)
+      for (int b = 0; b < Bt; ++b) tt[(size_t)i * Bt + b] = timesteps[i];
+    SD_HIP(hipMemcpyAsync(tt_tab_, tt.data(), tt.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
+    SD_HIP(hipStreamSynchronize(stream_));   // tt is a local
+    const int c0 = tpath_.c0, td = tpath_.tdim;
+    launch_timestep_embedding(tt_tab_, tpath_.freq, tsin_tab_, rows, c0, stream_);
+    launch_gemv(tpath_.w1, tpath_.b1, tsin_tab_, c0, e1_tab_, td, rows, td, c0, 0, 1, 0, stream_);
+    launch_gemv(tpath_.w2, tpath_.b2, e1_tab_, td, emb_tab_, td, rows, td, td, 0, 0, 0, stream_);
+    launch_gemv(temb_w_all_, temb_b_all_, emb_tab_, td, temb_tab_, kTembCap, rows, temb_used_, td, 1, 0, 0, stream_);
+  }
   LoopTables tab{tab_timesteps_, tab_coef_, step_, sample_scale ? tab_scale_ : nullptr,
-                 reinterpret_cast<unsigned*>(step_ + 1)};
+                 reinterpret_cast<unsigned*>(step_ + 1), hoist ? temb_tab_ : nullptr, temb_all_, cfg_.batch, kTembCap, temb_used_};
   auto step_ops = [&]() {
     launch_loop_prep(latents_, x_in_.p, tbuf_, tab, n_images, C, H, W, cfgmul, stream_);
     run_attached();
-    run_time_and_main();
+    if (hoist) run_ops(main_ops_);
+    else run_time_and_main();
     launch_cfg_sched_step(noise_pred_, latents_, eps_hist_, tab, guidance, n_images, C * H * W, cfgmul, history,
                           stream_);
   };
-  const int key = n_images * 32 + history * 4 + (cfgmul - 1) * 2 + (sample_scale ? 1 : 0);
+  const int key = n_images * 64 + (hoist ? 32 : 0) + history * 4 + (cfgmul - 1) * 2 + (sample_scale ? 1 : 0);
   std::unique_ptr<EventList> ev;
   if (ms_per_step) ev = std::make_unique<EventList>((size_t)n_steps + 1);
   if (cfg_.use_graph) {

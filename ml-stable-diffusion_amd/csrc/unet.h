@@ -154,6 +154,18 @@ class UNet {
   float* tbuf_ = nullptr;           // (B,) f32 timesteps
   float* emb_ = nullptr;            // (B, temb_dim)
   float* temb_all_ = nullptr;       // (B, kTembCap)
+  // device loop: time-embedding rows of every step of the current schedule (unconditioned time path only), and the
+  // timesteps they were computed for
+  float* temb_tab_ = nullptr;       // [steps][B][kTembCap]
+  int temb_tab_cap_ = 0;            // in steps
+  float *tt_tab_ = nullptr, *tsin_tab_ = nullptr, *e1_tab_ = nullptr, *emb_tab_ = nullptr;   // [steps * B] x {1, C0, tdim, tdim}
+  struct TimePath {                 // the unconditioned time path's weights (unet.py:703-728), kept for the table pass
+    const float* freq = nullptr;
+    const half_t *w1 = nullptr, *w2 = nullptr;
+    const float *b1 = nullptr, *b2 = nullptr;
+    int c0 = 0, tdim = 0;
+    bool ok = false;                // false: text_time conditioning enters the MLP (SDXL) -> in-step path only
+  } tpath_;
   int temb_used_ = 0;
   std::vector<std::pair<std::string, int>> temb_layers_;
   half_t* temb_w_all_ = nullptr;

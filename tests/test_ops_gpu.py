@@ -186,6 +186,8 @@ CONVS = [  # (B, Cin, H, W, Cout, k, stride, upsample, bias, res)
     (1, 1024, 1, 77, 320, 1, 1, False, False, False),
     (2, 4, 16, 16, 64, 3, 1, False, True, False), (2, 32, 8, 8, 48, 3, 1, False, True, True),      # generic path
     (1, 64, 8, 8, 3, 3, 1, False, True, False), (1, 3, 32, 32, 16, 3, 2, False, True, False),
+    # conv_in on the MFMA (4 input channels): SD2.1 shape, + residual (ControlNet conditioning), ragged M and N
+    (2, 4, 64, 64, 320, 3, 1, False, True, False), (1, 4, 24, 40, 320, 3, 1, False, True, True), (1, 4, 9, 11, 72, 3, 1, False, False, False),
 ]
 
 
