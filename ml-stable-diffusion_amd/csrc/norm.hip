@@ -256,14 +256,14 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const half_t* __re
 // reduction, then affine (+SiLU) and the concatenated store.  Replaces the two dependent launches of
 // the slab version - a UNet step is launch-latency-bound on its ~60 GroupNorms (~4 us per dependent
 // launch), not bandwidth-bound.  VW = halves per vector access (alignment of the group's channel run).
-template <int VW>
-__global__ __launch_bounds__(256) void groupnorm_fused_kernel(const half_t* __restrict__ x0, int C0,
+template <int VW, int NT = 256>   // NT threads per (group, sample): 1024 for the 32x32 level (one launch instead of two, 16 waves per slice)
+__global__ __launch_bounds__(NT) void groupnorm_fused_kernel(const half_t* __restrict__ x0, int C0,
                                                               const half_t* __restrict__ x1, int C1,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, half_t* __restrict__ y,
                                                               int HW, int G, float eps, int silu) {
   typedef _Float16 vec_t __attribute__((ext_vector_type(VW)));
-  __shared__ float red[16];
+  __shared__ float red[2 * (NT / 64)];
   __shared__ float s_sc[128], s_sh[128];
   const int C = C0 + C1;
   const int cpg = C / G;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void groupnorm_fused_kernel(const half_t* __re
   const int nv = cpg / VW;                       // vectors per pixel
   const int items = HW * nv;
   float s = 0.f, q = 0.f;
-  for (int it = t; it < items; it += 256) {
+  for (int it = t; it < items; it += NT) {
     const int p = it / nv, v = it - p * nv;
     const int c = c0 + v * VW;
     const half_t* src = (c < C0) ? x0 + ((size_t)b * HW + p) * C0 + c : x1 + ((size_t)b * HW + p) * C1 + (c - C0);
@@ -286,13 +286,19 @@ __global__ __launch_bounds__(256) void groupnorm_fused_kernel(const half_t* __re
   }
   s = wave_sum(s);
   q = wave_sum(q);
+  constexpr int NW = NT / 64;
   if ((t & 63) == 0) {
     red[t >> 6] = s;
-    red[4 + (t >> 6)] = q;
+    red[NW + (t >> 6)] = q;
   }
   __syncthreads();
-  s = (red[0] + red[1]) + (red[2] + red[3]);
-  q = (red[4] + red[5]) + (red[6] + red[7]);
+  s = 0.f;
+  q = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; w += 4) {   // fixed order: deterministic
+    s += (red[w] + red[w + 1]) + (red[w + 2] + red[w + 3]);
+    q += (red[NW + w] + red[NW + w + 1]) + (red[NW + w + 2] + red[NW + w + 3]);
+  }
   const float inv_n = 1.0f / ((float)cpg * (float)HW);
   const float mean = s * inv_n;
   const float rstd = rsqrtf(fmaxf(q * inv_n - mean * mean, 0.f) + eps);
@@ -302,7 +308,7 @@ __global__ __launch_bounds__(256) void groupnorm_fused_kernel(const half_t* __re
     s_sh[t] = beta[c0 + t] - mean * sc;
   }
   __syncthreads();
-  for (int it = t; it < items; it += 256) {
+  for (int it = t; it < items; it += NT) {
     const int p = it / nv, v = it - p * nv;
     const int c = c0 + v * VW;
     const half_t* src = (c < C0) ? x0 + ((size_t)b * HW + p) * C0 + c : x1 + ((size_t)b * HW + p) * C1 + (c - C0);
@@ -412,6 +418,18 @@ void launch_groupnorm(const half_t* x0, int C0, const half_t* x1, int C1, float*
       hipLaunchKernelGGL(groupnorm_fused_kernel<4>, grid, dim3(256), 0, s, x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu);
     else
       hipLaunchKernelGGL(groupnorm_fused_kernel<2>, grid, dim3(256), 0, s, x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu);
+    SD_HIP(hipGetLastError());
+    return;
+  }
+  // 32x32 level: one 1024-thread workgroup per (group, sample) instead of the slab pair (in sequence a dependent launch costs
+  // more than the second pass over a slice that is still in L2); SD_GN_WIDE=0 switches it off (A/B)
+  static const bool wide = !(getenv("SD_GN_WIDE") && atoi(getenv("SD_GN_WIDE")) == 0);
+  if (wide && HW <= 1024 && cpg >= 16 && cpg <= 48 && cpg % 4 == 0) {   // (60-channel groups measured slower: 20.8 vs 16.0 us)
+    dim3 grid(G, B);
+    if (cpg % 8 == 0)
+      hipLaunchKernelGGL((groupnorm_fused_kernel<8, 1024>), grid, dim3(1024), 0, s, x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu);
+    else
+      hipLaunchKernelGGL((groupnorm_fused_kernel<4, 1024>), grid, dim3(1024), 0, s, x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu);
     SD_HIP(hipGetLastError());
     return;
   }

@@ -152,7 +152,10 @@ def test_layernorm_matches_oracle(shape):
 @pytest.mark.parametrize("shape,eps,silu", [((2, 320, 64, 64), 1e-5, True), ((2, 320, 32, 32), 1e-6, False),
                                             ((2, 1920, 16, 16), 1e-5, True), ((2, 2560, 8, 8), 1e-5, True),
                                             ((1, 64, 5, 3), 1e-5, True), ((2, 32, 8, 8), 1e-6, False),
-                                            ((1, 960, 17, 9), 1e-5, True)])
+                                            ((1, 960, 17, 9), 1e-5, True),
+                                            # 32x32 level: the 1024-thread one-launch kernel (8- and 4-half vectors), ragged HW
+                                            ((2, 640, 32, 32), 1e-5, True), ((2, 1280, 32, 32), 1e-6, False),
+                                            ((1, 1920, 32, 32), 1e-5, True), ((2, 640, 23, 29), 1e-5, True)])
 def test_groupnorm_matches_torch(shape, eps, silu):
     b, c, hh, ww = shape
     rs = np.random.RandomState(c + hh)

@@ -17,9 +17,9 @@ if len(sys.argv) > 1:
     print(json.dumps(out))
 else:
     res = {}
-    for name, thr in (("slab", "0"), ("fused", "100000000")):
-        env = dict(os.environ, SD_GN_FUSED_MAX_HW=thr)
+    for name, thr, wide in (("slab", "0", "0"), ("wide", "256", "1"), ("fused", "100000000", "0")):
+        env = dict(os.environ, SD_GN_FUSED_MAX_HW=thr, SD_GN_WIDE=wide)
         r = subprocess.run([sys.executable, __file__, "x"], env=env, capture_output=True, text=True)
         res[name] = json.loads(r.stdout.strip().splitlines()[-1])
     for k in res["slab"]:
-        print(f"GN {k:10s}: slab {res['slab'][k]:6.1f} us   fused {res['fused'][k]:6.1f} us")
+        print(f"GN {k:10s}: slab pair {res['slab'][k]:6.1f} us   production (1024-thread one-launch at 32x32) {res['wide'][k]:6.1f} us   256-thread fused everywhere {res['fused'][k]:6.1f} us")
