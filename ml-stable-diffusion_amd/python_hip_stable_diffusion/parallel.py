@@ -88,3 +88,37 @@ def run_sharded(loop_fn, ehs_pairs, latents, dist=None, local_rank=0):
     mine = shard_prompts(n, world)[rank]
     out = loop_fn(latents[mine], cfg_batch(ehs_pairs[mine]))
     return gather_arrays(np.asarray(out, np.float32), dist, local_rank)
+
+
+def run_cfg_split(unet_fn, scheduler, ehs_pair, latents, guidance_scale, dist, local_rank=0):
+    """Optional LATENCY mode for one prompt on two GPUs: rank 0 evaluates the unconditional half of
+    the classifier-free-guidance batch, rank 1 the text half - each with a UNet handle of batch 1 - and the two noise
+    predictions are exchanged ONCE per step (2-rank all_gather of 4 x h x w f32 = 64 KB at 512x512, one xGMI link); both ranks
+    then do the guidance combine (pipeline.py:561-562) and the scheduler step redundantly, so the latents stay identical
+    without a second exchange.  ``unet_fn(latents (1,4,h,w) f32, timestep, encoder_hidden_states (1,C,1,L) f16) -> noise
+    (1,4,h,w) f32`` is the per-rank model call (the host-stepped `HipModel.__call__` path: a per-step collective cannot sit
+    inside the device-resident loop); ``ehs_pair`` is (2, C, 1, L) = [uncond, cond] on rank 0 (broadcast to rank 1).
+    Returns the final latents (the same array on both ranks)."""
+    if dist is None or dist.get_world_size() != 2:
+        raise ValueError("run_cfg_split needs exactly two ranks (rank 0 = uncond, rank 1 = cond)")
+    rank = dist.get_rank()
+    import torch
+    meta = torch.zeros(6, dtype=torch.int64)
+    if rank == 0:
+        e, l = np.asarray(ehs_pair), np.asarray(latents)
+        if e.shape[0] != 2 or l.shape[0] != 1:
+            raise ValueError("run_cfg_split takes one prompt: ehs_pair (2, C, 1, L), latents (1, 4, h, w)")
+        meta = torch.tensor(list(e.shape[1:]) + list(l.shape[1:]), dtype=torch.int64)
+    meta = meta.to(_device(dist, local_rank))
+    dist.broadcast(meta, src=0)
+    c, one, length, lc, lh, lw = [int(v) for v in meta.tolist()]
+    ehs_pair = broadcast_array(ehs_pair if rank == 0 else None, (2, c, one, length), np.float16, dist, local_rank)
+    x = broadcast_array(latents if rank == 0 else None, (1, lc, lh, lw), np.float32, dist, local_rank)
+    mine = ehs_pair[rank:rank + 1]
+    for t in scheduler.timesteps:
+        xin = scheduler.scale_model_input(x, t)
+        eps_local = np.asarray(unet_fn(xin, t, mine), np.float32)
+        both = gather_arrays(eps_local, dist, local_rank)          # [uncond, cond] in rank order
+        eps = both[0:1] + guidance_scale * (both[1:2] - both[0:1])
+        x = np.asarray(scheduler.step(eps, t, x).prev_sample, np.float32)
+    return x

@@ -121,6 +121,60 @@ def test_config3_two_prompts_per_rank_world_size_two():
                                                                          "broadcast": lambda s, t, src=0: None})())
 
 
+def _cfg_split_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rs = np.random.RandomState(3)
+        ehs = rs.randn(2, 16, 1, 77).astype(np.float16) if rank == 0 else None
+        lat = rs.randn(1, 4, 8, 8).astype(np.float32) if rank == 0 else None
+        sch = schedulers.DDIMScheduler()
+        sch.set_timesteps(5)
+        calls = []
+
+        def unet(x, t, e):   # stand-in for a batch-1 HipModel: any function of (latents, timestep, this rank's embedding)
+            calls.append((x.shape, e.shape))
+            return 0.3 * x + float(e.astype(np.float32).mean()) + 1e-3 * float(t)
+
+        out = parallel.run_cfg_split(unet, sch, ehs, lat, 7.5, dist)
+        q.put((rank, calls, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cfg_split_latency_mode_world_size_two():
+    """SURVEY section 8e optional mode: one prompt on two ranks (uncond / cond), one 2-rank exchange of the noise prediction per
+    step, redundant guidance combine + scheduler step - equal to the single-process CFG loop (pipeline.py:500-573)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cfg_split_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rs = np.random.RandomState(3)
+    ehs = rs.randn(2, 16, 1, 77).astype(np.float16)
+    x = rs.randn(1, 4, 8, 8).astype(np.float32)
+    sch = schedulers.DDIMScheduler()
+    sch.set_timesteps(5)
+    for t in sch.timesteps:   # the reference's loop on one process, batch [uncond, cond]
+        eps = [0.3 * x + float(ehs[i].astype(np.float32).mean()) + 1e-3 * float(t) for i in range(2)]
+        x = sch.step(eps[0] + 7.5 * (eps[1] - eps[0]), t, x).prev_sample
+    for rank, calls, out in results:
+        assert calls == [((1, 4, 8, 8), (1, 16, 1, 77))] * 5          # batch 1 per rank, one call per step
+        np.testing.assert_allclose(out, x, rtol=1e-5, atol=1e-6)
+    assert np.array_equal(results[0][2], results[1][2])               # both ranks hold the same latents
+    with pytest.raises(ValueError):
+        parallel.run_cfg_split(lambda *a: None, sch, ehs, x, 7.5, None)
+
+
 def test_single_process_degenerate_case():
     a = np.ones((2, 3), np.float32)
     assert np.array_equal(parallel.broadcast_array(a, (2, 3), np.float32, None), a)
