@@ -57,6 +57,7 @@ struct IgemmArgs {
   // (the V^T operand of attention); columns below it to out with row length ldo
   int n_trans, ldo;
   half_t* out_t;
+  int res_pre;   // 1: igemm_kernel fetches its residual tile at kernel entry (SD_RES_PREFETCH=0 switches it off, A/B)
 };
 
 // exact-GELU (erf form, unet.py:613-617 via F.gelu) with erf from Abramowitz-Stegun 7.1.26:
@@ -100,10 +101,13 @@ __device__ __forceinline__ void dma16_to_lds(const __amdgpu_buffer_rsrc_t& rs, c
 // n = n0 + (r&3) + 8*(r>>2) + 4*hi ; m = m0 + (lane&31).  Split-K slabs, or bias / timestep embedding / LayerNorm fold /
 // GEGLU / residual / fused q|k|v write-out staged through LDS (`smem` is free: the caller's K loop is over and every wave
 // has passed a barrier after its last fragment read - this function starts with its own barrier for that).
-template <int BM, int BN, int WGM, int WGN, int TM, int TN, bool LNF>
+// resv (NRES > 0, use_resv): the residual chunks of the final store loop, fetched by the caller at kernel entry - read here, a
+// residual tile costs every workgroup one exposed memory round trip after its K loop.
+template <int BM, int BN, int WGM, int WGN, int TM, int TN, bool LNF, int NRES = 0>
 __device__ __forceinline__ void tile_epilogue(const IgemmArgs& a, floatx16 (&acc)[TM][TN], const float (&ln_a)[TM],
                                               const float (&ln_b)[TM], char* smem, float* sconst, float const_b, float const_t,
-                                              float const_c, int m_blk, int n_blk, int wave, int split, bool temb_uniform) {
+                                              float const_c, int m_blk, int n_blk, int wave, int split, bool temb_uniform,
+                                              const half8* resv = nullptr, bool use_resv = false) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wm = wave / WGN, wn = wave % WGN;
   const int frow = lane & 31, hi = lane >> 5;
@@ -225,6 +229,29 @@ __device__ __forceinline__ void tile_epilogue(const IgemmArgs& a, floatx16 (&acc
     const int nb0 = geglu ? (n_blk >> 1) : n_blk;         // first output column of this tile
     constexpr int OWC = OW / 8;                           // 16-B chunks per staged row (GEGLU: first half used)
     const int wc = geglu ? OWC / 2 : OWC;
+    if constexpr (NRES > 0) {
+      if (use_resv) {   // (never GEGLU: wc == OWC, BM * OWC == NRES * 256)
+#pragma unroll
+        for (int it = 0; it < NRES; ++it) {
+          const int idx = tid + it * 256;
+          const int r = idx / OWC, c = idx - r * OWC;
+          const int m = m_blk + r, n = nb0 + c * 8;
+          if (m < a.M && n < NO) {
+            half8 v = *reinterpret_cast<const half8*>(ot + r * OROW + c * 8);
+            half_t* dst = a.out + (size_t)m * NO + n;
+            if (n + 8 <= NO) {
+              const half8 rr = resv[it];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
+              *reinterpret_cast<half8*>(dst) = v;
+            } else {
+              for (int e = 0; e < NO - n; ++e) dst[e] = (half_t)((float)v[e] + (float)a.res[(size_t)m * NO + n + e]);
+            }
+          }
+        }
+        return;
+      }
+    }
     for (int idx = tid; idx < BM * wc; idx += 256) {
       const int r = idx / wc, c = idx - r * wc;
       const int m = m_blk + r, n = nb0 + c * 8;
@@ -516,6 +543,23 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     }
   }
 
+  // residual tile of the final store loop, requested now (oldest VMEM ops: the ring's counted waits are unaffected)
+  constexpr int RIT = BM * BN / 8 / 256;
+  constexpr bool RES_PRE = !TRANS_OUT && GLDS && RIT <= 4 && DBG == 0;
+  half8 resv[RES_PRE ? RIT : 1];
+  const bool use_resv = RES_PRE && a.res_pre && a.res != nullptr && a.splitk == 1 && a.out_mode == kOutHalf && n_blk < a.n_trans;
+  if constexpr (RES_PRE) {
+    if (use_resv) {
+#pragma unroll
+      for (int it = 0; it < RIT; ++it) {
+        const int idx = tid + it * 256;
+        const int r = idx / (BN / 8), c = idx - r * (BN / 8);
+        const int m = m_blk + r, n = n_blk + c * 8;
+        const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        resv[it] = (m < a.M && n + 8 <= a.ldo) ? *reinterpret_cast<const half8*>(a.res + (size_t)m * a.ldo + n) : z;
+      }
+    }
+  }
   if (prof) prof_t[1] = clock64();
   if constexpr (GLDS && NST >= 3) {
     // NST-stage ring: the DMA of tile kt+NST-1 is issued while tile kt is computed and tiles
@@ -625,8 +669,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
       }
     return;
   } else {
-    tile_epilogue<BM, BN, WGM, WGN, TM, TN, LNF>(a, acc, ln_a, ln_b, smem, sconst, const_b, const_t, const_c, m_blk, n_blk, wave, split,
-                                                 temb_uniform);
+    tile_epilogue<BM, BN, WGM, WGN, TM, TN, LNF, (RES_PRE ? RIT : 0)>(a, acc, ln_a, ln_b, smem, sconst, const_b, const_t, const_c, m_blk,
+                                                                      n_blk, wave, split, temb_uniform, resv, use_resv);
   }
   if (prof) {
     prof_t[3] = clock64();
@@ -1640,6 +1684,8 @@ IgemmArgs make_args(const ConvDesc& d) {
   a.n_trans = d.out_t ? d.n_trans : 0x7fffffff;
   a.ldo = d.out_t ? d.n_trans : d.N;
   a.out_t = d.out_t;
+  static const int res_pre = !(getenv("SD_RES_PREFETCH") && atoi(getenv("SD_RES_PREFETCH")) == 0);
+  a.res_pre = res_pre;
   return a;
 }
 

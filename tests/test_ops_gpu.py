@@ -281,7 +281,7 @@ def test_timestep_embedding_reference_golden():
     np.testing.assert_allclose(_lib.timestep_embedding(ts, 256), unet_ref.timestep_embedding(torch.from_numpy(ts), 256).numpy(), atol=1e-4)
 
 
-@pytest.mark.parametrize("tile,splitk", [(3, 8), (33, 16), (6, 4), (26, 2), (1, 4), (37, 2), (7, 1)])
+@pytest.mark.parametrize("tile,splitk", [(3, 8), (33, 16), (6, 4), (26, 2), (1, 4), (37, 2), (7, 1), (47, 1), (57, 2)])
 def test_splitk_is_complete_and_bit_reproducible(tile, splitk):
     """Split-K: fp32 slabs per K slice, combined in slice order by the reduce kernel (no atomics): repeated launches
     must agree bit for bit, and with torch.  A weight-streaming shape (M = 128 rows, K = 11520), up to 16 slices.
