@@ -177,7 +177,7 @@ def main():
 
 def hbm_traffic(step_ms):
     """HBM bytes per step from the committed rocprofv3 PMC passes (bench.py cannot run under the profiler
-    itself): profiles/r02_final_hbm_traffic.json is written by tools/pmc_traffic.py from separate --pmc
+    itself): profiles/r02_final_hbm_traffic.json is written by tools/pmc_reduce.py from separate --pmc
     FETCH_SIZE / WRITE_SIZE runs of the same step, corrected as MI355X_MICROARCH.md prescribes."""
     path = os.path.join(ROOT, "profiles", "r02_final_hbm_traffic.json")
     if not os.path.exists(path):

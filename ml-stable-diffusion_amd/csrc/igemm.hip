@@ -1121,7 +1121,7 @@ __global__ __launch_bounds__(256, halo_lds_bytes(64, D) <= 80 * 1024 ? 2 : 1) vo
   }
 
   // the halo of one channel chunk: which of the two concatenated sources it comes from is decided once per chunk
-  // (HALO_SRC declares rs / off[] / soff for chunk `ch`; a struct cannot hold the buffer resource type on the host pass)
+  // (HALO_SRC declares rs / off[] / soff for chunk `ch` as plain locals)
 #define HALO_SRC(rs, off, soff, ch)                                                                                        \
   const bool rs##_second = (ch) * BK >= a.C0; /* wave-uniform */                                                           \
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(                                                     \
