@@ -24,7 +24,7 @@ Extra objects on the JSON line:
   roofline     MFMA roofline of the step graph: algorithmic FLOP per step (SURVEY.md section 8d:
                1.6085e12 per CFG-batch-2 step) / HIP-event time per step on the handle's stream;
                `traffic` = HBM bytes per step from rocprofv3 PMC passes (profiles/r02_final_hbm_traffic.json,
-               tools/gpu_pmc_traffic.sh), `dominant_kernel` = the largest conv family timed IN SEQUENCE
+               tools/gpu_r2_r.sh), `dominant_kernel` = the largest conv family timed IN SEQUENCE
                (sd_unet_profile: HIP events around every op of the eager step) next to its stand-alone time
   cpu_baseline the oracle (CPU restatement of the reference UNet + loop) timed on this box's host
                cores on a bounded sample (rank 0, N=1 only) at the best of a small thread sweep; kind "port"
