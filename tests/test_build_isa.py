@@ -1,0 +1,42 @@
+"""CPU suite: invariants of the compiled gfx950 code that the performance of the hot path depends on (hipcc cross-compiles
+without a GPU): no kernel spills to scratch, and the kernels that are meant to run two workgroups per CU fit 256 VGPRs."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "ml-stable-diffusion_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def kernel_resources(src, tmp_path):
+    out = tmp_path / (os.path.basename(src) + ".s")
+    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-DNDEBUG", "--cuda-device-only", "-S", src, "-o", str(out)],
+                   check=True, cwd=CSRC, stderr=subprocess.DEVNULL)
+    res = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", out.read_text(), re.S):
+        body = m.group(2)
+        res[m.group(1)] = (int(re.search(r"next_free_vgpr (\d+)", body).group(1)),
+                           int(re.search(r"private_segment_fixed_size (\d+)", body).group(1)))
+    return res
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+@pytest.mark.parametrize("src", ["igemm.hip", "attention.hip", "norm.hip", "misc.hip"])
+def test_no_kernel_spills_and_two_workgroups_per_cu_where_planned(src, tmp_path):
+    res = kernel_resources(os.path.join(CSRC, src), tmp_path)
+    assert res, "no kernels found"
+    spilled = {k: v for k, v in res.items() if v[1] != 0}
+    assert not spilled, f"kernels with scratch (register spills): {spilled}"
+    if src == "igemm.hip":
+        # the K-split halo kernel with rings of <= 4 stages (78 KB of LDS) runs two workgroups per CU: <= 256 VGPRs;
+        # so do the 64x64 / 64x128 / 128x64 GEMM tiles with 2-4 stages
+        for name, (vgpr, _) in res.items():
+            m = re.search(r"conv3x3_halo_ks_kernelILi(\d+)ELi0E", name)
+            if m and int(m.group(1)) <= 4:
+                assert vgpr <= 256, (name, vgpr)
+            if "igemm_kernelILi64ELi64E" in name:
+                assert vgpr <= 256, (name, vgpr)
