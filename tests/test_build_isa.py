@@ -40,3 +40,28 @@ def test_no_kernel_spills_and_two_workgroups_per_cu_where_planned(src, tmp_path)
                 assert vgpr <= 256, (name, vgpr)
             if "igemm_kernelILi64ELi64E" in name:
                 assert vgpr <= 256, (name, vgpr)
+
+
+def test_plan_table_rows_are_well_formed_and_unique():
+    """csrc/tuned_convs.inc: every row is {kind, ksize, stride, up, Ctot, N, M, tile, staging, splitk} with legal codes, no
+    shape key twice (the first match wins in choose_plan, a duplicate would be dead), the K-split halo kernel (tile 7) only on
+    3x3 / stride-1 shapes, split-K only where the epilogue kind can split."""
+    rows = []
+    for line in open(os.path.join(CSRC, "tuned_convs.inc")):
+        if line.startswith("{"):
+            v = [int(x) for x in re.findall(r"-?\d+", line.split("}")[0])]
+            assert len(v) == 10, line
+            rows.append(v)
+    assert len(rows) >= 40
+    keys = [tuple(r[:7]) for r in rows]
+    assert len(set(keys)) == len(keys), [k for k in keys if keys.count(k) > 1]
+    for kind, ks, st, up, ctot, n, m, tile, staging, sk in rows:
+        assert kind in (0, 1, 2, 3) and ks in (1, 3) and st in (1, 2) and up in (1, 2)
+        assert ctot % 64 == 0 and n % 4 == 0 and m > 0
+        assert 1 <= tile <= 7 and 0 <= staging <= 5 and 0 <= sk <= 16
+        if tile in (5, 6, 7):
+            assert ks == 3 and st == 1 and (up == 1 or tile == 7)
+        if kind != 0:
+            assert sk in (0, 1) and tile in (1, 2, 3, 4)
+        if kind == 2:
+            assert tile in (1, 4)
