@@ -128,22 +128,30 @@ class TorchCpuRandom(NumpyLegacyRandom):
         return data
 
 
+def philox4x32_10(counter, key):
+    """Philox4x32-10 block function (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11; the generator behind
+    torch's CUDA RNG and NvRandomSource.swift:25-63): 4 x 32-bit counter, 2 x 32-bit key -> 4 x 32-bit output.  Pinned
+    against the published known-answer vectors of the Random123 distribution (tests/test_oracle.py)."""
+    m0, m1, w0, w1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+    c, k = [int(x) & M32 for x in counter], [int(x) & M32 for x in key]
+    for r in range(10):
+        v1 = c[0] * m0
+        v2 = c[2] * m1
+        c = [((v2 >> 32) ^ c[1] ^ k[0]) & M32, v2 & M32, ((v1 >> 32) ^ c[3] ^ k[1]) & M32, v1 & M32]
+        if r < 9:
+            k = [(k[0] + w0) & M32, (k[1] + w1) & M32]
+    return c
+
+
 def philox_randn(seed, offset, n):
     """torch.randn on a CUDA device as swift/StableDiffusion/pipeline/NvRandomSource.swift:25-80 restates it:
     Philox4x32-10 with counter (offset, 0, i, 0) and key (seed lo, seed hi) per element i, Box-Muller on the first
-    two output words.  ``offset`` counts previous calls (the Swift struct increments it per array).  No golden
-    exists in the reference and no CUDA device here: PARITY UNPINNED."""
-    m0, m1, w0, w1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+    two output words.  ``offset`` counts previous calls (the Swift struct increments it per array).  The block function is
+    pinned against the published known-answer vectors; the counter layout and the Box-Muller step follow the Swift code and
+    have no golden in the reference (no CUDA device here): that part stays PARITY UNPINNED."""
     out = []
     for i in range(n):
-        c = [offset & M32, 0, i & M32, 0]
-        k = [seed & M32, (seed >> 32) & M32]
-        for r in range(10):
-            v1 = c[0] * m0
-            v2 = c[2] * m1
-            c = [((v2 >> 32) ^ c[1] ^ k[0]) & M32, v2 & M32, ((v1 >> 32) ^ c[3] ^ k[1]) & M32, v1 & M32]
-            if r < 9:
-                k = [(k[0] + w0) & M32, (k[1] + w1) & M32]
+        c = philox4x32_10([offset & M32, 0, i & M32, 0], [seed & M32, (seed >> 32) & M32])
         u = c[0] / 4294967296.0 + (1.0 / 8589934592.0)
         v = c[1] * (math.pi / 2147483648.0) + (math.pi / 4294967296.0)
         out.append(math.sqrt(-2.0 * math.log(u)) * math.sin(v))

@@ -179,3 +179,16 @@ def test_clip_oracle_matches_the_installed_transformers(name):
         np.testing.assert_allclose(mine["text_embeds"].numpy(), ref.text_embeds.numpy(), atol=2e-4)
     else:
         np.testing.assert_allclose(mine["pooler_output"].numpy(), ref.pooler_output.numpy(), atol=2e-4)
+
+
+def test_philox_block_function_matches_the_published_known_answer_vectors():
+    """Philox4x32-10 (the generator of NvRandomSource.swift:25-63 / torch's CUDA RNG): the three known-answer vectors of the
+    Random123 distribution (kat_vectors: all-zero, all-ones, digits of pi).  The C ABI's sd_philox_randn is compared with the
+    oracle built on this function in tests/test_library_abi.py."""
+    from oracle import rng_ref
+    kat = [([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+           ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+            [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for counter, key, want in kat:
+        assert rng_ref.philox4x32_10(counter, key) == want
