@@ -192,3 +192,26 @@ def test_philox_block_function_matches_the_published_known_answer_vectors():
             [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
     for counter, key, want in kat:
         assert rng_ref.philox4x32_10(counter, key) == want
+
+
+def test_tokenizer_reproduces_the_reference_test_vectors(tmp_path):
+    """The tokenizer is out of scope (transformers' CLIPTokenizer is used like the reference's Python pipeline does), but the
+    reference's own test holds two known-answer prompts (swift/StableDiffusionTests/StableDiffusionTests.swift:43-49) for the
+    vocabulary it ships: `load_tokenizer` on that vocabulary must give the same ids.  Reads the vocabulary from the reference
+    tree in place, so it only runs where /root/reference exists (never on the GPU box)."""
+    import os
+    import shutil
+    res = "/root/reference/swift/StableDiffusionTests/Resources"
+    if not os.path.exists(os.path.join(res, "vocab.json")):
+        pytest.skip("reference resources not available here")
+    from python_hip_stable_diffusion.text_encoder import load_tokenizer
+    folder = tmp_path / "tokenizer"
+    folder.mkdir()
+    for f in ("vocab.json", "merges.txt"):
+        shutil.copy(os.path.join(res, f), folder / f)       # temporary copy outside the repository
+    tok = load_tokenizer(str(folder))
+    for prompt, want in (("a photo of an astronaut riding a horse on mars",
+                          [49406, 320, 1125, 539, 550, 18376, 6765, 320, 4558, 525, 7496, 49407]),
+                         ("Apple CoreML developer tools on a Macbook Air are fast",
+                          [49406, 3055, 19622, 5780, 10929, 5771, 525, 320, 20617, 1922, 631, 1953, 49407])):
+        assert tok(prompt)["input_ids"] == want
