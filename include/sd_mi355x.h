@@ -250,6 +250,21 @@ int sd_op_groupnorm(const void* x, const float* weight, const float* bias, void*
 int sd_op_conv2d(const void* x, const void* w, const float* bias, const void* res, void* out, int B, int Cin, int H,
                  int W, int Cout, int ksize, int stride, int upsample, int tile, int splitk, int force_generic,
                  int iters, float* ms);
+/* The same conv followed by torch.nn.GroupNorm (+ SiLU) of its output (unet.py:470-489 conv -> norm -> SiLU; stride 1, no
+ * upsample): with producer_stats = 1 the GroupNorm statistics come out of the conv kernel's own epilogue (one launch less per
+ * GroupNorm), with 0 from the GroupNorm's own statistics pass.  *entries (may be NULL) returns the number of partial
+ * (sum, sumsq) entries per (sample, group) the conv wrote - 0 when its plan cannot produce them.  conv_out (may be NULL) receives
+ * the conv result, out the normalised tensor; both (B, Cout, H, W) f16 NCHW. */
+int sd_op_conv2d_groupnorm(const void* x, const void* w, const float* bias, const void* res, const float* gn_weight,
+                           const float* gn_bias, void* conv_out, void* out, int B, int Cin, int H, int W, int Cout, int ksize,
+                           int groups, float eps, int silu, int tile, int producer_stats, int* entries, int iters, float* ms);
+/* Cross-attention front half as one launch (unet.py:87-118 inside :586-591): out = softmax(to_q(LayerNormANE(x)) k^T / 8) v
+ * per head, head dim 64, Sk <= 96 (the prompt), Sq % 128 == 0.  x (B, heads*64, 1, Sq), k / v (B, heads*64, 1, Sk) f16 BC1S,
+ * ln_weight / ln_bias (C) f32 as in the checkpoint (x_hat * w + b), wq (C, C) f16 -> out (B, C, 1, Sq) f16.  nst: LDS-DMA
+ * ring depth 2-4 (0 = heuristic). */
+int sd_op_cross_attention_fused(const void* x, const float* ln_weight, const float* ln_bias, const void* wq, const void* k,
+                                const void* v, void* out, int B, int heads, int Sq, int Sk, float eps, int nst, int iters,
+                                float* ms);
 /* GEGLU feed-forward first half (unet.py:609-617): x (M, C) f16, w (8C', C) f16, bias (8C'/.. ) */
 int sd_op_geglu(const void* x, const void* w, const float* bias, void* out, int M, int C, int N2, int iters, float* ms);
 /* unet.py:703-728 */

@@ -424,6 +424,129 @@ int sd_op_conv2d(const void* x, const void* w, const float* bias, const void* re
   });
 }
 
+int sd_op_conv2d_groupnorm(const void* x, const void* w, const float* bias, const void* res, const float* gn_weight,
+                           const float* gn_bias, void* conv_out, void* out, int B, int Cin, int H, int W, int Cout, int ksize,
+                           int groups, float eps, int silu, int tile, int producer_stats, int* entries, int iters, float* ms) {
+  return guarded([&] {
+    SD_REQUIRE(x && w && gn_weight && gn_bias && out, kInvalidArgument, "NULL argument");
+    SD_REQUIRE(ksize == 1 || ksize == 3, kInvalidArgument, "conv2d_groupnorm: ksize %d", ksize);
+    Scratch sc;
+    std::vector<half_t> xt = nchw_to_nhwc(reinterpret_cast<const half_t*>(x), B, Cin, H, W);
+    const half_t* wh = reinterpret_cast<const half_t*>(w);
+    const int kk = ksize * ksize;
+    std::vector<half_t> wt((size_t)Cout * Cin * kk);
+    for (int o = 0; o < Cout; ++o)
+      for (int c = 0; c < Cin; ++c)
+        for (int t = 0; t < kk; ++t) wt[((size_t)o * kk + t) * Cin + c] = wh[((size_t)o * Cin + c) * kk + t];
+    ConvDesc d;
+    d.x0 = sc.dev<half_t>(xt.size(), xt.data());
+    d.C0 = Cin;
+    d.w = sc.dev<half_t>(wt.size(), wt.data());
+    d.bias = bias ? sc.dev<float>(Cout, bias) : nullptr;
+    std::vector<half_t> rt;
+    if (res) {
+      rt = nchw_to_nhwc(reinterpret_cast<const half_t*>(res), B, Cout, H, W);
+      d.res = sc.dev<half_t>(rt.size(), rt.data());
+    }
+    const size_t on = (size_t)B * H * W * Cout;
+    half_t* dconv = sc.dev<half_t>(on);
+    half_t* dy = sc.dev<half_t>(on);
+    d.out = dconv;
+    d.B = B; d.Hi = H; d.Wi = W; d.Ho = H; d.Wo = W;
+    d.ksize = ksize; d.stride = 1; d.up = 1; d.N = Cout;
+    d.tile = tile % 10;
+    d.staging = tile / 10;
+    d.splitk = 1;
+    const bool fast = conv_fast_path_ok(d);   // else: conv_in's 4-channel MFMA kernel / the direct kernels
+    float* partial = sc.dev<float>(groupnorm_scratch_floats(B, H * W, groups));
+    // poison the partial buffer: the fold must only read what the producer wrote
+    {
+      std::vector<float> poison(groupnorm_scratch_floats(B, H * W, groups), 1.0e30f);
+      SD_HIP(hipMemcpy(partial, poison.data(), poison.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    if (producer_stats) {
+      d.gn_partial = partial;
+      d.gn_groups = groups;
+    }
+    float* dgw = sc.dev<float>(Cout, gn_weight);
+    float* dgb = sc.dev<float>(Cout, gn_bias);
+    ConvWorkspace ws;
+    int n_entries = 0;
+    sc.timed(iters, ms, [&] {
+      n_entries = fast ? launch_conv(d, ws, sc.stream) : launch_conv_generic(d, 0, sc.stream);
+      launch_groupnorm(dconv, Cout, nullptr, 0, partial, dgw, dgb, dy, B, H * W, groups, eps, silu, sc.stream, n_entries);
+    });
+    if (entries) *entries = n_entries;
+    std::vector<half_t> ot(on);
+    if (conv_out) {
+      SD_HIP(hipMemcpy(ot.data(), dconv, on * 2, hipMemcpyDeviceToHost));
+      nhwc_to_nchw(ot.data(), reinterpret_cast<half_t*>(conv_out), B, Cout, H, W);
+    }
+    SD_HIP(hipMemcpy(ot.data(), dy, on * 2, hipMemcpyDeviceToHost));
+    nhwc_to_nchw(ot.data(), reinterpret_cast<half_t*>(out), B, Cout, H, W);
+  });
+}
+
+int sd_op_cross_attention_fused(const void* x, const float* ln_weight, const float* ln_bias, const void* wq, const void* k,
+                                const void* v, void* out, int B, int heads, int Sq, int Sk, float eps, int nst, int iters,
+                                float* ms) {
+  return guarded([&] {
+    SD_REQUIRE(x && ln_weight && ln_bias && wq && k && v && out, kInvalidArgument, "NULL argument");
+    const int C = heads * 64;
+    SD_REQUIRE(B > 0 && heads > 0 && xattn_fused_ok(C, heads, Sq, Sk), kUnsupported,
+               "cross_attention_fused: heads %d x 64 channels, Sq %d (need Sq %% 128 == 0), Sk %d (<= 96)", heads, Sq, Sk);
+    Scratch sc;
+    const int ldv = (Sk + 7) / 8 * 8;
+    const half_t* xh = reinterpret_cast<const half_t*>(x);
+    const half_t* kh = reinterpret_cast<const half_t*>(k);
+    const half_t* vh = reinterpret_cast<const half_t*>(v);
+    const half_t* wh = reinterpret_cast<const half_t*>(wq);
+    std::vector<half_t> xt((size_t)B * Sq * C), kt((size_t)B * Sk * C), vt((size_t)B * C * ldv, (half_t)0);
+    for (int b = 0; b < B; ++b)
+      for (int c = 0; c < C; ++c) {
+        for (int s = 0; s < Sq; ++s) xt[((size_t)b * Sq + s) * C + c] = xh[((size_t)b * C + c) * Sq + s];
+        for (int s = 0; s < Sk; ++s) {
+          kt[((size_t)b * Sk + s) * C + c] = kh[((size_t)b * C + c) * Sk + s];
+          vt[((size_t)b * C + c) * ldv + s] = vh[((size_t)b * C + c) * Sk + s];
+        }
+      }
+    // the LayerNorm fold of UNet::fold_layernorm: w' = W * gamma (fp16), colsum of what the MFMA multiplies, bias' = W . beta
+    std::vector<half_t> wf((size_t)C * C);
+    std::vector<float> colsum(C), biasf(C);
+    for (int o = 0; o < C; ++o) {
+      double cs = 0.0, bb = 0.0;
+      for (int c = 0; c < C; ++c) {
+        const float wv = (float)wh[(size_t)o * C + c];
+        const half_t hq = (half_t)(wv * ln_weight[c]);
+        wf[(size_t)o * C + c] = hq;
+        cs += (double)(float)hq;
+        bb += (double)wv * (double)ln_bias[c];
+      }
+      colsum[o] = (float)cs;
+      biasf[o] = (float)bb;
+    }
+    XAttnDesc d;
+    d.x = sc.dev<half_t>(xt.size(), xt.data());
+    d.wq = sc.dev<half_t>(wf.size(), wf.data());
+    d.bias = sc.dev<float>(C, biasf.data());
+    d.colsum = sc.dev<float>(C, colsum.data());
+    d.k = sc.dev<half_t>(kt.size(), kt.data());
+    d.vt = sc.dev<half_t>(vt.size(), vt.data());
+    half_t* o = sc.dev<half_t>((size_t)B * Sq * C);
+    d.out = o;
+    d.M = B * Sq; d.C = C; d.S = Sq; d.L = Sk; d.ldv = ldv; d.heads = heads;
+    d.ln_eps = eps;
+    d.nst = nst;
+    sc.timed(iters, ms, [&] { launch_xattn_fused(d, sc.stream); });
+    std::vector<half_t> ot((size_t)B * Sq * C);
+    SD_HIP(hipMemcpy(ot.data(), o, ot.size() * 2, hipMemcpyDeviceToHost));
+    half_t* oh = reinterpret_cast<half_t*>(out);
+    for (int b = 0; b < B; ++b)
+      for (int c = 0; c < C; ++c)
+        for (int s = 0; s < Sq; ++s) oh[((size_t)b * C + c) * Sq + s] = ot[((size_t)b * Sq + s) * C + c];
+  });
+}
+
 int sd_op_geglu(const void* x, const void* w, const float* bias, void* out, int M, int C, int N2, int iters, float* ms) {
   return guarded([&] {
     SD_REQUIRE(x && w && out && N2 % 2 == 0, kInvalidArgument, "bad GEGLU arguments");

@@ -58,7 +58,65 @@ struct IgemmArgs {
   int n_trans, ldo;
   half_t* out_t;
   int res_pre;   // 1: igemm_kernel fetches its residual tile at kernel entry (SD_RES_PREFETCH=0 switches it off, A/B)
+  // GroupNorm statistics of the OUTPUT tensor from this kernel's epilogue (the consumer is torch.nn.GroupNorm of
+  // unet.py:430-451 / :528-531): per (sample, group, m-tile) partial (sum, sumsq) of the fp16-rounded outputs, written to
+  // gn_partial [B][G][kGnMaxSlabs][2] at entry mt * 2 + slot (slot 1: the part of a group that began in the previous n-tile).
+  // Every entry < 2 * gn_T is written by exactly one workgroup per launch (no atomics: the replay stays bit-reproducible).
+  float* gn_partial;
+  int gn_G, gn_cpg, gn_T;   // groups, channels per group, m-tiles per sample
 };
+
+constexpr int kGnScratchFloats = 256 * 17;   // per-thread (sum[8], sumsq[8]) of the epilogue's store loop, +1 pad
+
+// Per-tile GroupNorm statistics from the store loop of an epilogue.  Thread t owns the 8-channel chunk (t % (BN/8)) of the
+// rows it stored; fs / fq are its sums over those rows.  scratch: kGnScratchFloats + 2 * BN floats of LDS that no thread
+// reads or writes any more.  Fixed-order reductions only.
+template <int BN>
+__device__ __forceinline__ void tile_gn_stats(const IgemmArgs& a, float* scratch, const float (&fs)[8], const float (&fq)[8],
+                                              int n_blk, int b, int mt) {
+  constexpr int OWC = BN / 8;
+  const int tid = threadIdx.x;
+  float* chan = scratch + kGnScratchFloats;   // [2][BN] per-channel sum | sumsq of this tile
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    scratch[tid * 17 + e] = fs[e];
+    scratch[tid * 17 + 8 + e] = fq[e];
+  }
+  __syncthreads();
+  for (int cc = tid; cc < 2 * BN; cc += 256) {
+    const int which = cc / BN, ch = cc - which * BN;
+    const int cl = ch >> 3, e = ch & 7;
+    float s = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < 256 / OWC; ++k) s += scratch[(k * OWC + cl) * 17 + which * 8 + e];
+    chan[cc] = s;
+  }
+  __syncthreads();
+  const int g0 = n_blk / a.gn_cpg;
+  const int g = g0 + tid;
+  const int n_end = min(n_blk + BN, a.N);
+  if (tid < BN && g < a.gn_G && g * a.gn_cpg < n_end) {
+    const int gs = g * a.gn_cpg, ge = gs + a.gn_cpg;
+    const int lo = max(gs, n_blk), hi = min(ge, n_end);
+    float s = 0.f, q = 0.f;
+    for (int c = lo; c < hi; ++c) {
+      s += chan[c - n_blk];
+      q += chan[BN + c - n_blk];
+    }
+    float* dst = a.gn_partial + (((size_t)b * a.gn_G + g) * kGnMaxSlabs + (size_t)mt * 2) * 2;
+    if (gs < n_blk) {            // the group began in the previous n-tile, which wrote slot 0
+      dst[2] = s;
+      dst[3] = q;
+    } else {
+      dst[0] = s;
+      dst[1] = q;
+      if (ge <= n_end) {         // the group ends inside this tile: nobody else writes slot 1
+        dst[2] = 0.f;
+        dst[3] = 0.f;
+      }
+    }
+  }
+}
 
 // exact-GELU (erf form, unet.py:613-617 via F.gelu) with erf from Abramowitz-Stegun 7.1.26:
 // |erf error| < 6.1e-7 in fp32, |gelu error| < 3.7e-7 absolute and < 1.7e-4 relative wherever
@@ -229,6 +287,10 @@ __device__ __forceinline__ void tile_epilogue(const IgemmArgs& a, floatx16 (&acc
     const int nb0 = geglu ? (n_blk >> 1) : n_blk;         // first output column of this tile
     constexpr int OWC = OW / 8;                           // 16-B chunks per staged row (GEGLU: first half used)
     const int wc = geglu ? OWC / 2 : OWC;
+    // GroupNorm statistics of what this tile stores (block-uniform; launch_conv checks: rows of one sample, N % 8 == 0)
+    const bool gn = a.gn_partial != nullptr && !geglu;
+    float fs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, fq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bool stored = false;
     if constexpr (NRES > 0) {
       if (use_resv) {   // (never GEGLU: wc == OWC, BM * OWC == NRES * 256)
 #pragma unroll
@@ -244,31 +306,53 @@ __device__ __forceinline__ void tile_epilogue(const IgemmArgs& a, floatx16 (&acc
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
               *reinterpret_cast<half8*>(dst) = v;
+              if (gn) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                  const float f = (float)v[e];
+                  fs[e] += f;
+                  fq[e] = fmaf(f, f, fq[e]);
+                }
+              }
             } else {
               for (int e = 0; e < NO - n; ++e) dst[e] = (half_t)((float)v[e] + (float)a.res[(size_t)m * NO + n + e]);
             }
           }
         }
-        return;
+        stored = true;
       }
     }
-    for (int idx = tid; idx < BM * wc; idx += 256) {
-      const int r = idx / wc, c = idx - r * wc;
-      const int m = m_blk + r, n = nb0 + c * 8;
-      if (m < a.M && n < NO) {
-        half8 v = *reinterpret_cast<const half8*>(ot + r * OROW + c * 8);
-        half_t* dst = a.out + (size_t)m * NO + n;
-        if (n + 8 <= NO) {
-          if (a.res) {
-            const half8 rr = *reinterpret_cast<const half8*>(a.res + (size_t)m * NO + n);
+    if (!stored) {
+      for (int idx = tid; idx < BM * wc; idx += 256) {
+        const int r = idx / wc, c = idx - r * wc;
+        const int m = m_blk + r, n = nb0 + c * 8;
+        if (m < a.M && n < NO) {
+          half8 v = *reinterpret_cast<const half8*>(ot + r * OROW + c * 8);
+          half_t* dst = a.out + (size_t)m * NO + n;
+          if (n + 8 <= NO) {
+            if (a.res) {
+              const half8 rr = *reinterpret_cast<const half8*>(a.res + (size_t)m * NO + n);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
+              for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
+            }
+            *reinterpret_cast<half8*>(dst) = v;
+            if (gn) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float f = (float)v[e];
+                fs[e] += f;
+                fq[e] = fmaf(f, f, fq[e]);
+              }
+            }
+          } else {   // ragged last chunk (N % 8 == 4)
+            for (int e = 0; e < NO - n; ++e) dst[e] = a.res ? (half_t)((float)v[e] + (float)a.res[(size_t)m * NO + n + e]) : v[e];
           }
-          *reinterpret_cast<half8*>(dst) = v;
-        } else {   // ragged last chunk (N % 8 == 4)
-          for (int e = 0; e < NO - n; ++e) dst[e] = a.res ? (half_t)((float)v[e] + (float)a.res[(size_t)m * NO + n + e]) : v[e];
         }
       }
+    }
+    if (gn) {   // scratch behind the staged tile (launch_variant sizes the LDS for it)
+      float* scratch = reinterpret_cast<float*>(smem + (((size_t)BM * OROW * sizeof(half_t) + 15) & ~(size_t)15));
+      tile_gn_stats<BN>(a, scratch, fs, fq, n_blk, m_blk / a.HoWo, (m_blk % a.HoWo) / BM);
     }
   }
 }
@@ -1363,6 +1447,8 @@ __global__ __launch_bounds__(256, halo_lds_bytes(64, D) <= 80 * 1024 ? 2 : 1) vo
     }
   __syncthreads();
   constexpr int WC = BN / 8;
+  const bool gn = a.gn_partial != nullptr;   // block-uniform (launch_conv: N % 8 == 0)
+  float fs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, fq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int idx = tid; idx < BM * WC; idx += 256) {
     const int r = idx / WC, c = idx - r * WC;
     const int y = y0 + (r >> 4), x = x0 + (r & 15);
@@ -1378,11 +1464,22 @@ __global__ __launch_bounds__(256, halo_lds_bytes(64, D) <= 80 * 1024 ? 2 : 1) vo
           for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
         }
         *reinterpret_cast<half8*>(dst) = v;
+        if (gn) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float f = (float)v[e];
+            fs[e] += f;
+            fq[e] = fmaf(f, f, fq[e]);
+          }
+        }
       } else {
         for (int e = 0; e < a.N - n; ++e) dst[e] = a.res ? (half_t)((float)v[e] + (float)a.res[m * a.N + n + e]) : v[e];
       }
     }
   }
+  // GroupNorm statistics of the stored pixels (only those inside the image); the scratch is the K-half reduction
+  // buffer at the start of the LDS, which nobody reads after the barrier above
+  if (gn) tile_gn_stats<BN>(a, reinterpret_cast<float*>(smem), fs, fq, n_blk, b, ty * a.tiles_x + tx);
 }
 
 #undef HALO_SRC
@@ -1686,6 +1783,8 @@ IgemmArgs make_args(const ConvDesc& d) {
   a.out_t = d.out_t;
   static const int res_pre = !(getenv("SD_RES_PREFETCH") && atoi(getenv("SD_RES_PREFETCH")) == 0);
   a.res_pre = res_pre;
+  a.gn_partial = nullptr;
+  a.gn_G = a.gn_cpg = a.gn_T = 0;
   return a;
 }
 
@@ -1954,6 +2053,9 @@ template <int BM, int BN, int WGM, int WGN, bool TRANS, bool GLDS, int NST, bool
 void launch_variant(const IgemmArgs& a, hipStream_t s) {
   const size_t lds = (size_t)NST * (BM + BN) * (GLDS ? BK : LDS_ROW) * sizeof(half_t) + 2 * BN * sizeof(float);
   static_assert((size_t)BN * (BM + 8) <= (size_t)NST * (BM + BN) * (GLDS ? BK : LDS_ROW), "transposed staging fits");
+  static_assert((size_t)BM * (BN + 8) * 2 + 16 + (kGnScratchFloats + 2 * BN) * sizeof(float) <=
+                    (size_t)NST * (BM + BN) * (GLDS ? BK : LDS_ROW) * sizeof(half_t),
+                "GroupNorm statistics scratch fits behind the staged tile");
   dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), a.splitk);
   auto k = igemm_kernel<BM, BN, WGM, WGN, TRANS, GLDS, NST, 0, LNF>;
   static DynLdsOnce once;   // per instantiation, per device
@@ -2069,7 +2171,32 @@ void conv_tune_set_candidate(int tile, int staging, int splitk) {
   g_tune.splitk = splitk;
 }
 
-void launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
+namespace {
+// GroupNorm statistics from the epilogue: fills a.gn_* and returns the entries per (sample, group) the launch will write,
+// or 0 when this launch cannot produce them (bm: rows per m-tile of an igemm tile, 0 for the 8x16-pixel halo tiles)
+int setup_gn_stats(const ConvDesc& d, IgemmArgs& a, int bm) {
+  a.gn_partial = nullptr;
+  if (!d.gn_partial || d.gn_groups < 1 || a.splitk > 1 || d.out_mode != kOutHalf || d.out_t || d.debug) return 0;
+  if (a.N % d.gn_groups != 0 || a.N % 8 != 0) return 0;
+  const int cpg = a.N / d.gn_groups;
+  if (cpg > 64) return 0;                       // a group may span two 64-column n-tiles, not three
+  int T;
+  if (bm == 0) {
+    T = a.tiles_x * a.tiles_y;
+  } else {
+    if (a.HoWo % bm != 0) return 0;             // every m-tile inside one sample
+    T = a.HoWo / bm;
+  }
+  if (2 * T > kGnMaxSlabs) return 0;
+  a.gn_partial = d.gn_partial;
+  a.gn_G = d.gn_groups;
+  a.gn_cpg = cpg;
+  a.gn_T = T;
+  return 2 * T;
+}
+}  // namespace
+
+int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
   SD_REQUIRE(conv_fast_path_ok(d), kInvalidArgument, "launch_conv: shape not MFMA-tileable (C0=%d C1=%d N=%d k=%d)",
              d.C0, d.C1, d.N, d.ksize);
   SD_REQUIRE(!d.ln_colsum || (d.ksize == 1 && !d.x1 && d.bias && d.out_mode != kOutHalfT), kInvalidArgument,
@@ -2101,15 +2228,22 @@ void launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
   if (log_plans)
     fprintf(stderr, "[sd conv] k%d s%d up%d C0=%d C1=%d M=%d N=%d K=%d mode=%d tile=%d splitk=%d\n", a.ksize, a.stride, a.up,
             a.C0, a.C1, a.M, a.N, a.K, d.out_mode, p.tile, a.splitk);
+  int gn_entries = 0;
   if (halo) {
+    if (p.tile == 7) gn_entries = setup_gn_stats(d, a, 0);
     if (p.tile == 5) launch_halo<128>(a, a.splitk, st, s);
     else if (p.tile == 7) launch_halo_ks(a, a.splitk, st, s);
     else launch_halo<64>(a, a.splitk, st, s);
   } else if (d.debug) {   // ablation builds exist for two tiles only (tools/prof_conv.py)
     const bool ok = p.tile == 1 ? launch_debug_mode<128, 128>(a, d.debug, s) : launch_debug_mode<64, 64>(a, d.debug, s);
     SD_REQUIRE(ok && !trans, kInvalidArgument, "no ablation kernel for debug mode %d", d.debug);
-    return;
+    return 0;
   } else {
+    if (!trans) {
+      int bm, bn;
+      tile_dims(p.tile >= 1 && p.tile <= 3 ? p.tile : 4, bm, bn);
+      gn_entries = setup_gn_stats(d, a, bm);
+    }
     switch (p.tile) {
       case 1: launch_tile<128, 128, 2, 2>(a, trans, st, s); break;
       case 2: launch_tile<128, 64, 2, 2>(a, trans, st, s); break;
@@ -2123,28 +2257,33 @@ void launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a);
   }
   SD_HIP(hipGetLastError());
+  return gn_entries;
 }
 
-void launch_conv_generic(const ConvDesc& d, int act_silu_out, hipStream_t s) {
+int launch_conv_generic(const ConvDesc& d, int act_silu_out, hipStream_t s) {
   IgemmArgs a = make_args(d);
   if (a.ksize == 3 && a.stride == 1 && a.up == 1 && a.Ctot == 4 && !d.x1 && d.pad < 0 && d.out_mode == kOutHalf && a.N % 8 == 0 &&
       !d.temb && !act_silu_out) {
-    const size_t lds = (size_t)(128 + 64) * BK * 2 + 2 * 64 * sizeof(float);
+    // (+ room for the GroupNorm statistics scratch of the shared tile epilogue behind the staged 128 x 64 tile)
+    const size_t lds = std::max((size_t)(128 + 64) * BK * 2 + 2 * 64 * sizeof(float),
+                                (size_t)128 * (64 + 8) * 2 + 16 + (kGnScratchFloats + 2 * 64) * sizeof(float));
     a.splitk = 1;
+    const int gn_entries = setup_gn_stats(d, a, 128);
     hipLaunchKernelGGL(conv3x3_cin4_kernel, dim3(cdiv(a.M, 128) * cdiv(a.N, 64)), dim3(256), lds, s, a);
     SD_HIP(hipGetLastError());
-    return;
+    return gn_entries;
   }
   if (a.K <= SC_KMAX && d.out_mode == kOutHalf && a.N >= 64) {
     hipLaunchKernelGGL(conv_small_cin_kernel, dim3(cdiv(a.M, SC_PIX)), dim3(256), 0, s, a, act_silu_out);
     SD_HIP(hipGetLastError());
-    return;
+    return 0;
   }
   SD_REQUIRE(d.out_mode != kOutGeglu || d.N % 64 == 0, kUnsupported, "generic GEGLU needs N %% 64 == 0 (N=%d)", d.N);
   size_t total = (size_t)a.M * a.N;
   int blocks = (int)std::min<size_t>((total + 255) / 256, 65535);
   hipLaunchKernelGGL(conv_generic_kernel, dim3(blocks), dim3(256), 0, s, a, act_silu_out);
   SD_HIP(hipGetLastError());
+  return 0;
 }
 
 void launch_conv_small_n(const ConvDesc& d, float* out_nchw_f32, hipStream_t s) {

@@ -47,7 +47,15 @@ struct ConvDesc {
   // (attention's V^T), columns [0, n_trans) to out with row length n_trans.  Needs Ho*Wo % 8 == 0.
   half_t* out_t = nullptr;
   int n_trans = 0;
+  // GroupNorm statistics of the output from the conv's own epilogue (the consumer is a GroupNorm over exactly this
+  // tensor, gn_groups groups): partial sums go to gn_partial [B][gn_groups][kGnMaxSlabs][2].  launch_conv returns how
+  // many entries per (sample, group) it wrote - 0 when the chosen plan cannot (split-K, ragged tiles): the GroupNorm
+  // then runs its own statistics pass.
+  float* gn_partial = nullptr;
+  int gn_groups = 0;
 };
+
+constexpr int kGnMaxSlabs = 256;   // entries per (sample, group) of a GroupNorm partial buffer
 
 struct ConvWorkspace {
   float* partial = nullptr;     // split-K slabs
@@ -56,14 +64,15 @@ struct ConvWorkspace {
 
 // Returns the workspace bytes this conv needs with its current heuristic (for planning).
 size_t conv_workspace_bytes(const ConvDesc& d);
-void launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s);
+// returns the number of GroupNorm partial entries per (sample, group) written to d.gn_partial (0: none)
+int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s);
 bool conv_fast_path_ok(const ConvDesc& d);
 // tuning hook: plan (tile 1-6, staging 0-5, splitk) forced on every conv that admits it; tile 0 = off
 void conv_tune_set_candidate(int tile, int staging, int splitk);
 int conv_plan_table_set(const char* text);   // rows of tuned_convs.inc format; returns the number of plans read
 
 // direct conv for tiny / odd shapes (any Cin, any N): fp32 accumulate, one thread per output
-void launch_conv_generic(const ConvDesc& d, int act_silu_out, hipStream_t s);
+int launch_conv_generic(const ConvDesc& d, int act_silu_out, hipStream_t s);   // returns like launch_conv
 
 // N <= 8 outputs, K % 8 == 0: one wavefront per output pixel.  out_nchw_f32: write float
 // [B][N][Ho][Wo] (the UNet's noise_pred boundary), else half NHWC.
@@ -88,6 +97,25 @@ struct AttnDesc {
 void launch_attention(const AttnDesc& d, hipStream_t s);
 bool attention_supported(int d);
 
+// Cross-attention front half in one launch (xattn.hip): out = softmax(to_q(LayerNorm(x)) k^T / sqrt(d)) v per head,
+// head dim 64, <= 96 keys (unet.py:87-118 with the prompt's K / V hoisted).  x [M][C] is the UN-normalised input; wq /
+// bias / colsum are the LayerNorm-folded projection (UNet::fold_layernorm); k [B][L][C], vt [B][C][ldv], out [M][C].
+struct XAttnDesc {
+  const half_t* x = nullptr;
+  const half_t* wq = nullptr;
+  const float* bias = nullptr;
+  const float* colsum = nullptr;
+  const half_t* k = nullptr;
+  const half_t* vt = nullptr;
+  half_t* out = nullptr;
+  int M = 0, C = 0, S = 0, L = 0, ldv = 0, heads = 0;   // S: query tokens per sample (M = B * S)
+  float ln_eps = 1e-5f;
+  int impl = kAttnOriginal;   // only checked: SPLIT_EINSUM_V2 rejects S % 512 != 0 like the streaming kernel
+  int nst = 0;                // LDS-DMA ring depth 2-4 (0 = heuristic)
+};
+bool xattn_fused_ok(int C, int heads, int S, int L);
+void launch_xattn_fused(const XAttnDesc& d, hipStream_t s);
+
 // ---------------------------------------------------------------------------------------------
 // K6/K7: norms (norm.hip)
 // ---------------------------------------------------------------------------------------------
@@ -98,8 +126,13 @@ void launch_layernorm(const half_t* x, const float* w, const float* b, half_t* y
 // statistics (partial: groupnorm_scratch_floats() floats per call) + apply.
 int groupnorm_num_slabs(int B, int HW);
 size_t groupnorm_scratch_floats(int B, int HW, int G);
+// producer_entries > 0: `partial` already holds that many (sum, sumsq) entries per (sample, group), written by the
+// epilogue of the kernel that produced x0 (ConvDesc::gn_partial) - the statistics pass is skipped.
 void launch_groupnorm(const half_t* x0, int C0, const half_t* x1, int C1, float* partial, const float* gamma,
-                      const float* beta, half_t* y, int B, int HW, int G, float eps, int silu, hipStream_t s);
+                      const float* beta, half_t* y, int B, int HW, int G, float eps, int silu, hipStream_t s,
+                      int producer_entries = 0);
+// true when a GroupNorm of this shape would run a separate statistics launch, i.e. producer statistics pay
+bool groupnorm_wants_producer_stats(int HW, int C, int G);
 
 // in-place softmax(scale * x) over each row of a [rows][cols] fp16 matrix (VAE single-head attention)
 void launch_row_softmax(half_t* x, int rows, int cols, float scale, hipStream_t s);

@@ -26,7 +26,7 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-constexpr int kGnMaxSlabs = 128;  // partial layout [B][G][kGnMaxSlabs][2]; unused slabs stay zero
+// partial layout [B][G][kGnMaxSlabs][2] (kernels.h); entries >= the producer's count are ignored by the fold
 constexpr int LN_MAX_CHUNKS = 4;   // C <= 64 lanes * 4 chunks * 8 = 2048
 
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, const float* __restrict__ w,
@@ -178,21 +178,30 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const half_t* __re
   const int b = blockIdx.y;
   const int t = threadIdx.x;
   {
-    // fold the slabs: LPG lanes per group, each sums a contiguous run of kGnMaxSlabs/LPG slab entries
-    // (unused entries are zero) loaded as independent float4s, then a fixed-order shuffle tree.
+    // fold the entries: LPG lanes per group, each sums a contiguous run of kGnMaxSlabs/LPG entries (those at or
+    // beyond `slabs` count as zero) loaded as independent float4s, then a fixed-order shuffle tree.
     const int LPG = (G <= 32) ? 8 : 4;
     const int g = t / LPG, j = t % LPG;
-    const int per = kGnMaxSlabs / LPG;                 // 16 or 32 slab entries = 8 or 16 float4
+    const int per = kGnMaxSlabs / LPG;                 // 32 or 64 entries = 16 or 32 float4
     float s = 0.f, q = 0.f;
     if (g < G) {
       const floatx4* src = reinterpret_cast<const floatx4*>(partial + (((size_t)b * G + g) * kGnMaxSlabs + j * per) * 2);
-      floatx4 v[16];
+      for (int k0 = 0; k0 < per / 2; k0 += 16) {       // (block-uniform trip count)
+        floatx4 v[16];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) v[k] = (k < per / 2) ? src[k] : floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < 16; ++k) {
+          const int e0 = j * per + 2 * (k0 + k);       // first of the two entries of this float4
+          v[k] = (e0 < slabs) ? src[k0 + k] : floatx4{0.f, 0.f, 0.f, 0.f};
+          if (e0 + 1 >= slabs) {
+            v[k][2] = 0.f;
+            v[k][3] = 0.f;
+          }
+        }
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        s += v[k][0] + v[k][2];
-        q += v[k][1] + v[k][3];
+        for (int k = 0; k < 16; ++k) {
+          s += v[k][0] + v[k][2];
+          q += v[k][1] + v[k][3];
+        }
       }
     }
     for (int o = 1; o < LPG; o <<= 1) {
@@ -399,17 +408,43 @@ int groupnorm_num_slabs(int B, int HW) {
   return std::max(1, std::min(std::min(want, 128), std::max(1, HW / 16)));
 }
 
+namespace {
+long gn_fused_max_hw() {
+  // measured crossover (tools/gn_sweep.py): the single launch wins for HW <= 256 (3.5-11 us vs 10-23 us), the
+  // slab pair wins at 32x32 and above (8-16 us vs 13-208 us).  SD_GN_FUSED_MAX_HW overrides for tuning.
+  static const long v = getenv("SD_GN_FUSED_MAX_HW") ? atol(getenv("SD_GN_FUSED_MAX_HW")) : 256;
+  return v;
+}
+}  // namespace
+
+bool groupnorm_wants_producer_stats(int HW, int C, int G) {
+  static const bool off = getenv("SD_NO_GN_PRODUCER_STATS") != nullptr;   // A/B switch
+  if (off || G < 1 || C % G != 0) return false;
+  const int cpg = C / G;
+  const bool single_launch = HW <= gn_fused_max_hw() && cpg <= 128 && cpg % 2 == 0;
+  return !single_launch && cpg <= 64 && G <= 64;
+}
+
 size_t groupnorm_scratch_floats(int B, int HW, int G) { return (size_t)B * G * kGnMaxSlabs * 2; }
 
 void launch_groupnorm(const half_t* x0, int C0, const half_t* x1, int C1, float* partial, const float* gamma,
-                      const float* beta, half_t* y, int B, int HW, int G, float eps, int silu, hipStream_t s) {
+                      const float* beta, half_t* y, int B, int HW, int G, float eps, int silu, hipStream_t s,
+                      int producer_entries) {
   if (!x1) C1 = 0;
   const int C = C0 + C1;
   SD_REQUIRE(C % G == 0 && C0 % 8 == 0 && C1 % 8 == 0 && G <= 64, kUnsupported, "groupnorm: C0=%d C1=%d G=%d", C0, C1, G);
   const int cpg = C / G;
-  // measured crossover (tools/gn_sweep.py): the single launch wins for HW <= 256 (3.5-11 us vs 10-23 us), the
-  // slab pair wins at 32x32 and above (8-16 us vs 13-208 us).  SD_GN_FUSED_MAX_HW overrides for tuning.
-  static const long fused_max_hw = getenv("SD_GN_FUSED_MAX_HW") ? atol(getenv("SD_GN_FUSED_MAX_HW")) : 256;
+  if (producer_entries > 0) {   // statistics came out of the producing kernel's epilogue: one apply launch
+    SD_REQUIRE(producer_entries <= kGnMaxSlabs && !x1, kInternal, "groupnorm: %d producer entries", producer_entries);
+    int slabs = groupnorm_num_slabs(B, HW);
+    const int ppb = cdiv(HW, slabs);
+    slabs = cdiv(HW, ppb);
+    hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(slabs, B), dim3(256), 0, s, x0, C0, x1, C1, partial, producer_entries, gamma,
+                       beta, y, HW, G, eps, silu, ppb);
+    SD_HIP(hipGetLastError());
+    return;
+  }
+  const long fused_max_hw = gn_fused_max_hw();
   if (HW <= fused_max_hw && cpg <= 128 && cpg % 2 == 0) {
     dim3 grid(G, B);
     if (cpg % 8 == 0)

@@ -257,12 +257,32 @@ Tensor UNet::conv_w(std::vector<Op>& ops, const std::string& name, const half_t*
   d.out = out.p;
   SD_REQUIRE(!ex || (conv_fast_path_ok(d) && !silu_out), kInternal, "%s: LayerNorm fold / fused q|k|v off the MFMA path",
              name.c_str());
+  // a GroupNorm built later over exactly this tensor may ask for its statistics from this op's epilogue (GnHook)
+  std::shared_ptr<GnHook> hook;
+  if (out_mode == kOutHalf && !(ex && ex->n_trans > 0)) {
+    hook = std::make_shared<GnHook>();
+    out.gn = hook;
+  }
+  auto with_hook = [hook](const ConvDesc& d0) {
+    ConvDesc dd = d0;
+    if (hook) {
+      dd.gn_partial = hook->partial;
+      dd.gn_groups = hook->groups;
+    }
+    return dd;
+  };
   if (conv_fast_path_ok(d) && !silu_out) {
     ws_need_ = std::max(ws_need_, conv_workspace_bytes(d));
-    ops.push_back([this, d](hipStream_t s) { launch_conv(d, ws_conv_, s); });
+    ops.push_back([this, d, hook, with_hook](hipStream_t s) {
+      const int n = launch_conv(with_hook(d), ws_conv_, s);
+      if (hook) hook->entries = n;
+    });
   } else {
     const int so = silu_out ? 1 : 0;
-    ops.push_back([d, so](hipStream_t s) { launch_conv_generic(d, so, s); });
+    ops.push_back([d, so, hook, with_hook](hipStream_t s) {
+      const int n = launch_conv_generic(with_hook(d), so, s);
+      if (hook) hook->entries = n;
+    });
   }
   {
     const int cin = x.C + (x2 ? x2->C : 0);
@@ -291,8 +311,15 @@ Tensor UNet::group_norm(std::vector<Op>& ops, const std::string& name, const Ten
   const half_t* p1 = x2 ? x2->p : nullptr;
   const int C0 = x.C, C1 = x2 ? x2->C : 0, B = x.B, HW = x.H * x.W, si = silu ? 1 : 0;
   half_t* yp = y.p;
+  // single-source GroupNorm that would need its own statistics launch: ask the op that produced x for them
+  std::shared_ptr<GnHook> hook;
+  if (!x2 && x.gn && !x.gn->partial && groupnorm_wants_producer_stats(HW, C, G)) {
+    hook = x.gn;
+    hook->partial = partial;
+    hook->groups = G;
+  }
   ops.push_back([=](hipStream_t s) {
-    launch_groupnorm(p0, C0, p1, C1, partial, gamma, beta, yp, B, HW, G, eps, si, s);
+    launch_groupnorm(p0, C0, p1, C1, partial, gamma, beta, yp, B, HW, G, eps, si, s, hook ? hook->entries : 0);
   });
   ops.back().label = "groupnorm C=" + std::to_string(C) + " @" + std::to_string(x.H) + "x" + std::to_string(x.W) + " " + name;
   return y;
@@ -394,20 +421,49 @@ Tensor UNet::transformer_block(std::vector<Op>& ops, const std::string& b, const
   Tensor a1 = attention(ops, q, qk.p + C, vtp, heads, S, S, 2 * C, ldv, 2 * C);
   Tensor h1 = conv(ops, b + ".attn1.to_out.0", a1, nullptr, C, 1, 1, 1, true, nullptr, h.p);
   // --- cross attention: K / V^T of the prompt are computed by ctx_ops_ when the prompt changes
-  Tensor q2;
-  if (can_fold_ln(h1, C, false)) {
-    LnFold f = fold_layernorm(b + ".norm2", {b + ".attn2.to_q"}, C, C, false);
-    ConvExtra ex;
-    ex.ln_colsum = f.colsum;
-    q2 = conv_w(ops, b + ".attn2.to_q", f.w, f.bias, h1, nullptr, C, 1, 1, 1, nullptr, nullptr, kOutHalf, 0, false, &ex);
-  } else {
-    Tensor n2 = layer_norm(ops, b + ".norm2", h1);
-    q2 = conv(ops, b + ".attn2.to_q", n2, nullptr, C, 1, 1, 1, false, nullptr, nullptr);
-  }
   const int ldvc = round_up(L, 8);
   Tensor k2 = conv(ctx_ops_, b + ".attn2.to_k", ctx_, nullptr, C, 1, 1, 1, false, nullptr, nullptr);
   Tensor vt2 = conv(ctx_ops_, b + ".attn2.to_v", ctx_, nullptr, C, 1, 1, 1, false, nullptr, nullptr, kOutHalfT, ldvc);
-  Tensor a2 = attention(ops, q2, k2.p, vt2.p, heads, S, L, C, ldvc, C);
+  Tensor a2;
+  if (can_fold_ln(h1, C, false) && xattn_fused_ok(C, heads, S, L)) {
+    // norm2 -> to_q -> softmax(q k^T) v as ONE launch (xattn.hip): the q tile stays in registers
+    LnFold f = fold_layernorm(b + ".norm2", {b + ".attn2.to_q"}, C, C, false);
+    a2 = new_tensor(h1.B, h1.H, h1.W, C);
+    XAttnDesc xd;
+    xd.x = h1.p;
+    xd.wq = f.w;
+    xd.bias = f.bias;
+    xd.colsum = f.colsum;
+    xd.k = k2.p;
+    xd.vt = vt2.p;
+    xd.out = a2.p;
+    xd.M = h1.M();
+    xd.C = C;
+    xd.S = S;
+    xd.L = L;
+    xd.ldv = ldvc;
+    xd.heads = heads;
+    ops.push_back([this, xd](hipStream_t s) {
+      XAttnDesc dd = xd;
+      dd.impl = cfg_.attention_impl;
+      launch_xattn_fused(dd, s);
+    });
+    ops.back().label = "xattn+ln q-proj " + std::to_string(C) + "->" + std::to_string(C) + " + attention h=" + std::to_string(heads) +
+                       " d=64 Sq=" + std::to_string(S) + " Sk=" + std::to_string(L) + " " + b + ".attn2";
+    ops.back().flop = 2.0 * h1.M() * (double)C * C + 4.0 * h1.B * (double)C * S * L;
+  } else {
+    Tensor q2;
+    if (can_fold_ln(h1, C, false)) {
+      LnFold f = fold_layernorm(b + ".norm2", {b + ".attn2.to_q"}, C, C, false);
+      ConvExtra ex;
+      ex.ln_colsum = f.colsum;
+      q2 = conv_w(ops, b + ".attn2.to_q", f.w, f.bias, h1, nullptr, C, 1, 1, 1, nullptr, nullptr, kOutHalf, 0, false, &ex);
+    } else {
+      Tensor n2 = layer_norm(ops, b + ".norm2", h1);
+      q2 = conv(ops, b + ".attn2.to_q", n2, nullptr, C, 1, 1, 1, false, nullptr, nullptr);
+    }
+    a2 = attention(ops, q2, k2.p, vt2.p, heads, S, L, C, ldvc, C);
+  }
   Tensor h2 = conv(ops, b + ".attn2.to_out.0", a2, nullptr, C, 1, 1, 1, true, nullptr, h1.p);
   // --- GEGLU feed-forward (norm3 folded the same way)
   Tensor g;

@@ -9,9 +9,19 @@
 
 namespace sd {
 
+// Link between a conv / GEMM op and the GroupNorm that consumes its output: the GroupNorm (built later) asks the
+// producer to leave per-tile (sum, sumsq) partials of the tensor in `partial`; at launch time the producer reports how
+// many entries per (sample, group) its plan wrote (0: none - split-K, ragged tiles - the GroupNorm runs its own pass).
+struct GnHook {
+  float* partial = nullptr;
+  int groups = 0;
+  int entries = 0;
+};
+
 struct Tensor {
   half_t* p = nullptr;
   int B = 0, H = 0, W = 0, C = 0;
+  std::shared_ptr<GnHook> gn;   // set on conv / GEMM outputs
   int M() const { return B * H * W; }
   size_t numel() const { return (size_t)B * H * W * C; }
 };

@@ -91,6 +91,8 @@ SYMBOLS = [
     ("sd_op_layernorm", _I, [_P, _FP, _FP, _P, _I, _I, _I, _F, _I, _FP]),
     ("sd_op_groupnorm", _I, [_P, _FP, _FP, _P, _I, _I, _I, _I, _I, _F, _I, _I, _FP]),
     ("sd_op_conv2d", _I, [_P, _P, _FP, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _FP]),
+    ("sd_op_conv2d_groupnorm", _I, [_P, _P, _FP, _P, _FP, _FP, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, C.POINTER(_I), _I, _FP]),
+    ("sd_op_cross_attention_fused", _I, [_P, _FP, _FP, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _FP]),
     ("sd_op_geglu", _I, [_P, _P, _FP, _P, _I, _I, _I, _I, _FP]),
     ("sd_op_timestep_embedding", _I, [_FP, _FP, _I, _I, _I, _F]),
     ("sd_numpy_randn", _I, [C.c_uint32, C.POINTER(C.c_double), C.c_size_t]),
@@ -203,6 +205,42 @@ def conv2d(x, w, bias=None, res=None, stride=1, upsample=False, tile=0, splitk=0
     ms = C.c_float(0)
     check(lib().sd_op_conv2d(ptr(x), ptr(w), fptr(bias), ptr(res), ptr(out), B, Cin, H, W, Cout, k, stride,
                              int(upsample), tile, splitk, int(force_generic), iters, C.byref(ms)))
+    return out, ms.value
+
+
+def conv2d_groupnorm(x, w, gn_weight, gn_bias, bias=None, res=None, groups=32, eps=1e-5, silu=False, tile=0,
+                     producer_stats=True, iters=1):
+    """conv (stride 1) -> GroupNorm (+ SiLU); producer_stats: GroupNorm statistics from the conv kernel's epilogue.
+    Returns (conv output, normalised output, entries the conv wrote per (sample, group), ms)."""
+    x, w = f16(x), f16(w)
+    B, Cin, H, W = x.shape
+    Cout, Cin2, k, k2 = w.shape
+    if Cin2 != Cin or k != k2:
+        raise ValueError("conv2d_groupnorm: weight shape does not match input")
+    bias = None if bias is None else f32(bias)
+    res = None if res is None else f16(res)
+    gn_weight, gn_bias = f32(gn_weight), f32(gn_bias)
+    conv_out = np.empty((B, Cout, H, W), np.float16)
+    out = np.empty((B, Cout, H, W), np.float16)
+    ms, entries = C.c_float(0), C.c_int(0)
+    check(lib().sd_op_conv2d_groupnorm(ptr(x), ptr(w), fptr(bias), ptr(res), fptr(gn_weight), fptr(gn_bias), ptr(conv_out),
+                                       ptr(out), B, Cin, H, W, Cout, k, groups, eps, int(silu), tile, int(producer_stats),
+                                       C.byref(entries), iters, C.byref(ms)))
+    return conv_out, out, entries.value, ms.value
+
+
+def cross_attention_fused(x, ln_weight, ln_bias, wq, k, v, heads, eps=1e-5, nst=0, iters=1):
+    """softmax(to_q(LayerNormANE(x)) k^T / 8) v per head (head dim 64) as one launch.  x (B,C,1,Sq), k/v (B,C,1,Sk)."""
+    x, k, v, wq = f16(x), f16(k), f16(v), f16(wq)
+    B, Cn, _, Sq = x.shape
+    Sk = k.shape[3]
+    if Cn != heads * 64 or k.shape[1] != Cn or v.shape != k.shape or wq.shape != (Cn, Cn):
+        raise ValueError("cross_attention_fused: inconsistent shapes")
+    ln_weight, ln_bias = f32(ln_weight), f32(ln_bias)
+    out = np.empty_like(x)
+    ms = C.c_float(0)
+    check(lib().sd_op_cross_attention_fused(ptr(x), fptr(ln_weight), fptr(ln_bias), ptr(wq), ptr(k), ptr(v), ptr(out), B, heads,
+                                            Sq, Sk, eps, nst, iters, C.byref(ms)))
     return out, ms.value
 
 

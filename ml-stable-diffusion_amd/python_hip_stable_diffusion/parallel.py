@@ -61,6 +61,21 @@ def cfg_batch(ehs_pairs):
     return np.concatenate([ehs_pairs[:, 0], ehs_pairs[:, 1]])
 
 
+def _check_sharded_inputs(ehs_pairs, latents, world):
+    """None, or why rank 0's inputs cannot be sharded (evaluated on rank 0 only, before any collective)."""
+    try:
+        e, l = np.asarray(ehs_pairs), np.asarray(latents)
+    except Exception as exc:      # ragged lists etc.
+        return f"run_sharded: inputs are not arrays ({exc})"
+    if e.ndim != 5 or e.shape[1] != 2 or e.shape[3] != 1:
+        return f"run_sharded: ehs_pairs must be (P, 2, C, 1, L), got {e.shape}"
+    if l.ndim != 4 or l.shape[0] != e.shape[0]:
+        return f"run_sharded: latents must be (P, 4, h, w) with P = {e.shape[0]}, got {l.shape}"
+    if e.shape[0] % world:
+        return f"{e.shape[0]} prompts do not split evenly over {world} ranks (static UNet batch per rank)"
+    return None
+
+
 def run_sharded(loop_fn, ehs_pairs, latents, dist=None, local_rank=0):
     """BASELINE config 3 in one call: rank 0 holds the text embeddings (P, 2, C, 1, L) and the initial latents
     (P, 4, h, w) of ALL prompts; they are broadcast, each rank runs ``loop_fn(latents_of_its_prompts,
@@ -71,20 +86,29 @@ def run_sharded(loop_fn, ehs_pairs, latents, dist=None, local_rank=0):
     rank = 0 if dist is None else dist.get_rank()
     if dist is not None:
         import torch
+        # rank 0 validates its inputs BEFORE the first collective and ships the verdict in the header: a user error
+        # raises on every rank after the broadcast instead of leaving the other ranks waiting in it for ever
         meta = torch.zeros(8, dtype=torch.int64)
         if rank == 0:
-            e, l = np.asarray(ehs_pairs), np.asarray(latents)
-            meta = torch.tensor(list(e.shape[:1] + e.shape[2:]) + list(l.shape[1:]) + [0], dtype=torch.int64)[:8]
+            err = _check_sharded_inputs(ehs_pairs, latents, world)
+            if err is None:
+                e, l = np.asarray(ehs_pairs), np.asarray(latents)
+                meta = torch.tensor(list(e.shape[:1] + e.shape[2:]) + list(l.shape[1:]) + [0], dtype=torch.int64)[:8]
+            else:
+                meta[7] = -1
         meta = meta.to(_device(dist, local_rank))
         dist.broadcast(meta, src=0)
+        if int(meta[7]) < 0:
+            raise ValueError(err if rank == 0 else "run_sharded: rank 0 rejected its inputs (see its exception)")
         p, c, one, length, lc, lh, lw = [int(v) for v in meta.tolist()[:7]]
         ehs_pairs = broadcast_array(ehs_pairs if rank == 0 else None, (p, 2, c, one, length), np.float16, dist, local_rank)
         latents = broadcast_array(latents if rank == 0 else None, (p, lc, lh, lw), np.float32, dist, local_rank)
     else:
+        err = _check_sharded_inputs(ehs_pairs, latents, world)
+        if err is not None:
+            raise ValueError(err)
         ehs_pairs, latents = np.asarray(ehs_pairs, np.float16), np.asarray(latents, np.float32)
     n = ehs_pairs.shape[0]
-    if n % world:
-        raise ValueError(f"{n} prompts do not split evenly over {world} ranks (static UNet batch per rank)")
     mine = shard_prompts(n, world)[rank]
     out = loop_fn(latents[mine], cfg_batch(ehs_pairs[mine]))
     return gather_arrays(np.asarray(out, np.float32), dist, local_rank)
@@ -98,20 +122,32 @@ def run_cfg_split(unet_fn, scheduler, ehs_pair, latents, guidance_scale, dist, l
     without a second exchange.  ``unet_fn(latents (1,4,h,w) f32, timestep, encoder_hidden_states (1,C,1,L) f16) -> noise
     (1,4,h,w) f32`` is the per-rank model call (the host-stepped `HipModel.__call__` path: a per-step collective cannot sit
     inside the device-resident loop); ``ehs_pair`` is (2, C, 1, L) = [uncond, cond] on rank 0 (broadcast to rank 1).
-    Returns the final latents (the same array on both ranks)."""
+    Returns the final latents (the same array on both ranks).
+
+    EXPERIMENTAL and unmeasured on hardware: every step crosses the host (D2H -> numpy -> collective -> H2D) and uses the
+    host-stepped UNet call, so on one node it adds more latency than the halved batch saves; kept as the reference point for a
+    device-pointer exchange, not as a recommended mode."""
     if dist is None or dist.get_world_size() != 2:
         raise ValueError("run_cfg_split needs exactly two ranks (rank 0 = uncond, rank 1 = cond)")
     rank = dist.get_rank()
     import torch
-    meta = torch.zeros(6, dtype=torch.int64)
+    meta = torch.zeros(7, dtype=torch.int64)      # [C, 1, L, 4, h, w, status]: status < 0 = rank 0 rejected its inputs
+    msg = "run_cfg_split takes one prompt: ehs_pair (2, C, 1, L), latents (1, 4, h, w)"
     if rank == 0:
-        e, l = np.asarray(ehs_pair), np.asarray(latents)
-        if e.shape[0] != 2 or l.shape[0] != 1:
-            raise ValueError("run_cfg_split takes one prompt: ehs_pair (2, C, 1, L), latents (1, 4, h, w)")
-        meta = torch.tensor(list(e.shape[1:]) + list(l.shape[1:]), dtype=torch.int64)
+        try:
+            e, l = np.asarray(ehs_pair), np.asarray(latents)
+            ok = e.ndim == 4 and l.ndim == 4 and e.shape[0] == 2 and l.shape[0] == 1
+        except Exception:
+            ok = False
+        if ok:
+            meta = torch.tensor(list(e.shape[1:]) + list(l.shape[1:]) + [0], dtype=torch.int64)
+        else:
+            meta[6] = -1
     meta = meta.to(_device(dist, local_rank))
     dist.broadcast(meta, src=0)
-    c, one, length, lc, lh, lw = [int(v) for v in meta.tolist()]
+    if int(meta[6]) < 0:      # raised on BOTH ranks, after the collective (a raise before it would strand rank 1 inside)
+        raise ValueError(msg if rank == 0 else "run_cfg_split: rank 0 rejected its inputs: " + msg)
+    c, one, length, lc, lh, lw = [int(v) for v in meta.tolist()[:6]]
     ehs_pair = broadcast_array(ehs_pair if rank == 0 else None, (2, c, one, length), np.float16, dist, local_rank)
     x = broadcast_array(latents if rank == 0 else None, (1, lc, lh, lw), np.float32, dist, local_rank)
     mine = ehs_pair[rank:rank + 1]

@@ -291,6 +291,10 @@ class HipStableDiffusionPipeline:
         fused = not reasons
         step_ms = None
         if fused:
+            if not controlnet_cond and getattr(self.unet, "_attached", None):
+                # a previous call attached ControlNets: without conditioning images this call must not run them with the
+                # stale ones (the reference would fail on the missing additional_residual_* inputs, pipeline.py:519-529)
+                self.unet.attach_controlnets([])
             if controlnet_cond:
                 if len(controlnet_cond) != len(self.controlnet):
                     raise ValueError(f"need {len(self.controlnet)} controlnet conditions, got {len(controlnet_cond)}")
@@ -386,6 +390,18 @@ def _find_weights(folder):
     raise FileNotFoundError(f"no .safetensors checkpoint under {folder} (coreml_model.py:176-178)")
 
 
+def checkpoint_scheduler_config(model_dir):
+    """``pytorch_pipe.scheduler.config`` (pipeline.py:738-741) read from ``scheduler/scheduler_config.json`` of a
+    diffusers checkpoint directory; a checkpoint without one gets Stable Diffusion's PNDM config."""
+    from .schedulers import load_scheduler_config
+    path = os.path.join(model_dir, "scheduler", "scheduler_config.json")
+    if os.path.exists(path):
+        return load_scheduler_config(path)
+    logger.warning("%s not found: assuming Stable Diffusion's PNDM scheduler config", path)
+    return load_scheduler_config(dict(_class_name="PNDMScheduler", beta_start=0.00085, beta_end=0.012,
+                                      beta_schedule="scaled_linear", skip_prk_steps=True, steps_offset=1))
+
+
 def get_hip_pipe(model_dir, model_version, compute_unit="ALL", scheduler_override=None, controlnet_models=None,
                  force_zeros_for_empty_prompt=True, sources=None, attention_implementation="SPLIT_EINSUM",
                  num_images=1, guidance_scale=7.5, unet_batch_one=False, latent_size=None, device=0,
@@ -402,16 +418,20 @@ def get_hip_pipe(model_dir, model_version, compute_unit="ALL", scheduler_overrid
     xl = "xl" in model_version
     do_cfg = guidance_scale > 1.0
     batch = 1 if (unet_batch_one and do_cfg) else (2 if do_cfg else 1) * num_images
-    if scheduler_override is not None:
+    if scheduler_override is not None and not isinstance(scheduler_override, str):
         logger.warning("Overriding scheduler in pipeline: Override=%s", type(scheduler_override).__name__)
         scheduler = scheduler_override
     else:
-        sc_cfg = os.path.join(model_dir, "scheduler", "scheduler_config.json")
-        cls = _read_json(sc_cfg).get("_class_name", "PNDMScheduler") if os.path.exists(sc_cfg) else "PNDMScheduler"
-        name = cls.replace("Scheduler", "")
+        # pipeline.py:738-741: SCHEDULER_MAP[name].from_config(pytorch_pipe.scheduler.config) - betas, steps_offset,
+        # timestep_spacing and prediction_type are the CHECKPOINT's (a v-prediction model with an epsilon scheduler
+        # generates garbage); unsupported config values raise instead of being ignored
+        sc_cfg = checkpoint_scheduler_config(model_dir)
+        name = scheduler_override or sc_cfg["_class_name"].replace("Scheduler", "")
         if name not in SCHEDULER_MAP:
-            raise NotImplementedError(f"checkpoint default scheduler {cls} is not one of {sorted(SCHEDULER_MAP)}")
-        scheduler = SCHEDULER_MAP[name]()
+            raise NotImplementedError(f"scheduler {name} is not one of {sorted(SCHEDULER_MAP)}")
+        if scheduler_override is not None:
+            logger.warning("Overriding scheduler in pipeline: Override=%s", name)
+        scheduler = SCHEDULER_MAP[name].from_config(sc_cfg)
 
     def load_unet(folder, kind="unet", support_controlnet=False):
         cfg = dict(_read_json(os.path.join(folder, "config.json")))
@@ -504,6 +524,10 @@ def build_parser():
     parser.add_argument("--attention-implementation", choices=tuple(_lib.ATTENTION_IMPLEMENTATIONS), default="SPLIT_EINSUM",
                         help="Attention schedule of the UNet kernels (a conversion-time flag in the reference).")
     parser.add_argument("--refiner", default=None, help="SDXL: diffusers directory of the refiner checkpoint")
+    parser.add_argument("--rng", choices=("numpy", "torch", "nvidia"), default="numpy",
+                        help="Seed-exact random source of the initial latents (swift/StableDiffusionCLI/main.swift --rng): "
+                             "numpy = np.random.seed + randn (this pipeline's and the reference's default), torch = torch's CPU "
+                             "generator, nvidia = torch's CUDA generator (Philox)")
     return parser
 
 
@@ -511,7 +535,7 @@ def main(args):
     """pipeline.py:724-782."""
     logger.info("Setting random seed to %d", args.seed)
     np.random.seed(args.seed)
-    scheduler = SCHEDULER_MAP[args.scheduler]() if args.scheduler is not None else None
+    scheduler = args.scheduler          # a name: get_hip_pipe builds it from the checkpoint's config (pipeline.py:738-741)
     xl = "xl" in args.model_version
     force_zeros = False                                                            # pipeline.py:744-746
     idx = os.path.join(args.i, "model_index.json")
@@ -528,7 +552,7 @@ def main(args):
     logger.info("Beginning image generation.")
     image = pipe(prompt=args.prompt, height=pipe.height, width=pipe.width, num_inference_steps=args.num_inference_steps,
                  guidance_scale=args.guidance_scale, controlnet_cond=controlnet_cond, negative_prompt=args.negative_prompt,
-                 unet_batch_one=args.unet_batch_one, seed=args.seed, output_type="pil")
+                 unet_batch_one=args.unet_batch_one, seed=args.seed, output_type="pil", rng=getattr(args, "rng", "numpy"))
     out_path = get_image_path(args)
     logger.info("Saving generated image to %s", out_path)
     image["images"][0].save(out_path)

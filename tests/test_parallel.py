@@ -175,6 +175,59 @@ def test_cfg_split_latency_mode_world_size_two():
         parallel.run_cfg_split(lambda *a: None, sch, ehs, x, 7.5, None)
 
 
+def _bad_input_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out = []
+        # 3 prompts on 2 ranks; a mis-shaped embedding array; run_cfg_split with two prompts: all rejected by rank 0 BEFORE
+        # its first collective - every rank must get the exception, none may be left inside the broadcast
+        bad = [(np.zeros((3, 2, 16, 1, 77), np.float16), np.zeros((3, 4, 8, 8), np.float32)),
+               (np.zeros((2, 16, 1, 77), np.float16), np.zeros((2, 4, 8, 8), np.float32))]
+        for e, l in bad:
+            try:
+                parallel.run_sharded(lambda lat, ehs: lat, e if rank == 0 else None, l if rank == 0 else None, dist)
+                out.append("no error")
+            except ValueError as exc:
+                out.append(str(exc))
+        sch = schedulers.DDIMScheduler()
+        sch.set_timesteps(2)
+        try:
+            parallel.run_cfg_split(lambda *a: None, sch, np.zeros((4, 16, 1, 77), np.float16) if rank == 0 else None,
+                                   np.zeros((2, 4, 8, 8), np.float32) if rank == 0 else None, 7.5, dist)
+            out.append("no error")
+        except ValueError as exc:
+            out.append(str(exc))
+        # the group is still usable afterwards (nobody is stuck in a half-finished collective)
+        ok = parallel.run_sharded(lambda lat, ehs: lat + 1, np.zeros((2, 2, 16, 1, 77), np.float16) if rank == 0 else None,
+                                  np.zeros((2, 4, 8, 8), np.float32) if rank == 0 else None, dist)
+        q.put((rank, out, float(ok.sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_invalid_rank0_inputs_raise_on_every_rank_instead_of_deadlocking():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bad_input_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, msgs, total in results:
+        assert len(msgs) == 3 and "no error" not in msgs, (rank, msgs)
+        assert total == 2 * 4 * 8 * 8
+    r0 = dict((r, m) for r, m, _ in results)[0]
+    assert "do not split evenly" in r0[0] and "must be (P, 2, C, 1, L)" in r0[1] and "one prompt" in r0[2]
+
+
 def test_single_process_degenerate_case():
     a = np.ones((2, 3), np.float32)
     assert np.array_equal(parallel.broadcast_array(a, (2, 3), np.float32, None), a)

@@ -242,7 +242,7 @@ def _oracle_unet(sd, cfg):
     return fn
 
 
-@pytest.mark.parametrize("name,oracle", [("PNDM", scheduler_ref.PNDM), ("DPMSolverMultistep", scheduler_ref.DPMSolverMultistep),
+@pytest.mark.parametrize("name,oracle", [("PNDM", scheduler_ref.PNDM), ("DPMSolverMultistep", scheduler_ref.DPMSolverMultistepDiffusers),
                                          ("EulerDiscrete", scheduler_ref.EulerDiscrete), ("LMSDiscrete", scheduler_ref.LMSDiscrete)])
 def test_every_deterministic_scheduler_runs_the_fused_device_loop(name, oracle):
     """PNDM is SD2.1-base's default scheduler (N + 1 evaluations with the PLMS warm-up, Scheduler.swift:137-344);
