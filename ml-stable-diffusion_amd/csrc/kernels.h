@@ -111,7 +111,7 @@ struct XAttnDesc {
   int M = 0, C = 0, S = 0, L = 0, ldv = 0, heads = 0;   // S: query tokens per sample (M = B * S)
   float ln_eps = 1e-5f;
   int impl = kAttnOriginal;   // only checked: SPLIT_EINSUM_V2 rejects S % 512 != 0 like the streaming kernel
-  int nst = 0;                // LDS-DMA ring depth 2-4 (0 = heuristic)
+  int nst = 0;                // LDS-DMA ring depth 2-5 (0 = heuristic)
 };
 bool xattn_fused_ok(int C, int heads, int S, int L);
 void launch_xattn_fused(const XAttnDesc& d, hipStream_t s);

@@ -162,9 +162,12 @@ __global__ __launch_bounds__(256) void groupnorm_partial_kernel(const half_t* __
 }
 
 // Pass 2, grid (pixel slabs, B): every block first folds the per-slab partials of its sample in a
-// fixed order (4 lanes per group + two shuffles: deterministic), turns them into per-channel
+// fixed order (4 or 8 lanes per group + shuffles: deterministic), turns them into per-channel
 // scale/shift held in registers, then streams its pixel slab: one 16-B load, 8 FMAs (+SiLU), one
 // 16-B store per thread-iteration.  Fusing the fold here saves a dependent launch per GroupNorm.
+// Everything that does not depend on the statistics - gamma / beta of the thread's channels and its first
+// four pixels - is requested BEFORE the fold, so the kernel pays one memory round trip, not three in a row
+// (partials -> affine -> data; a UNet step has 31 of these launches and each is latency-, not bandwidth-bound).
 __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const half_t* __restrict__ x0, int C0,
                                                               const half_t* __restrict__ x1, int C1,
                                                               const float* __restrict__ partial, int slabs,
@@ -177,6 +180,31 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const half_t* __re
   const int cpg = C / G;
   const int b = blockIdx.y;
   const int t = threadIdx.x;
+  const int p0 = blockIdx.x * pix_per_block;
+  const int p1 = min(p0 + pix_per_block, HW);
+  // ---- first column block: coordinates + the loads that do not wait for the statistics ----
+  const int cols0 = min(256, ncol);
+  const int rows0 = 256 / cols0;
+  const int c_first = (t % cols0) * 8;
+  const int r_first = t / cols0;
+  const bool act0 = r_first < rows0;
+  floatx4 g_lo = {0.f, 0.f, 0.f, 0.f}, g_hi = g_lo, b_lo = g_lo, b_hi = g_lo;
+  half8 pre[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) pre[u] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+  if (act0) {
+    g_lo = *reinterpret_cast<const floatx4*>(gamma + c_first);
+    g_hi = *reinterpret_cast<const floatx4*>(gamma + c_first + 4);
+    b_lo = *reinterpret_cast<const floatx4*>(beta + c_first);
+    b_hi = *reinterpret_cast<const floatx4*>(beta + c_first + 4);
+    const half_t* src = (c_first < C0) ? x0 + c_first : x1 + (c_first - C0);
+    const int Cs = (c_first < C0) ? C0 : C1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int pp = p0 + r_first + u * rows0;
+      if (pp < p1) pre[u] = *reinterpret_cast<const half8*>(src + ((size_t)b * HW + pp) * Cs);
+    }
+  }
   {
     // fold the entries: LPG lanes per group, each sums a contiguous run of kGnMaxSlabs/LPG entries (those at or
     // beyond `slabs` count as zero) loaded as independent float4s, then a fixed-order shuffle tree.
@@ -187,6 +215,7 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const half_t* __re
     if (g < G) {
       const floatx4* src = reinterpret_cast<const floatx4*>(partial + (((size_t)b * G + g) * kGnMaxSlabs + j * per) * 2);
       for (int k0 = 0; k0 < per / 2; k0 += 16) {       // (block-uniform trip count)
+        if (j * per + 2 * k0 >= slabs) break;          // nothing but masked entries from here on
         floatx4 v[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
@@ -217,8 +246,16 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const half_t* __re
     }
   }
   __syncthreads();
-  const int p0 = blockIdx.x * pix_per_block;
-  const int p1 = min(p0 + pix_per_block, HW);
+  auto apply_store = [&](const half8& h, const float (&sc)[8], const float (&sh)[8], int pp, int c) {
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = (float)h[e] * sc[e] + sh[e];
+      if (silu) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+      o[e] = (half_t)v;
+    }
+    *reinterpret_cast<half8*>(y + ((size_t)b * HW + pp) * C + c) = o;
+  };
   for (int cb = 0; cb < ncol; cb += 256) {
     const int cols = min(256, ncol - cb);
     const int rows = 256 / cols;
@@ -227,15 +264,33 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const half_t* __re
     if (r0 >= rows) continue;
     const int c = col * 8;
     float sc[8], sh[8];
+    if (cb == 0) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int g = (c + e) / cpg;
-      sc[e] = s_rstd[g] * gamma[c + e];
-      sh[e] = beta[c + e] - s_mean[g] * sc[e];
+      for (int e = 0; e < 8; ++e) {
+        const int g = (c + e) / cpg;
+        sc[e] = s_rstd[g] * (e < 4 ? g_lo[e & 3] : g_hi[e & 3]);
+        sh[e] = (e < 4 ? b_lo[e & 3] : b_hi[e & 3]) - s_mean[g] * sc[e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int g = (c + e) / cpg;
+        sc[e] = s_rstd[g] * gamma[c + e];
+        sh[e] = beta[c + e] - s_mean[g] * sc[e];
+      }
     }
     const half_t* src = (c < C0) ? x0 + c : x1 + (c - C0);
     const int Cs = (c < C0) ? C0 : C1;
-    for (int p = p0 + r0; p < p1; p += 4 * rows) {
+    int p = p0 + r0;
+    if (cb == 0) {                                     // the four pixels requested before the fold
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pp = p + u * rows;
+        if (pp < p1) apply_store(pre[u], sc, sh, pp, c);
+      }
+      p += 4 * rows;
+    }
+    for (; p < p1; p += 4 * rows) {
       half8 h[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -245,16 +300,7 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const half_t* __re
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int pp = p + u * rows;
-        if (pp < p1) {
-          half8 o;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float v = (float)h[u][e] * sc[e] + sh[e];
-            if (silu) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
-            o[e] = (half_t)v;
-          }
-          *reinterpret_cast<half8*>(y + ((size_t)b * HW + pp) * C + c) = o;
-        }
+        if (pp < p1) apply_store(h[u], sc, sh, pp, c);
       }
     }
   }
@@ -436,7 +482,8 @@ void launch_groupnorm(const half_t* x0, int C0, const half_t* x1, int C1, float*
   const int cpg = C / G;
   if (producer_entries > 0) {   // statistics came out of the producing kernel's epilogue: one apply launch
     SD_REQUIRE(producer_entries <= kGnMaxSlabs && !x1, kInternal, "groupnorm: %d producer entries", producer_entries);
-    int slabs = groupnorm_num_slabs(B, HW);
+    // pixel slabs of the apply pass are independent of the producer's entries: ~512 workgroups, >= 8 pixels each
+    int slabs = std::max(1, std::min(std::max(1, 512 / std::max(1, B)), std::max(1, HW / 8)));
     const int ppb = cdiv(HW, slabs);
     slabs = cdiv(HW, ppb);
     hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(slabs, B), dim3(256), 0, s, x0, C0, x1, C1, partial, producer_entries, gamma,

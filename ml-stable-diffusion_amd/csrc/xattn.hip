@@ -150,7 +150,8 @@ __global__ __launch_bounds__(256, xattn_lds_bytes(NST) <= 80 * 1024 ? 2 : 1) voi
     const int fly = ahead < DEPTH ? ahead : DEPTH;
     // tile kt has landed for every wave (loads of one wave return in order) and every wave has finished reading the
     // stage the next DMA overwrites; counted wait + raw barrier in one statement (a __syncthreads would drain vmcnt(0))
-    if (DEPTH >= 2 && fly == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((DEPTH >= 2 ? 2 : 0) * PER_TILE) : "memory");
+    if (DEPTH >= 3 && fly == 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((DEPTH >= 3 ? 3 : 0) * PER_TILE) : "memory");
+    else if (DEPTH >= 2 && fly == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((DEPTH >= 2 ? 2 : 0) * PER_TILE) : "memory");
     else if (DEPTH >= 1 && fly == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((DEPTH >= 1 ? 1 : 0) * PER_TILE) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     const int st = kt % NST;
@@ -328,7 +329,8 @@ void launch_xattn_fused(const XAttnDesc& d, hipStream_t s) {
   // the deep-K levels; SD_XATTN_NST overrides (tuning)
   static const int forced = getenv("SD_XATTN_NST") ? atoi(getenv("SD_XATTN_NST")) : 0;
   const int nst = forced ? forced : (d.nst ? d.nst : (d.C <= 640 ? 2 : 3));
-  if (nst >= 4) launch_nst<4>(a, s);
+  if (nst >= 5) launch_nst<5>(a, s);
+  else if (nst == 4) launch_nst<4>(a, s);
   else if (nst == 3) launch_nst<3>(a, s);
   else launch_nst<2>(a, s);
   SD_HIP(hipGetLastError());

@@ -106,7 +106,7 @@ XATTN_CASES = [  # (B, heads, Sq, Sk)
 
 
 @pytest.mark.parametrize("case", XATTN_CASES, ids=lambda c: "x".join(map(str, c)))
-@pytest.mark.parametrize("nst", [2, 3, 4])
+@pytest.mark.parametrize("nst", [2, 3, 4, 5])
 def test_cross_attention_fused_matches_oracle(case, nst):
     b, heads, sq, sk = case
     c = heads * 64
