@@ -23,9 +23,13 @@ Timing: the K-step timed region (barrier + synchronize on both sides, max over r
 Extra objects on the JSON line:
   roofline     MFMA roofline of the step graph: algorithmic FLOP per step (SURVEY.md section 8d:
                1.6085e12 per CFG-batch-2 step) / HIP-event time per step on the handle's stream;
-               `traffic` = HBM bytes per step from rocprofv3 PMC passes (profiles/r02_final_hbm_traffic.json,
-               tools/gpu_r2_r.sh), `dominant_kernel` = the largest conv family timed IN SEQUENCE
-               (sd_unet_profile: HIP events around every op of the eager step) next to its stand-alone time
+               `traffic` = HBM bytes per step from rocprofv3 PMC passes (profiles/r03_final_hbm_traffic.json,
+               `tools/gpu_session.sh <tag> pmc`; only when the file was measured on this very library and workload),
+               `dominant_kernel` = the kernel family with the largest TIME share of the step (sd_unet_profile: HIP
+               events around every op of the eager step), `kernel_families` = all of them, `flop_heaviest_kernel` =
+               the largest conv family in sequence next to its stand-alone time
+  --model / --latent select the UNets of BASELINE configs 4 and 5 and 768x768 latents (reported lines; the default
+               invocation is BASELINE config 2)
   cpu_baseline the oracle (CPU restatement of the reference UNet + loop) timed on this box's host
                cores on a bounded sample (rank 0, N=1 only) at the best of a small thread sweep; kind "port"
 """
@@ -42,10 +46,21 @@ for p in (ROOT, os.path.join(ROOT, "ml-stable-diffusion_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-FLOP_PER_SAMPLE_STEP = 1.6085e12 / 2     # 804.3 GFLOP per latent sample
+FLOP_PER_SAMPLE_STEP = 1.6085e12 / 2     # 804.3 GFLOP per latent sample (SD2.1-base, 64x64 latents)
 MFMA_PEAK_TFLOPS = 2500.0                # MI355X dense fp16/bf16 (MI355X_MICROARCH.md)
 PUBLISHED_BEST_ITS = 3.07                # best published SD2.1-base it/s (iPad Pro M2, Core ML)
 MODEL = "stabilityai/stable-diffusion-2-1-base"
+# --model: the UNets of BASELINE.json's configs (random-init weights of the real architectures).  The default
+# invocation stays BASELINE config 2 (sd21-base at 64x64 latents); the others are reported lines, never `vs_baseline`.
+MODELS = {
+    "sd21-base": dict(id=MODEL, latent=64, config="BASELINE config 2", name="SD2.1-base (865.9 M-parameter UNet)"),
+    "sdxl-base": dict(id="stabilityai/stable-diffusion-xl-base-1.0", latent=96, config="BASELINE config 4 (base stage)",
+                      name="SDXL-base-1.0 (2.57 B-parameter UNet, dual-text-encoder conditioning)"),
+    "sdxl-refiner": dict(id="stabilityai/stable-diffusion-xl-refiner-1.0", latent=96, config="BASELINE config 4 (refiner stage)",
+                         name="SDXL-refiner-1.0 (2.26 B-parameter UNet)"),
+    "sd15-control": dict(id="runwayml/stable-diffusion-v1-5", latent=64, config="BASELINE config 5", control=True,
+                         name="SD1.5 control-UNet + ControlNet, residuals handed over on the device"),
+}
 
 
 def main():
@@ -59,7 +74,13 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=2, help="oracle steps timed for cpu_baseline (0 = skip)")
     ap.add_argument("--repeats", type=int, default=5, help="repeats of the K-step timed region (median reported)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--model", default="sd21-base", choices=sorted(MODELS), help="UNet of BASELINE configs 2 / 4 / 5")
+    ap.add_argument("--latent", type=int, default=0, choices=[0, 64, 96, 128],
+                    help="latent height = width (64: 512x512 images, 96: 768x768); 0 = the model's BASELINE size")
     args = ap.parse_args()
+    spec = MODELS[args.model]
+    lat_hw = args.latent or spec["latent"]
+    default_cfg = args.model == "sd21-base" and lat_hw == 64
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -80,28 +101,50 @@ def main():
 
     ppg = args.prompts_per_gpu
     t_build = time.time()
-    shapes = checkpoint.unet_param_shapes(MODEL)
+    from python_hip_stable_diffusion.hip_model import UNET_CONFIGS, normalize_unet_config
+    ucfg = dict(UNET_CONFIGS[spec["id"]])
+    control = None
+    if spec.get("control"):
+        ucfg["support_controlnet"] = True
+    ucfg = normalize_unet_config(ucfg)
+    shapes = checkpoint.unet_param_shapes(ucfg)
     ckpt = checkpoint.random_checkpoint(shapes, seed=0)
-    model = HipModel(MODEL, ckpt, batch=2 * ppg, attention_implementation=args.attention, device=local_rank,
-                     use_graph=not args.no_graph)
+    model = HipModel(ucfg, ckpt, batch=2 * ppg, latent_height=lat_hw, latent_width=lat_hw,
+                     attention_implementation=args.attention, device=local_rank, use_graph=not args.no_graph)
+    if spec.get("control"):   # pipeline.py:259-284, :519-529: the ControlNet runs inside the UNet handle's step graph
+        ccfg = normalize_unet_config(UNET_CONFIGS[spec["id"]])
+        control = HipModel(ccfg, checkpoint.random_checkpoint(checkpoint.controlnet_param_shapes(ccfg), seed=2), kind="controlnet",
+                           batch=2 * ppg, latent_height=lat_hw, latent_width=lat_hw, attention_implementation=args.attention,
+                           device=local_rank, use_graph=not args.no_graph)
+        control.set_controlnet_cond(np.random.RandomState(95).rand(2 * ppg, 3, lat_hw * 8, lat_hw * 8).astype(np.float16))
+        model.attach_controlnets([control])
+    if not default_cfg:
+        del ckpt
+        ckpt = None
     build_s = time.time() - t_build
+    ctx_dim = ucfg["cross_attention_dim"]
 
     # prompts are independent units: rank r owns global prompts shard_prompts(...)[r]
     mine = shard_prompts(world * ppg, world)[rank]
     ehs = None
     if rank == 0:   # "text embeddings" for all prompts, [uncond | cond] halves per prompt
-        ehs = np.random.RandomState(94).randn(world * ppg, 2, 1024, 1, 77).astype(np.float16)
-    ehs = broadcast_array(ehs, (world * ppg, 2, 1024, 1, 77), np.float16, dist, local_rank)
+        ehs = np.random.RandomState(94).randn(world * ppg, 2, ctx_dim, 1, 77).astype(np.float16)
+    ehs = broadcast_array(ehs, (world * ppg, 2, ctx_dim, 1, 77), np.float16, dist, local_rank)
     my_ehs = np.concatenate([ehs[mine, 0], ehs[mine, 1]])          # batch order [uncond..., cond...] (pipeline.py:245)
-    latents = np.stack([np.random.RandomState(93 + g).randn(4, 64, 64) for g in mine]).astype(np.float32)
+    latents = np.stack([np.random.RandomState(93 + g).randn(4, lat_hw, lat_hw) for g in mine]).astype(np.float32)
+    loop_inputs = {"encoder_hidden_states": my_ehs}
+    if model.num_time_ids:   # SDXL micro-conditioning (pipeline.py:245-257, StableDiffusionXLPipeline.swift:326-358)
+        img = lat_hw * 8
+        ids = [img, img, 0, 0, img, img] if model.num_time_ids == 6 else [img, img, 0, 0, 6.0]
+        loop_inputs["time_ids"] = np.tile(np.asarray(ids, np.float16), (2 * ppg, 1))
+        loop_inputs["text_embeds"] = np.random.RandomState(96).randn(2 * ppg, model.text_embed_dim).astype(np.float16)
 
     sch = schedulers.DDIMScheduler()
 
     def run(n_steps):
         sch.set_timesteps(max(n_steps, 1))
         ts, coef, hist = sch.device_tables()
-        return model.denoise_loop(latents * sch.init_noise_sigma, ts, coef, args.guidance_scale, history=hist,
-                                  encoder_hidden_states=my_ehs)
+        return model.denoise_loop(latents * sch.init_noise_sigma, ts, coef, args.guidance_scale, history=hist, **loop_inputs)
 
     def barrier():
         if dist is not None:
@@ -137,73 +180,144 @@ def main():
     total_prompt_steps = world * ppg * args.steps
     value = total_prompt_steps / elapsed
     ev_ms_step = rep_ev[mid]
-    flop_per_launch = FLOP_PER_SAMPLE_STEP * 2 * ppg
+    x = np.concatenate([latents, latents]).astype(np.float16)
+    fwd_inputs = dict(loop_inputs, sample=x, timestep=np.full((2 * ppg,), 951, np.float16))
+    ops = None
+    if world == 1:   # per-op HIP-event times of one eager step (sd_unet_profile), attached ControlNet included
+        model(**fwd_inputs)
+        ops = model.profile(iters=7)
+        if control is not None:
+            ops = control.profile(iters=7) + ops
+    if default_cfg:
+        flop_per_launch = FLOP_PER_SAMPLE_STEP * 2 * ppg
+        flop_note = "algorithmic: 804.3 GFLOP per latent sample (SURVEY.md section 8d)"
+    else:   # executed MFMA FLOP of the launch list (the prompt's K/V projections are hoisted out of the step)
+        assert ops is not None, "--model / --latent other than the default are single-GPU lines"
+        flop_per_launch = float(sum(fl for _, fl, _ in ops))
+        flop_note = "sum of the algorithmic FLOP of every conv / GEMM / attention launch of the step (sd_unet_profile labels)"
     achieved = flop_per_launch / (ev_ms_step * 1e-3) / 1e12
+    px = lat_hw * 8
+    metric = ("diffusion iter/s (UNet steps/s), SD2.1-base 512x512 fp16" if default_cfg else
+              f"diffusion iter/s (UNet steps/s), {args.model} {px}x{px} fp16")
     out = {
-        "metric": "diffusion iter/s (UNet steps/s), SD2.1-base 512x512 fp16",
+        "metric": metric,
         "value": round(value, 3), "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "repeats": len(rep_s), "repeats_ms_per_step": [round(r / args.steps * 1e3, 4) for r in rep_s],
-        "vs_baseline": round(value / PUBLISHED_BEST_ITS, 2),
+        "vs_baseline": round(value / PUBLISHED_BEST_ITS, 2) if default_cfg and ppg == 1 else None,
         "vs_baseline_note": "BASELINE.md best published SD2.1-base number: 3.07 it/s, iPad Pro (M2), Core ML "
                             "6-bit palettized (README.md:74); no published CPU/GPU-server number exists",
         "dtype": "fp16", "data": "synthetic",
-        "config": {"workload": "BASELINE config 2: SD2.1-base (865.9 M-parameter UNet, random-init) denoising iteration, "
-                               "512x512 (64x64 latents), CFG batch 2 per prompt, DDIM, device-resident loop",
+        "config": {"workload": f"{spec['config']}: {spec['name']}, random-init, denoising iteration at {px}x{px} "
+                               f"({lat_hw}x{lat_hw} latents), CFG batch 2 per prompt, DDIM, device-resident loop",
+                   "model": args.model, "latent": lat_hw,
                    "attention": args.attention, "prompts_per_gpu": ppg, "global_batch": 2 * ppg * world,
                    "guidance_scale": args.guidance_scale, "hip_graph": not args.no_graph,
                    "parallelism": f"dp{world} (independent prompts per rank, no data-path collective)"},
         "roofline": {"bound": "mfma", "kernel": "unet_step_graph (all MFMA conv/GEMM/attention launches of one step)",
                      "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                     "flop_per_launch": flop_per_launch, "launch_ms": round(ev_ms_step, 4),
+                     "flop_per_launch": flop_per_launch, "flop_definition": flop_note, "launch_ms": round(ev_ms_step, 4),
                      "timing": "hipEvent on the handle's stream: median step of the median repeat"},
         "e2e": {"model_build_s": round(build_s, 1), "final_latents_finite": True,
                 "gathered_latents": list(all_final.shape), "hbm_bytes": int(model.device_bytes)},
     }
-    if world == 1 and ppg == 1:
-        out["roofline"].update(hbm_traffic(ev_ms_step))
-    if world == 1:   # the most FLOP-heavy kernel family of the step: in sequence and alone
-        out["roofline"]["dominant_kernel"] = dominant_kernel(model, my_ehs, latents, ppg)
-    if world == 1:   # end-to-end latency of one generation: 20 DDIM steps + VAE decode (pipeline.py:500-589)
+    if world == 1:
+        out["roofline"].update(hbm_traffic(ev_ms_step, args, lat_hw))
+        out["roofline"].update(kernel_families(ops, ev_ms_step))
+    if world == 1 and default_cfg:   # the most FLOP-heavy kernel family of the step: in sequence and alone
+        out["roofline"]["flop_heaviest_kernel"] = flop_heaviest_kernel(ops, 2 * ppg)
+    if world == 1 and default_cfg:   # end-to-end latency of one generation: 20 DDIM steps + VAE decode (pipeline.py:500-589)
         out["e2e"].update(e2e_latency(model, checkpoint, my_ehs[[0, ppg]], latents[:1], args.guidance_scale,
                                       local_rank))
-    if world == 1 and args.cpu_steps > 0:
+    if world == 1 and default_cfg and args.cpu_steps > 0:
         out["cpu_baseline"] = cpu_baseline(ckpt, my_ehs[[0, ppg]], latents[:1], args.cpu_steps, args.guidance_scale)
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
 
-def hbm_traffic(step_ms):
-    """HBM bytes per step from the committed rocprofv3 PMC passes (bench.py cannot run under the profiler
-    itself): profiles/r02_final_hbm_traffic.json is written by tools/pmc_reduce.py from separate --pmc
-    FETCH_SIZE / WRITE_SIZE runs of the same step, corrected as MI355X_MICROARCH.md prescribes."""
-    path = os.path.join(ROOT, "profiles", "r02_final_hbm_traffic.json")
+def build_id():
+    """Identity of the running build for the committed PMC file: hash of the shipped library (the GPU box has no .git)."""
+    import hashlib
+    lib = os.path.join(ROOT, "ml-stable-diffusion_amd", "lib", "libsdmi355.so")
+    with open(lib, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def hbm_traffic(step_ms, args, lat_hw):
+    """HBM bytes per step from committed rocprofv3 PMC passes (bench.py cannot run under the profiler itself):
+    profiles/r03_final_hbm_traffic.json is written by tools/pmc_reduce.py from separate --pmc FETCH_SIZE / WRITE_SIZE
+    runs of the same step, corrected as MI355X_MICROARCH.md prescribes, and stamped with the hash of the library it
+    profiled and the workload.  The number is only emitted when both match this run; otherwise `traffic` is null."""
+    path = os.path.join(ROOT, "profiles", "r03_final_hbm_traffic.json")
     if not os.path.exists(path):
-        return {}
+        return {"traffic": None, "traffic_detail": {"note": "no PMC file committed for this round"}}
     with open(path) as f:
         t = json.load(f)
+    want = {"build_id": build_id(), "model": args.model, "latent": lat_hw, "prompts_per_gpu": args.prompts_per_gpu,
+            "attention": args.attention}
+    have = {k: t.get(k) for k in want}
+    if have != want:
+        return {"traffic": None, "traffic_detail": {
+            "note": "profiles/r03_final_hbm_traffic.json was measured on another build / workload: not reported as this run's",
+            "file": have, "this_run": want}}
     total = float(t["bytes_per_step"])
     return {"traffic": total, "traffic_detail": {
-        "source": "profiles/r02_final_hbm_traffic.json (rocprofv3 --pmc, eager launches of the same step)",
+        "source": "profiles/r03_final_hbm_traffic.json (rocprofv3 --pmc, eager launches of the same step, same library hash)",
+        "build_id": want["build_id"],
         "read_bytes": t.get("read_bytes_per_step"), "write_bytes": t.get("write_bytes_per_step"),
         "algorithmic_min_bytes": t.get("algorithmic_min_bytes"),
         "hbm_gb_per_s_at_this_run": round(total / (step_ms * 1e-3) / 1e9, 1), "hbm_peak_gb_per_s": 8000.0,
         "hbm_frac": round(total / (step_ms * 1e-3) / 8e12, 4)}}
 
 
-def dominant_kernel(model, ehs, latents, ppg):
+def op_family(label):
+    """Kernel family of a launch-list entry (sd_unet_profile label) = the source kernel that runs it."""
+    if label.startswith("conv3x3") and "small-N" not in label and " 4->" not in label:
+        return "conv3x3 (conv3x3_halo_ks_kernel / stride-2 igemm_kernel)"
+    if label.startswith(("gemm1x1", "geglu1x1")):
+        return "1x1 GEMMs (igemm_kernel)"
+    if label.startswith("attention"):
+        return "self-attention (attn_kernel)"
+    if label.startswith("xattn"):
+        return "cross-attention with fused q projection (xattn_kernel)"
+    if label.startswith("groupnorm"):
+        return "GroupNorm (groupnorm_* kernels)"
+    return "other (boundary, time embedding, conv_in / conv_out, residual adds)"
+
+
+def kernel_families(ops, graph_ms):
+    """Time share of every kernel family of the step from the per-op HIP-event medians of one eager step
+    (sd_unet_profile), largest first; `dominant_kernel` is the family with the largest TIME share, with its
+    fraction of the MFMA roof over all of its launches."""
+    fam = {}
+    for lbl, fl, ms in ops:
+        f = fam.setdefault(op_family(lbl), [0, 0.0, 0.0])
+        f[0] += 1
+        f[1] += ms
+        f[2] += fl
+    total = sum(f[1] for f in fam.values())
+    rows = []
+    for k, (n, ms, fl) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+        tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        rows.append({"family": k, "launches": n, "ms": round(ms, 4), "share": round(ms / total, 4), "gflop": round(fl / 1e9, 1),
+                     "achieved": round(tf, 1), "frac": round(tf / MFMA_PEAK_TFLOPS, 4)})
+    top = dict(rows[0])
+    top.update({"kernel": top.pop("family"), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "bound": "mfma",
+                "timing": "sum over the family's launches of the per-op HIP-event median of one eager step (sd_unet_profile); "
+                          "shares are of the eager per-op sum"})
+    return {"dominant_kernel": top, "kernel_families": rows, "step_ops": len(ops), "step_ops_ms_sum": round(total, 4),
+            "graph_ms": round(graph_ms, 4)}
+
+
+def flop_heaviest_kernel(ops, B):
     """3x3 convolutions are 49.8 % of the step's FLOPs; the 320->320 conv at 64x64
     (seven per step, 15.1 GFLOP each at CFG batch 2) is the largest family.  `frac` is its IN-SEQUENCE
     time (HIP events around every op of one eager UNet forward, predecessors' caches cold exactly as in the
-    graph; agrees with the rocprofv3 kernel trace in profiles/); the stand-alone time of the same kernel
-    (50 back-to-back launches, operands L2-warm) is reported beside it and is NOT the roofline number."""
+    graph); the stand-alone time of the same kernel (50 back-to-back launches, operands L2-warm) is reported
+    beside it and is NOT the roofline number."""
     from python_hip_stable_diffusion import _lib
-    B = 2 * ppg
-    x = np.concatenate([latents, latents]).astype(np.float16)
-    model(sample=x, timestep=np.full((B,), 951, np.float16), encoder_hidden_states=ehs)
-    ops = model.profile(iters=7)
     fam = [(lbl, fl, ms) for lbl, fl, ms in ops if lbl.startswith("conv3x3 320->320 @64x64")]
     assert len(fam) == 7, [o[0] for o in ops if o[0].startswith("conv3x3")][:12]
     ms_in = float(np.mean([m for _, _, m in fam]))
@@ -214,18 +328,13 @@ def dominant_kernel(model, ehs, latents, ppg):
     w = (rs.randn(320, 320, 3, 3) / np.sqrt(320 * 9)).astype(np.float16)
     _, ms = _lib.conv2d(xs, w, np.zeros(320, np.float32), None, iters=50)
     tf = flop / (ms * 1e-3) / 1e12
-    total_ms = float(sum(m for _, _, m in ops))
-    mfma_ms = float(sum(m for _, fl, m in ops if fl > 0))
     return {"kernel": f"3x3 conv 320->320 @64x64, UNet batch {B} (K-split software-pipelined LDS-halo MFMA kernel, plan from "
                       "tuned_convs.inc), 7 launches per step",
             "flop_per_launch": flop, "launch_ms": round(ms_in, 5), "achieved": round(tf_in, 1), "peak": MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": round(tf_in / MFMA_PEAK_TFLOPS, 4),
             "timing": "in sequence: mean over the family's 7 launches of the per-op HIP-event median (sd_unet_profile)",
             "standalone": {"launch_ms": round(ms, 5), "achieved": round(tf, 1), "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
-                           "timing": "same kernel alone, 50 back-to-back launches, operands L2-warm"},
-            "step_ops": len(ops), "step_ops_ms_sum": round(total_ms, 4), "step_mfma_ops_ms_sum": round(mfma_ms, 4),
-            "bound": "per-workgroup serial phases: of the 14.5 us a 256-workgroup launch takes, MFMA issue is 5.6 us, exposed fragment reads "
-                     "2.3 us, exposed DMA issue 2.1 us, launch + prologue + epilogue 4.5 us (profiles/r02_ablate_halo_ks_warm.txt)"}
+                           "timing": "same kernel alone, 50 back-to-back launches, operands L2-warm"}}
 
 
 def e2e_latency(model, checkpoint, ehs, latents, guidance, device):

@@ -93,6 +93,9 @@ typedef struct sd_unet_config {
   int32_t is_vae_decoder;        /* build the AutoencoderKL decoder (sd_vae_decoder_create)          */
   int32_t attention_impl;        /* sd_attention_impl                                                */
   int32_t use_graph;             /* 1: capture the forward into a HIP graph and replay it            */
+  int32_t compute_fp32;          /* VAE handles only: 1 = fp32 activations and arithmetic, the reference's
+                                  * float32 VAE of SDXL (torch2coreml.py:570-578 decoder, :726-733 encoder: "z" / "x"
+                                  * declared float32, pipeline.py:315 reads the dtype off the model); 0 = fp16 storage */
 } sd_unet_config;
 
 typedef struct sd_unet sd_unet;
@@ -140,7 +143,9 @@ int sd_unet_time_forward(sd_unet* u, int warmup, int iters, float* ms_per_iter);
 int sd_unet_profile(sd_unet* u, int iters, int cap, float* ms, double* flop, char* labels, int label_bytes,
                     int* n_ops);
 
-/* Tuning hook of the same kind: while tile != 0, every convolution / GEMM whose constraints admit it runs with
+/* ---- debug ABI (tuning / race-guard tools): both entry points below return SD_ERR_UNSUPPORTED unless the process
+ * runs with SD_TUNE=1 in its environment; nothing in the product path calls them. ----
+ * Tuning hook of the same kind: while tile != 0, every convolution / GEMM whose constraints admit it runs with
  * this plan (tile 1-6, LDS-DMA ring code 0-5, split-K; csrc/igemm.hip) instead of the table's, so ONE profiled
  * forward measures a candidate on every layer shape in sequence (tools/tune_plans.py).  tile = 0 switches it off.
  * Process-global; never set in production. */

@@ -173,8 +173,16 @@ int sd_unet_set_attention(sd_unet* u, int impl) {
     u->impl->set_attention(impl);
   });
 }
+// Debug ABI: process-global plan overrides exist for the tuning / race-guard tools only and are refused unless the
+// process runs with SD_TUNE=1 (the product path has no global mutable state).
+static void require_tune_env() {
+  static const bool on = getenv("SD_TUNE") != nullptr;
+  SD_REQUIRE(on, kUnsupported, "sd_tune_* is a debug ABI: set SD_TUNE=1 in the environment to enable it");
+}
+
 int sd_tune_set_plan_table(const char* rows, sd_unet* u, int* n_plans) {
   return guarded([&] {
+    require_tune_env();
     const int n = conv_plan_table_set(rows);
     if (n_plans) *n_plans = n;
     if (u) u->impl->drop_graphs();   // the captured launches bake the old plans in
@@ -207,7 +215,8 @@ int sd_unet_denoise_loop(sd_unet* u, const sd_unet_io* io, float* latents, int n
 
 int sd_tune_set_candidate(int tile, int staging, int splitk) {
   return guarded([&] {
-    SD_REQUIRE(tile >= 0 && tile <= 7 && staging >= 0 && staging <= 8 && splitk >= 0 && splitk <= 64, kInvalidArgument,
+    require_tune_env();
+    SD_REQUIRE(tile >= 0 && tile <= 8 && staging >= 0 && staging <= 8 && splitk >= 0 && splitk <= 64, kInvalidArgument,
                "tune candidate (tile %d, staging %d, splitk %d)", tile, staging, splitk);
     conv_tune_set_candidate(tile, staging, splitk);
   });

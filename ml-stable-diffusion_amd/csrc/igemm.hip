@@ -64,6 +64,12 @@ struct IgemmArgs {
   // Every entry < 2 * gn_T is written by exactly one workgroup per launch (no atomics: the replay stays bit-reproducible).
   float* gn_partial;
   int gn_G, gn_cpg, gn_T;   // groups, channels per group, m-tiles per sample
+  // Tile order inside an XCD's contiguous run of workgroup ids.  0: m fastest - consecutive workgroups share a WEIGHT panel
+  // (right when the weights outweigh the activations: the 8x8 / 16x16 levels at small batch).  1: n fastest - consecutive
+  // workgroups share an ACTIVATION panel, so each XCD pulls its rows through the fabric once and the other n-tiles hit its L2
+  // (round 2 measured 27 MB of fabric reads for a 320->320 GEMM at M = 8192 with 10.6 MB of operands: every n-tile of a row
+  // block ran on a different XCD).  Chosen per launch from the operand sizes (launch_conv).
+  int n_fast;
 };
 
 constexpr int kGnScratchFloats = 256 * 17;   // per-thread (sum[8], sumsq[8]) of the epilogue's store loop, +1 pad
@@ -404,7 +410,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     bid = base + idx;   // bijective for any nwg
   }
-  const int bn_idx = bid / nbm, bm_idx = bid % nbm;   // consecutive ids share the weight panel
+  const int bn_idx = a.n_fast ? bid % nbn : bid / nbm, bm_idx = a.n_fast ? bid / nbn : bid % nbm;   // IgemmArgs::n_fast
   const int m_blk = bm_idx * BM, n_blk = bn_idx * BN;
 
   const int split = blockIdx.y;
@@ -840,7 +846,7 @@ __global__ __launch_bounds__(256, halo_lds_bytes(BN, D) <= 80 * 1024 ? 2 : 1) vo
     int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     bid = base + idx;
   }
-  const int bn_idx = bid / m_tiles, mt = bid % m_tiles;
+  const int bn_idx = a.n_fast ? bid % n_tiles : bid / m_tiles, mt = a.n_fast ? bid / n_tiles : bid % m_tiles;
   const int b = mt / (a.tiles_y * a.tiles_x);
   const int trem = mt - b * (a.tiles_y * a.tiles_x);
   const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
@@ -1159,7 +1165,7 @@ __global__ __launch_bounds__(256, halo_lds_bytes(64, D) <= 80 * 1024 ? 2 : 1) vo
     int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     bid = base + idx;
   }
-  const int bn_idx = bid / m_tiles, mt = bid % m_tiles;
+  const int bn_idx = a.n_fast ? bid % n_tiles : bid / m_tiles, mt = a.n_fast ? bid / n_tiles : bid % m_tiles;
   const int b = mt / (a.tiles_y * a.tiles_x);
   const int trem = mt - b * (a.tiles_y * a.tiles_x);
   const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
@@ -1483,6 +1489,246 @@ __global__ __launch_bounds__(256, halo_lds_bytes(64, D) <= 80 * 1024 ? 2 : 1) vo
 }
 
 #undef HALO_SRC
+
+// ---------------------------------------------------------------------------------------------
+// Software-pipelined 1x1 GEMM (every Linear / 1x1 conv of the transformer blocks and the resnet shortcuts at stride 1;
+// unet.py:62-118, :566-617).  igemm_kernel above reads the 16 fragments of a K step, waits for them, then issues its 16
+// MFMAs: with one wave per SIMD the LDS latency and the barrier are exposed once per step and the matrix pipe idles
+// 50-75 % of the loop (245-520 TFLOP/s at UNet batch 16, profiles/r03_op_profile_b16.txt).  Here the loop body is the
+// one of the K-split halo conv kernel:
+//   * fragments are double-buffered in registers - between the MFMAs of step s the wave issues the ds_read_b128 of
+//     step s+1 and the LDS-DMA of step s+D; the body is ONE basic block (no conditionals: tiles past the end of K go
+//     through a zero-sized buffer resource), so sched_group_barrier fixes the interleaving MFMA / 2 reads ... MFMA / DMA;
+//   * operands come HBM -> LDS by buffer_load_dwordx4 ... lds with loop-invariant per-lane offsets and a scalar K offset
+//     (no vector address arithmetic in the loop; rows past M read zeros through the buffer range check; the second
+//     source of a skip concat is a second resource selected per tile on the scalar unit);
+//   * one raw s_barrier per step behind counted waits: lgkmcnt(0) (this wave holds step s in registers, so after the
+//     barrier nobody reads ring stage s % D any more) and vmcnt((D-2) tiles) (tile s+1 has landed).
+// Before the epilogue re-uses the LDS the wave drains vmcnt(0): an LDS-DMA still in flight when a workgroup hands its
+// LDS back would land in whatever workgroup is dispatched there next.
+// Accumulator layout, swizzle and epilogue are igemm_kernel's (tile_epilogue: bias / timestep embedding / LayerNorm fold /
+// GEGLU / residual / fused q|k|v / GroupNorm statistics / split-K slabs).
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int WGM, int WGN, int D, bool LNF>
+__global__ __launch_bounds__(256) void gemm_pipe_kernel(IgemmArgs a) {
+  static_assert(WGM * WGN == 4, "4 waves");
+  constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
+  constexpr int XR = BM / 32, WR = BN / 32, PER = XR + WR, ROWB = BK * 2, KK = BK / 16;
+  static_assert((D - 1) * PER <= 63, "vmcnt range");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Xs = smem;                                   // [D][BM][BK] halves
+  char* const Ws = smem + D * BM * ROWB;                   // [D][BN][BK]
+  float* sconst = reinterpret_cast<float*>(smem + (size_t)D * (BM + BN) * ROWB);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
+  const int nwg = nbm * nbn;
+  int bid = blockIdx.x;
+  {   // XCD-aware order (see igemm_kernel): each XCD walks a contiguous run of tiles sharing a weight panel
+    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    bid = base + idx;
+  }
+  const int bn_idx = a.n_fast ? bid % nbn : bid / nbm, bm_idx = a.n_fast ? bid / nbn : bid % nbm;
+  const int m_blk = bm_idx * BM, n_blk = bn_idx * BN;
+  const int split = blockIdx.y;
+  const int kt_begin = split * a.nk_per_split;
+  int kt_end = kt_begin + a.nk_per_split;
+  if (kt_end > a.nk_total) kt_end = a.nk_total;
+  const int T = kt_end - kt_begin;                          // K steps of this workgroup (>= 1: launch_conv leaves no empty split)
+
+  constexpr unsigned kOob = 0x80000000u;
+  const int pchunk = tid & 7, lrow = tid >> 3;
+  const unsigned lchunk = (unsigned)(pchunk ^ ((lrow >> 1) & 7)) * 16u;   // logical 16-B chunk this lane fetches (bank swizzle)
+  unsigned xoff0[XR], xoff1[XR], woff[WR];
+#pragma unroll
+  for (int i = 0; i < XR; ++i) {
+    const int m = m_blk + lrow + 32 * i;
+    xoff0[i] = m < a.M ? (unsigned)m * (unsigned)a.C0 * 2u + lchunk : kOob;
+    xoff1[i] = m < a.M ? (unsigned)m * (unsigned)a.C1 * 2u + lchunk : kOob;
+  }
+#pragma unroll
+  for (int i = 0; i < WR; ++i) {
+    int n = n_blk + lrow + 32 * i;
+    if (n > a.N - 1) n = a.N - 1;                           // rows past N: clamped (their outputs are never stored)
+    woff[i] = (unsigned)n * (unsigned)a.K * 2u + lchunk;
+  }
+  const unsigned x0_bytes = (unsigned)((size_t)a.M * a.C0 * 2), x1_bytes = (unsigned)((size_t)a.M * a.C1 * 2);
+  const unsigned w_bytes = (unsigned)((size_t)a.N * a.K * 2);
+
+  int iw_kt = kt_begin, iw_stage = 0;                       // issue cursor of the ring
+  auto issue_tile = [&]() {
+    const bool live = iw_kt < kt_end;                       // wave-uniform; past the end: zero-sized resources, nothing is fetched
+    const int k = iw_kt * BK;
+    const bool second = k >= a.C0;                          // the skip-concat's second source (never with C1 == 0)
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<half_t*>(second ? a.x1 : a.x0), 0, (int)(live ? (second ? x1_bytes : x0_bytes) : 0u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.w), 0, (int)(live ? w_bytes : 0u), 0x00020000);
+    const int xs_off = (second ? k - a.C0 : k) * 2;
+    char* xs = Xs + iw_stage * (BM * ROWB) + wave * 1024;
+    char* ws = Ws + iw_stage * (BN * ROWB) + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < XR; ++i) dma16_to_lds(rs_x, xs + i * 4096, second ? xoff1[i] : xoff0[i], xs_off);
+#pragma unroll
+    for (int i = 0; i < WR; ++i) dma16_to_lds(rs_w, ws + i * 4096, woff[i], k * 2);
+    ++iw_kt;
+    iw_stage = (iw_stage + 1 == D) ? 0 : iw_stage + 1;
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float ln_s1[TM] = {}, ln_s2[TM] = {};
+
+  const int frow = lane & 31, hi = lane >> 5;
+  const int fsw = (frow >> 1) & 7;
+  int foff[KK];                                             // byte offset of this lane's chunk of k sub-step kk inside a row
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) foff[kk] = ((kk * 2 + hi) ^ fsw) * 16;
+  const int xrow = (wm * TM * 32 + frow) * ROWB, wrow = (wn * TN * 32 + frow) * ROWB;
+
+  // per-column epilogue constants and the residual tile, requested before the first DMA (oldest VMEM ops of the wave)
+  const bool temb_uniform = a.temb != nullptr && (a.HoWo % BM) == 0;
+  float const_b = 0.f, const_t = 0.f, const_c = 0.f;
+  if (a.splitk == 1 && tid < BN) {
+    const int n = n_blk + tid;
+    if (n < a.N) {
+      if (a.bias) const_b = a.bias[n];
+      if (temb_uniform) const_t = a.temb[(size_t)(m_blk / a.HoWo) * a.temb_stride + n];
+      if constexpr (LNF) const_c = a.ln_colsum[n];
+    }
+  }
+  constexpr int RIT = BM * BN / 8 / 256;
+  constexpr bool RES_PRE = RIT <= 4;
+  half8 resv[RES_PRE ? RIT : 1];
+  const bool use_resv = RES_PRE && a.res_pre && a.res != nullptr && a.splitk == 1 && a.out_mode == kOutHalf && n_blk < a.n_trans;
+  if constexpr (RES_PRE) {
+    if (use_resv) {
+#pragma unroll
+      for (int it = 0; it < RIT; ++it) {
+        const int idx = tid + it * 256;
+        const int r = idx / (BN / 8), c = idx - r * (BN / 8);
+        const int m = m_blk + r, n = n_blk + c * 8;
+        const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        resv[it] = (m < a.M && n + 8 <= a.ldo) ? *reinterpret_cast<const half8*>(a.res + (size_t)m * a.ldo + n) : z;
+      }
+    }
+  }
+
+  struct Frags {
+    half8 x[KK][TM];
+    half8 w[KK][TN];
+  };
+  auto read_step = [&](Frags& f, int stage) {
+    const char* xs = Xs + stage * (BM * ROWB) + xrow;
+    const char* ws = Ws + stage * (BN * ROWB) + wrow;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) f.x[kk][i] = *reinterpret_cast<const half8*>(xs + i * 32 * ROWB + foff[kk]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) f.w[kk][j] = *reinterpret_cast<const half8*>(ws + j * 32 * ROWB + foff[kk]);
+    }
+  };
+  auto mfma_step = [&](const Frags& f) {
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.w[kk][j], f.x[kk][i], acc[i][j], 0, 0, 0);
+      if constexpr (LNF) {   // row statistics of the A tile for the LayerNorm fold: VALU work in the MFMAs' issue shadow
+        const half2v one2 = {(half_t)1.f, (half_t)1.f};
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const half2v p2 = {f.x[kk][i][2 * e], f.x[kk][i][2 * e + 1]};
+            ln_s2[i] = __builtin_amdgcn_fdot2(p2, p2, ln_s2[i], false);
+            ln_s1[i] = __builtin_amdgcn_fdot2(p2, one2, ln_s1[i], false);
+          }
+      }
+    }
+  };
+
+  Frags fA, fB;
+#pragma unroll
+  for (int p = 0; p < D; ++p) {
+    asm volatile("" ::: "memory");                          // keep the DMA issue order: the counted waits rely on it
+    issue_tile();
+  }
+  wait_vmcnt_barrier<(D - 1) * PER>();                      // tile 0 has landed for every wave
+  read_step(fA, 0);
+  int rd_stage = 0;                                         // ring stage of the step being multiplied
+  auto body = [&](Frags& cur, Frags& nxt, auto last) {
+    constexpr bool LAST = decltype(last)::value;
+    if constexpr (LAST) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      mfma_step(cur);
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's fragments of the current step are in registers
+      wait_vmcnt_barrier<(D - 2) * PER>();                  // the next tile has landed; nobody reads stage rd_stage any more
+      const int nstage = (rd_stage + 1 == D) ? 0 : rd_stage + 1;
+      read_step(nxt, nstage);                               // fragments of the next step -> the other register set
+      issue_tile();                                         // tile (step + D) -> the stage just freed
+      mfma_step(cur);
+      rd_stage = nstage;
+      if constexpr (!LNF) {
+        constexpr int NM = KK * TM * TN, NR = KK * (TM + TN);
+        constexpr int RPM = (NR + NM / 2 - 1) / (NM / 2);   // reads behind each MFMA of the first half
+#pragma unroll
+        for (int g = 0; g < NM / 2; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, RPM, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < NM - NM / 2; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x010, (PER + NM - NM / 2 - 1) / (NM - NM / 2), 0);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  {
+    using Tt = std::true_type;
+    using Ff = std::false_type;
+    int st = 0;
+    for (; st + 2 < T; st += 2) {
+      body(fA, fB, Ff{});
+      body(fB, fA, Ff{});
+    }
+    if (T - st == 2) {
+      body(fA, fB, Ff{});
+      body(fB, fA, Tt{});
+    } else {
+      body(fA, fB, Tt{});
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the zero-sized tail DMAs too: the LDS is about to be re-used
+
+  float ln_a[TM] = {}, ln_b[TM] = {};
+  if constexpr (LNF) {
+    const float inv_k = 1.0f / (float)a.K;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const float s1 = xor32_sum(ln_s1[i]), s2 = xor32_sum(ln_s2[i]);
+      const float mean = s1 * inv_k;
+      const float var = fmaxf(s2 * inv_k - mean * mean, 0.f);
+      ln_a[i] = rsqrtf(var + a.ln_eps);
+      ln_b[i] = -ln_a[i] * mean;
+    }
+  }
+  tile_epilogue<BM, BN, WGM, WGN, TM, TN, LNF, (RES_PRE ? RIT : 0)>(a, acc, ln_a, ln_b, smem, sconst, const_b, const_t, const_c, m_blk,
+                                                                    n_blk, wave, split, temb_uniform, resv, use_resv);
+}
 
 // split-K combine + the same epilogue (bias, temb broadcast, residual) -> fp16
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmArgs a) {
@@ -1808,6 +2054,11 @@ bool halo_ks_ok(const ConvDesc& d) {
          d.C0 % BK == 0 && c1 % BK == 0 && d.N % 4 == 0;
 }
 
+bool gemm_pipe_ok(const IgemmArgs& a) {
+  const size_t lim = (size_t)1 << 31;
+  return a.ksize == 1 && a.stride == 1 && a.up == 1 && (size_t)a.M * std::max(a.C0, a.C1) * 2 < lim && (size_t)a.N * a.K * 2 < lim;
+}
+
 void tile_dims(int tile, int& bm, int& bn) {
   switch (tile) {
     case 5: bm = 128; bn = 128; break;   // halo kernel, 8x16-pixel tile
@@ -1816,6 +2067,7 @@ void tile_dims(int tile, int& bm, int& bn) {
     case 1: bm = 128; bn = 128; break;
     case 2: bm = 128; bn = 64; break;
     case 3: bm = 64; bn = 64; break;
+    case 8: bm = 256; bn = 128; break;   // software-pipelined 1x1 GEMM only (gemm_pipe_kernel): 87 FLOP per LDS-fill byte
     default: bm = 64; bn = 128; break;
   }
 }
@@ -1886,11 +2138,12 @@ Plan choose_plan(const ConvDesc& d, const IgemmArgs& a) {
   const bool can_split = d.out_mode == kOutHalf && !d.ln_colsum && !d.out_t;
   auto is_halo = [](int c) { return c == 5 || c == 6 || c == 7; };
   auto tile_ok = [&](int c) {
-    if (c < 1 || c > 7) return false;
+    if (c < 1 || c > 8) return false;
     if (is_halo(c)) return (c == 7 ? halo_ks_ok(d) : halo_ok(d)) && !d.ln_colsum && !d.out_t && !geglu;
+    if (c == 8 && (!gemm_pipe_ok(a) || d.out_mode == kOutHalfT)) return false;
     int bm, bn;
     tile_dims(c, bm, bn);
-    if (geglu && c != 1 && c != 4) return false;       // GEGLU value/gate pairs need 64 n-columns per wave
+    if (geglu && c != 1 && c != 4 && c != 8) return false;       // GEGLU value/gate pairs need 64 n-columns per wave
     if (d.out_t && d.n_trans % bn != 0) return false;  // the q|k / v boundary must be a tile boundary
     return true;
   };
@@ -1930,6 +2183,18 @@ Plan choose_plan(const ConvDesc& d, const IgemmArgs& a) {
       p.tile = hit->tile;
       p.staging = hit->staging;
       p.splitk = hit->splitk;
+    }
+  }
+  static const bool no_pipe_heur = getenv("SD_NO_PIPE_HEURISTIC") != nullptr;   // A/B switch
+  if (p.tile == 0 && !pinned && !no_pipe_heur && a.ksize == 1 && a.M >= 8192 && gemm_pipe_ok(a) && d.out_mode != kOutHalfT) {
+    // no measured plan and many tokens (batched prompts, larger latents): the software-pipelined GEMM kernel on the 128x64
+    // tile - two workgroups per CU - won 7 of 9 layer shapes at UNet batch 16 by 10-25 % (profiles/r03_gemm_pipe_bench_b16.txt);
+    // GEGLU needs 64 n-columns per wave: 64x128
+    const int c = geglu ? 4 : 2;
+    if (tile_ok(c)) {
+      p.tile = c;
+      p.staging = 6;
+      p.splitk = 1;
     }
   }
   if (p.tile == 0 && tile_ok(7)) {
@@ -2092,8 +2357,30 @@ template <int BM, int BN>
 constexpr bool ring_fits(int nst) {
   return (size_t)nst * (BM + BN) * BK * sizeof(half_t) + 2 * BN * sizeof(float) <= kLdsBudget;
 }
+// staging 6 / 7: the software-pipelined 1x1 GEMM kernel with a ring of 3 / 4 stages (1x1, stride 1, non-transposed
+// output; 32-bit buffer offsets); anything else that asks for them runs the 4-stage ring of igemm_kernel
+template <int BM, int BN, int WGM, int WGN, int D, bool LNF>
+void launch_pipe(const IgemmArgs& a, hipStream_t s) {
+  constexpr size_t lds = (size_t)D * (BM + BN) * BK * sizeof(half_t) + 2 * BN * sizeof(float);
+  static_assert(lds <= kLdsBudget, "LDS");
+  static_assert((size_t)BM * (BN + 8) * 2 + 16 + (kGnScratchFloats + 2 * BN) * sizeof(float) <= (size_t)D * (BM + BN) * BK * sizeof(half_t),
+                "staged tile + GroupNorm statistics scratch fit the K-loop buffers");
+  static_assert((size_t)BN * (BM + 8) <= (size_t)D * (BM + BN) * BK, "transposed staging fits");
+  dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), a.splitk);
+  auto k = gemm_pipe_kernel<BM, BN, WGM, WGN, D, LNF>;
+  static DynLdsOnce once;
+  once.set(k, lds);
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+}
 template <int BM, int BN, int WGM, int WGN, bool LNF>
 void launch_ring(const IgemmArgs& a, int staging, hipStream_t s) {
+  if ((staging == 6 || staging == 7) && gemm_pipe_ok(a)) {
+    if (staging == 7) {
+      if constexpr (ring_fits<BM, BN>(4)) { launch_pipe<BM, BN, WGM, WGN, 4, LNF>(a, s); return; }
+    }
+    launch_pipe<BM, BN, WGM, WGN, 3, LNF>(a, s);
+    return;
+  }
   if (staging >= 6) staging = 3;
   if (staging >= 5) {
     if constexpr (ring_fits<BM, BN>(8)) { launch_variant<BM, BN, WGM, WGN, false, true, 8, LNF>(a, s); return; }
@@ -2224,6 +2511,14 @@ int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
   }
   const bool trans = d.out_mode == kOutHalfT;
   const int st = p.staging;
+  {   // tile order (IgemmArgs::n_fast): fabric bytes ~ A * n-tiles + 8 W (m fastest) against A + 8 W * ... (n fastest)
+    int bm, bn;
+    tile_dims(p.tile, bm, bn);
+    const long nbn = cdiv(a.N, bn);
+    const double a_bytes = 2.0 * a.B * a.Hi * a.Wi * a.Ctot, w_bytes = 2.0 * a.N * a.K;
+    static const int forced = getenv("SD_TILE_ORDER") ? atoi(getenv("SD_TILE_ORDER")) : -1;   // A/B switch: 0 / 1
+    a.n_fast = forced >= 0 ? (forced != 0) : (nbn > 1 && a_bytes * (double)(nbn - 1) > 7.0 * w_bytes);
+  }
   static const bool log_plans = getenv("SD_LOG_CONVS") != nullptr;
   if (log_plans)
     fprintf(stderr, "[sd conv] k%d s%d up%d C0=%d C1=%d M=%d N=%d K=%d mode=%d tile=%d splitk=%d\n", a.ksize, a.stride, a.up,
@@ -2241,10 +2536,14 @@ int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
   } else {
     if (!trans) {
       int bm, bn;
-      tile_dims(p.tile >= 1 && p.tile <= 3 ? p.tile : 4, bm, bn);
+      tile_dims((p.tile >= 1 && p.tile <= 3) || p.tile == 8 ? p.tile : 4, bm, bn);
       gn_entries = setup_gn_stats(d, a, bm);
     }
     switch (p.tile) {
+      case 8:
+        if (a.ln_colsum) launch_pipe<256, 128, 2, 2, 3, true>(a, s);
+        else launch_pipe<256, 128, 2, 2, 3, false>(a, s);
+        break;
       case 1: launch_tile<128, 128, 2, 2>(a, trans, st, s); break;
       case 2: launch_tile<128, 64, 2, 2>(a, trans, st, s); break;
       case 3: launch_tile<64, 64, 2, 2>(a, trans, st, s); break;

@@ -138,6 +138,28 @@ bool groupnorm_wants_producer_stats(int HW, int C, int G);
 void launch_row_softmax(half_t* x, int rows, int cols, float scale, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
+// fp32 compute path of the VAE graphs (vae_f32.hip; torch2coreml.py:570-578, :726-733): fp32 NHWC activations
+// ---------------------------------------------------------------------------------------------
+struct ConvF32Desc {
+  const float* x = nullptr;     // [B][Hi][Wi][Cin]
+  const void* w = nullptr;      // w_kind 0: half [N][K], 1: float [N][K], 2: float [K][N];  K = ksize*ksize*Cin, tap-major
+  int w_kind = 0;
+  const float* bias = nullptr;  // [N] or null
+  const float* res = nullptr;   // [M][N] or null
+  float* out = nullptr;         // [M][N], M = B*Ho*Wo
+  int B = 1, Hi = 1, Wi = 1, Cin = 0, Ho = 1, Wo = 1, N = 0;
+  int ksize = 1, stride = 1, up = 1;
+  int pad = -1;                 // -1: ksize / 2; 0 with stride 2: the VAE encoder's F.pad(x, (0, 1, 0, 1))
+};
+void launch_conv_f32(const ConvF32Desc& d, hipStream_t s);
+size_t groupnorm_f32_scratch_bytes(int B, int G);
+void launch_groupnorm_f32(const float* x, void* scratch, const float* gamma, const float* beta, float* y, int B, int HW, int C, int G,
+                          float eps, int silu, hipStream_t s);
+void launch_row_softmax_f32(float* x, int rows, int cols, float scale, hipStream_t s);
+void launch_nchw_to_nhwc_f32(const void* src, int src_is_f32, float* dst, int B, int C, int H, int W, hipStream_t s);
+void launch_nhwc_to_nchw_f32f32(const float* src, float* dst, int B, int C, int H, int W, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
 // K8/K9 + boundary helpers (misc.hip)
 // ---------------------------------------------------------------------------------------------
 // sinusoidal embedding [cos|sin] (unet.py:703-728), fp32.  t: [n] fp32, freq: [dim/2] device

@@ -42,6 +42,9 @@ UNet::UNet(const sd_unet_config& cfg, const WeightStore& ws, int device) : cfg_(
     SD_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
     SD_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
   }
+  f32_ = cfg_.compute_fp32 != 0;
+  SD_REQUIRE(!f32_ || cfg_.is_vae_decoder, kUnsupported,
+             "compute_fp32 is the VAE graphs' option (torch2coreml.py:570-578, :726-733); the UNet kernels store fp16");
   if (cfg_.is_vae_decoder == 2)
     build_vae_encoder();
   else if (cfg_.is_vae_decoder)
@@ -74,7 +77,7 @@ Tensor UNet::new_tensor(int B, int H, int W, int C) {
   t.H = H;
   t.W = W;
   t.C = C;
-  t.p = arena_.alloc_n<half_t>(t.numel());
+  t.p = arena_.alloc_n<half_t>(t.numel() * (f32_ ? 2 : 1));   // compute_fp32: the same bookkeeping over float elements
   return t;
 }
 
@@ -255,6 +258,24 @@ Tensor UNet::conv_w(std::vector<Op>& ops, const std::string& name, const half_t*
     out = new_tensor(x.B, d.Ho, d.Wo, geglu ? cout / 2 : cout);
   }
   d.out = out.p;
+  if (f32_) {   // VAE handle with compute_fp32: the same op on the fp32 kernels (vae_f32.hip)
+    SD_REQUIRE(!x2 && !temb && !ex && out_mode == kOutHalf && !silu_out, kInternal, "%s: not a VAE conv", name.c_str());
+    ConvF32Desc fd;
+    fd.x = reinterpret_cast<const float*>(x.p);
+    fd.w = w;
+    fd.w_kind = 0;
+    fd.bias = bias;
+    fd.res = reinterpret_cast<const float*>(res);
+    fd.out = reinterpret_cast<float*>(out.p);
+    fd.B = x.B; fd.Hi = x.H; fd.Wi = x.W; fd.Cin = x.C; fd.Ho = d.Ho; fd.Wo = d.Wo; fd.N = cout;
+    fd.ksize = k; fd.stride = stride; fd.up = up; fd.pad = d.pad;
+    ops.push_back([fd](hipStream_t s) { launch_conv_f32(fd, s); });
+    char buf[256];
+    snprintf(buf, sizeof(buf), "conv%dx%d fp32 %d->%d @%dx%d %s", k, k, x.C, cout, d.Ho, d.Wo, name.c_str());
+    ops.back().label = buf;
+    ops.back().flop = 2.0 * x.B * d.Ho * d.Wo * (double)cout * x.C * k * k;
+    return out;
+  }
   SD_REQUIRE(!ex || (conv_fast_path_ok(d) && !silu_out), kInternal, "%s: LayerNorm fold / fused q|k|v off the MFMA path",
              name.c_str());
   // a GroupNorm built later over exactly this tensor may ask for its statistics from this op's epilogue (GnHook)
@@ -303,6 +324,19 @@ Tensor UNet::group_norm(std::vector<Op>& ops, const std::string& name, const Ten
   const int C = x.C + (x2 ? x2->C : 0);
   const int G = cfg_.norm_num_groups;
   SD_REQUIRE(C % G == 0, kUnsupported, "%s: %d channels not divisible by %d groups", name.c_str(), C, G);
+  if (f32_) {
+    SD_REQUIRE(!x2, kInternal, "%s: concat GroupNorm on the fp32 path", name.c_str());
+    void* scratch = arena_.alloc(groupnorm_f32_scratch_bytes(x.B, G));
+    const float* gamma = upload_vec(name + ".weight", C);
+    const float* beta = upload_vec(name + ".bias", C);
+    Tensor y = new_tensor(x.B, x.H, x.W, C);
+    const float* xp = reinterpret_cast<const float*>(x.p);
+    float* yp = reinterpret_cast<float*>(y.p);
+    const int B = x.B, HW = x.H * x.W, si = silu ? 1 : 0;
+    ops.push_back([=](hipStream_t s) { launch_groupnorm_f32(xp, scratch, gamma, beta, yp, B, HW, C, G, eps, si, s); });
+    ops.back().label = "groupnorm fp32 C=" + std::to_string(C) + " @" + std::to_string(x.H) + "x" + std::to_string(x.W) + " " + name;
+    return y;
+  }
   float* partial = arena_.alloc_n<float>(groupnorm_scratch_floats(x.B, x.H * x.W, G));
   const float* gamma = upload_vec(name + ".weight", C);
   const float* beta = upload_vec(name + ".bias", C);
@@ -777,6 +811,34 @@ Tensor UNet::vae_attention(std::vector<Op>& ops, const std::string& p, const Ten
   Tensor t0 = group_norm(ops, p + ".group_norm", h, nullptr, 1e-6f, false);
   Tensor q = conv(ops, p + ".to_q", t0, nullptr, C, 1, 1, 1, true, nullptr, nullptr);
   Tensor k = conv(ops, p + ".to_k", t0, nullptr, C, 1, 1, 1, true, nullptr, nullptr);
+  if (f32_) {   // the same three steps on the fp32 kernels: K tokens / V play the weight matrices
+    Tensor v = conv(ops, p + ".to_v", t0, nullptr, C, 1, 1, 1, true, nullptr, nullptr);
+    float* scores = arena_.alloc_n<float>((size_t)S * S);
+    Tensor a = new_tensor(B, H, W, C);
+    const float scale = 1.0f / std::sqrt((float)C);
+    for (int b = 0; b < B; ++b) {
+      ConvF32Desc d1;   // scores[q][k] = sum_c Q[q][c] K[k][c]
+      d1.x = reinterpret_cast<const float*>(q.p) + (size_t)b * S * C;
+      d1.w = reinterpret_cast<const float*>(k.p) + (size_t)b * S * C;
+      d1.w_kind = 1;
+      d1.out = scores;
+      d1.B = 1; d1.Hi = 1; d1.Wi = S; d1.Cin = C; d1.Ho = 1; d1.Wo = S; d1.N = S;
+      ConvF32Desc d2;   // out[q][c] = sum_k P[q][k] V[k][c]
+      d2.x = scores;
+      d2.w = reinterpret_cast<const float*>(v.p) + (size_t)b * S * C;
+      d2.w_kind = 2;
+      d2.out = reinterpret_cast<float*>(a.p) + (size_t)b * S * C;
+      d2.B = 1; d2.Hi = 1; d2.Wi = S; d2.Cin = S; d2.Ho = 1; d2.Wo = S; d2.N = C;
+      ops.push_back([d1, d2, scores, S, scale](hipStream_t s) {
+        launch_conv_f32(d1, s);
+        launch_row_softmax_f32(scores, S, S, scale, s);
+        launch_conv_f32(d2, s);
+      });
+      ops.back().label = "VAE attention fp32: QK^T GEMM + row softmax + PV GEMM, S=" + std::to_string(S);
+      ops.back().flop = 4.0 * (double)S * S * C;
+    }
+    return conv(ops, p + ".to_out.0", a, nullptr, C, 1, 1, 1, true, nullptr, h.p);
+  }
   const int ldv = round_up(S, 8);
   Tensor vt = conv(ops, p + ".to_v", t0, nullptr, C, 1, 1, 1, true, nullptr, nullptr, kOutHalfT, ldv);
   SD_REQUIRE(C % 64 == 0 && S % 64 == 0, kUnsupported, "VAE attention needs C %% 64 == 0 and H*W %% 64 == 0");
@@ -811,7 +873,8 @@ void UNet::build_vae_decoder() {
   Tensor z = new_tensor(B, H, W, Cz);
   {
     float* src = in_z_;
-    main_ops_.push_back([=](hipStream_t s) { launch_nchw_to_nhwc(src, 1, z.p, B, Cz, H, W, s); });
+    if (f32_) main_ops_.push_back([=](hipStream_t s) { launch_nchw_to_nhwc_f32(src, 1, reinterpret_cast<float*>(z.p), B, Cz, H, W, s); });
+    else main_ops_.push_back([=](hipStream_t s) { launch_nchw_to_nhwc(src, 1, z.p, B, Cz, H, W, s); });
   }
   Tensor h = conv(main_ops_, "post_quant_conv", z, nullptr, Cz, 1, 1, 1, true, nullptr, nullptr);
   const int Ctop = cfg_.block_out_channels[n - 1];
@@ -840,7 +903,18 @@ void UNet::build_vae_decoder() {
     d.B = t.B; d.Hi = t.H; d.Wi = t.W; d.Ho = t.H; d.Wo = t.W;
     d.ksize = 3; d.stride = 1; d.up = 1; d.N = cfg_.out_channels;
     float* dst = image_;
-    main_ops_.push_back([=](hipStream_t s) { launch_conv_small_n(d, dst, s); });
+    if (f32_) {
+      Tensor o = new_tensor(t.B, t.H, t.W, cfg_.out_channels);
+      ConvF32Desc fd;
+      fd.x = reinterpret_cast<const float*>(t.p); fd.w = d.w; fd.bias = d.bias; fd.out = reinterpret_cast<float*>(o.p);
+      fd.B = t.B; fd.Hi = t.H; fd.Wi = t.W; fd.Cin = t.C; fd.Ho = t.H; fd.Wo = t.W; fd.N = cfg_.out_channels; fd.ksize = 3;
+      main_ops_.push_back([=](hipStream_t s) {
+        launch_conv_f32(fd, s);
+        launch_nhwc_to_nchw_f32f32(fd.out, dst, fd.B, fd.N, fd.Ho, fd.Wo, s);
+      });
+    } else {
+      main_ops_.push_back([=](hipStream_t s) { launch_conv_small_n(d, dst, s); });
+    }
     main_ops_.back().label = "conv3x3 small-N decoder.conv_out -> fp32 NCHW";
     main_ops_.back().flop = 2.0 * t.B * t.H * t.W * (double)cfg_.out_channels * t.C * 9;
   }
@@ -902,8 +976,9 @@ void UNet::build_vae_encoder() {
   {
     void* src = in_x_;
     UNet* self = this;
-    main_ops_.push_back([=](hipStream_t s) { launch_nchw_to_nhwc(src, self->vae_in_f32_, x.p, B, 3, H, W, s); });
-    main_ops_.back().label = "boundary: image NCHW -> NHWC fp16";
+    if (f32_) main_ops_.push_back([=](hipStream_t s) { launch_nchw_to_nhwc_f32(src, self->vae_in_f32_, reinterpret_cast<float*>(x.p), B, 3, H, W, s); });
+    else main_ops_.push_back([=](hipStream_t s) { launch_nchw_to_nhwc(src, self->vae_in_f32_, x.p, B, 3, H, W, s); });
+    main_ops_.back().label = "boundary: image NCHW -> NHWC";
   }
   Tensor h = conv(main_ops_, "encoder.conv_in", x, nullptr, cfg_.block_out_channels[0], 3, 1, 1, true, nullptr, nullptr);
   for (int i = 0; i < n; ++i) {
@@ -930,7 +1005,14 @@ void UNet::build_vae_encoder() {
     d.out = m.p;
     d.B = t.B; d.Hi = t.H; d.Wi = t.W; d.Ho = t.H; d.Wo = t.W;
     d.ksize = 3; d.stride = 1; d.up = 1; d.N = Cm;
-    main_ops_.push_back([=](hipStream_t s) { launch_conv_small_n(d, nullptr, s); });
+    if (f32_) {
+      ConvF32Desc fd;
+      fd.x = reinterpret_cast<const float*>(t.p); fd.w = d.w; fd.bias = d.bias; fd.out = reinterpret_cast<float*>(m.p);
+      fd.B = t.B; fd.Hi = t.H; fd.Wi = t.W; fd.Cin = t.C; fd.Ho = t.H; fd.Wo = t.W; fd.N = Cm; fd.ksize = 3;
+      main_ops_.push_back([=](hipStream_t s) { launch_conv_f32(fd, s); });
+    } else {
+      main_ops_.push_back([=](hipStream_t s) { launch_conv_small_n(d, nullptr, s); });
+    }
     main_ops_.back().label = "conv3x3 small-N encoder.conv_out";
   }
   Tensor q = conv(main_ops_, "quant_conv", m, nullptr, Cm, 1, 1, 1, true, nullptr, nullptr);
@@ -938,8 +1020,9 @@ void UNet::build_vae_encoder() {
   image_ = arena_.alloc_n<float>(image_elems_);
   {
     float* dst = image_;
-    main_ops_.push_back([=](hipStream_t s) { launch_nhwc_to_nchw_f32(q.p, dst, q.B, q.C, q.H, q.W, s); });
-    main_ops_.back().label = "boundary: moments NHWC fp16 -> NCHW fp32";
+    if (f32_) main_ops_.push_back([=](hipStream_t s) { launch_nhwc_to_nchw_f32f32(reinterpret_cast<const float*>(q.p), dst, q.B, q.C, q.H, q.W, s); });
+    else main_ops_.push_back([=](hipStream_t s) { launch_nhwc_to_nchw_f32(q.p, dst, q.B, q.C, q.H, q.W, s); });
+    main_ops_.back().label = "boundary: moments NHWC -> NCHW fp32";
   }
   if (ws_need_ > 0) {
     ws_conv_.partial = reinterpret_cast<float*>(arena_.alloc(ws_need_));

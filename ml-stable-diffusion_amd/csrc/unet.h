@@ -131,6 +131,7 @@ class UNet {
   sd_unet_config cfg_;
   const WeightStore* ws_ = nullptr;   // only valid during construction
   int device_ = 0;
+  bool f32_ = false;                  // VAE handle with cfg.compute_fp32: fp32 activations on the vae_f32.hip kernels
   hipStream_t stream_ = nullptr;
   // SD_SIDE_TIME=1 (experiment, off by default): the time-embedding chain (depends only on the timestep)
   // runs on a forked stream beside conv_in / the first GroupNorm and joins before the first consumer of

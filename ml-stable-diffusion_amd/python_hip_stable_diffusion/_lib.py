@@ -39,7 +39,7 @@ class UNetConfig(C.Structure):
         ("addition_time_embed_dim", C.c_int32), ("projection_class_embeddings_input_dim", C.c_int32),
         ("num_time_ids", C.c_int32), ("support_controlnet", C.c_int32), ("is_controlnet", C.c_int32),
         ("is_vae_decoder", C.c_int32),
-        ("attention_impl", C.c_int32), ("use_graph", C.c_int32),
+        ("attention_impl", C.c_int32), ("use_graph", C.c_int32), ("compute_fp32", C.c_int32),
     ]
 
 

@@ -422,7 +422,10 @@ VAE_CONFIGS["runwayml/stable-diffusion-v1-5"] = VAE_CONFIGS["stabilityai/stable-
 class HipVaeDecoder:
     """``vae_decoder`` model runner: ``decoder(post_quant_conv(z))`` (torch2coreml.py:584-594) behind
     the CoreMLModel interface: ``expected_inputs["z"]`` (pipeline.py:315) and
-    ``model(z=...)["image"]`` in [-1, 1] (pipeline.py:316), NCHW fp32."""
+    ``model(z=...)["image"]`` in [-1, 1] (pipeline.py:316), NCHW fp32.
+    ``dtype`` is the model's declared input dtype AND its compute precision, as in the reference's conversion
+    (torch2coreml.py:570-578): ``np.float16`` = the MFMA kernels (fp16 storage, fp32 accumulation); ``np.float32`` = fp32
+    activations and arithmetic end to end (``compute_fp32``), what the stock SDXL VAE needs."""
 
     def __init__(self, config, weights, batch=1, latent_height=64, latent_width=64, device=0, use_graph=True,
                  dtype=np.float16):
@@ -439,6 +442,10 @@ class HipVaeDecoder:
         c.layers_per_block = config["layers_per_block"]
         c.norm_num_groups, c.norm_eps = 32, 1e-6
         c.use_graph = int(use_graph)
+        if np.dtype(dtype) not in (np.dtype(np.float16), np.dtype(np.float32)):
+            raise ValueError(f"VAE dtype must be float16 or float32, got {dtype}")
+        c.compute_fp32 = int(np.dtype(dtype) == np.float32)
+        self.compute_dtype = np.dtype(dtype)
         own = not isinstance(weights, Weights)
         wstore = weights if not own else (Weights(safetensors_path=weights) if isinstance(weights, (str, bytes))
                                           else Weights(tensors=weights))
@@ -507,6 +514,10 @@ class HipVaeEncoder:
         c.layers_per_block = config["layers_per_block"]
         c.norm_num_groups, c.norm_eps = 32, 1e-6
         c.use_graph = int(use_graph)
+        if np.dtype(dtype) not in (np.dtype(np.float16), np.dtype(np.float32)):
+            raise ValueError(f"VAE dtype must be float16 or float32, got {dtype}")
+        c.compute_fp32 = int(np.dtype(dtype) == np.float32)   # torch2coreml.py:726-733: the SDXL encoder is float32 too
+        self.compute_dtype = np.dtype(dtype)
         own = not isinstance(weights, Weights)
         wstore = weights if not own else (Weights(safetensors_path=weights) if isinstance(weights, (str, bytes))
                                           else Weights(tensors=weights))

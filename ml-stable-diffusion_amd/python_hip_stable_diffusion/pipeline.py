@@ -405,12 +405,15 @@ def checkpoint_scheduler_config(model_dir):
 def get_hip_pipe(model_dir, model_version, compute_unit="ALL", scheduler_override=None, controlnet_models=None,
                  force_zeros_for_empty_prompt=True, sources=None, attention_implementation="SPLIT_EINSUM",
                  num_images=1, guidance_scale=7.5, unet_batch_one=False, latent_size=None, device=0,
-                 refiner_dir=None, tokenizer_factory=None, text_encoder_factory=None):
+                 refiner_dir=None, tokenizer_factory=None, text_encoder_factory=None, vae_dtype=None):
     """``get_coreml_pipe`` (pipeline.py:607-697) without the conversion step: ``model_dir`` is a diffusers
     checkpoint directory (``unet/``, ``vae/``, ``text_encoder/``, ``tokenizer/``, ``scheduler/`` [,
     ``text_encoder_2/``, ``tokenizer_2/``]) instead of a folder of ``.mlpackage`` files; ControlNets are
     diffusers ControlNet directories.  ``compute_unit`` / ``sources`` are accepted and ignored.  Static shapes
-    (pipeline.py:112-114) are fixed here: UNet batch = (2 if guidance_scale > 1 else 1) * num_images."""
+    (pipeline.py:112-114) are fixed here: UNet batch = (2 if guidance_scale > 1 else 1) * num_images.
+    ``vae_dtype``: compute precision of the VAE decoder; default = the reference's conversion rule (torch2coreml.py:570-578):
+    float32 for an SDXL checkpoint's own VAE (it overflows fp16), float16 otherwise; pass ``np.float16`` for an
+    fp16-safe replacement VAE (``--custom-vae-version``)."""
     if not os.path.isdir(model_dir):
         raise FileNotFoundError(f"{model_dir} not found (coreml_model.py:176-178)")
     from . import text_encoder as te
@@ -450,7 +453,8 @@ def get_hip_pipe(model_dir, model_version, compute_unit="ALL", scheduler_overrid
         dict(latent_channels=vcfg.get("latent_channels", 4), out_channels=vcfg.get("out_channels", 3),
              block_out_channels=tuple(vcfg["block_out_channels"]), layers_per_block=vcfg.get("layers_per_block", 2)),
         _find_weights(os.path.join(model_dir, "vae")), batch=1, latent_height=lat,
-        latent_width=kwargs["unet"].latent_width, device=device)
+        latent_width=kwargs["unet"].latent_width, device=device,
+        dtype=np.dtype(vae_dtype) if vae_dtype is not None else (np.float32 if xl else np.float16))
     kwargs["vae_scaling_factor"] = vcfg.get("scaling_factor")
     make_tok = tokenizer_factory or te.load_tokenizer
     make_enc = text_encoder_factory or (lambda folder, **kw: te.HipTextEncoder.from_pretrained(folder, device=device, **kw))

@@ -45,7 +45,7 @@ def test_no_kernel_spills_and_two_workgroups_per_cu_where_planned(src, tmp_path)
 def test_plan_table_rows_are_well_formed_and_unique():
     """csrc/tuned_convs.inc: every row is {kind, ksize, stride, up, Ctot, N, M, tile, staging, splitk} with legal codes, no
     shape key twice (the first match wins in choose_plan, a duplicate would be dead), the K-split halo kernel (tile 7) only on
-    3x3 / stride-1 shapes, split-K only where the epilogue kind can split."""
+    3x3 / stride-1 shapes, the software-pipelined GEMM kernel (staging 6 / 7, tile 8) only on 1x1 / stride-1 shapes, split-K only where the epilogue kind can split."""
     rows = []
     for line in open(os.path.join(CSRC, "tuned_convs.inc")):
         if line.startswith("{"):
@@ -58,10 +58,12 @@ def test_plan_table_rows_are_well_formed_and_unique():
     for kind, ks, st, up, ctot, n, m, tile, staging, sk in rows:
         assert kind in (0, 1, 2, 3) and ks in (1, 3) and st in (1, 2) and up in (1, 2)
         assert ctot % 64 == 0 and n % 4 == 0 and m > 0
-        assert 1 <= tile <= 7 and 0 <= staging <= 5 and 0 <= sk <= 16
+        assert 1 <= tile <= 8 and 0 <= staging <= 7 and 0 <= sk <= 16
         if tile in (5, 6, 7):
             assert ks == 3 and st == 1 and (up == 1 or tile == 7)
+        if staging in (6, 7) or tile == 8:   # the software-pipelined GEMM kernel: 1x1 / stride 1 only
+            assert ks == 1 and st == 1 and up == 1 and tile in (1, 2, 3, 4, 8)
         if kind != 0:
-            assert sk in (0, 1) and tile in (1, 2, 3, 4)
+            assert sk in (0, 1) and tile in (1, 2, 3, 4, 8)
         if kind == 2:
-            assert tile in (1, 4)
+            assert tile in (1, 4, 8)

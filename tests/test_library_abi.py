@@ -108,3 +108,15 @@ def test_torch_cpu_and_philox_streams_match_their_restatements_and_torch(sdlib):
         np.testing.assert_allclose(got, np.array(rng_ref.philox_randn(seed, off, n)), atol=1e-12, rtol=0)
     g = _lib.philox_randn(93, 100000)
     assert abs(g.mean()) < 0.02 and abs(g.std() - 1.0) < 0.02
+
+
+def test_tune_abi_is_dead_without_the_environment_switch():
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k != "SD_TUNE"}
+    code = ("import sys; sys.path[:0] = [%r, %r]\n"
+            "from python_hip_stable_diffusion import _lib\n"
+            "rc = _lib.lib().sd_tune_set_candidate(3, 0, 1)\n"
+            "print('RC', rc, _lib.lib().sd_last_error().decode())\n") % (ROOT, os.path.join(ROOT, "ml-stable-diffusion_amd"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert "RC -4" in r.stdout and "SD_TUNE" in r.stdout, r.stdout + r.stderr

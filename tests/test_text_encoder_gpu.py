@@ -141,3 +141,79 @@ def test_get_hip_pipe_and_cli_generate_an_image_from_a_text_prompt(tmp_path):
     from PIL import Image
     im = Image.open(path)
     assert im.size == (128, 128) and os.path.basename(path).startswith("randomSeed_93_computeUnit_CPU_AND_NE_")
+
+
+def _byte_level_tokenizer(root):
+    from transformers import CLIPTokenizer
+    alpha = _bytes_to_unicode()
+    vocab = {}
+    for ch in alpha:
+        vocab[ch] = len(vocab)
+    for ch in alpha:
+        vocab[ch + "</w>"] = len(vocab)
+    vocab["<|startoftext|>"] = len(vocab)
+    vocab["<|endoftext|>"] = len(vocab)
+    os.makedirs(root, exist_ok=True)
+    json.dump(vocab, open(os.path.join(root, "vocab.json"), "w"))
+    open(os.path.join(root, "merges.txt"), "w").write("#version: 0.2\n")
+    return CLIPTokenizer(os.path.join(root, "vocab.json"), os.path.join(root, "merges.txt"), model_max_length=77)
+
+
+def test_sdxl_encode_prompt_against_two_independent_oracle_encoders(tmp_path):
+    """The SDXL branch of _encode_prompt (pipeline.py:134-141, :176-180, :245-257; StableDiffusionXLPipeline.swift:262-270):
+    hidden_embeds (penultimate layer) of BOTH encoders concatenated along channels, pooled output of encoder 2 ONLY
+    (its text projection), [negative, positive] order, BC1S transposition; the refiner conditions on encoder 2 alone.
+    The expectation is computed from oracle/clip_ref.py on both towers - never through the pipeline under test."""
+    from python_hip_stable_diffusion.pipeline import HipStableDiffusionPipeline
+    from python_hip_stable_diffusion import schedulers
+    tok = _byte_level_tokenizer(str(tmp_path / "tok"))
+    c1, c2 = dict(clip_ref.CONFIGS["mini-l"]), dict(clip_ref.CONFIGS["mini-g"])
+    eos = tok.eos_token_id
+    for c in (c1, c2):
+        c["vocab_size"] = len(tok)
+        c["eos_token_id"] = eos                      # first-occurrence pooling (non-legacy configs)
+    sds, encs = [], []
+    for c, seed in ((c1, 7), (c2, 8)):
+        sd16 = weights.make_state_dict(clip_ref.param_shapes(c), seed=seed, dtype=np.float16, gain=2.0)
+        sds.append(weights.to_torch({k: v.astype(np.float32) for k, v in sd16.items()}))
+        encs.append(HipTextEncoder(c, sd16, xl=True))
+
+    class UNetShape:                                   # _encode_prompt never touches the UNet beyond its static shapes
+        expected_inputs = {"sample": {"shape": (2, 4, 8, 8)}}
+    pipe = HipStableDiffusionPipeline(encs[0], UNetShape(), None, schedulers.DDIMScheduler(), tok, xl=True,
+                                      force_zeros_for_empty_prompt=False, text_encoder_2=encs[1], tokenizer_2=tok)
+
+    def oracle(text, which):
+        ids = tok(text, padding="max_length", max_length=77, truncation=True, return_tensors="np").input_ids
+        return clip_ref.text_encoder_forward(sds[which], (c1, c2)[which], torch.from_numpy(ids))
+
+    prompt, prompt_2, neg = "a watercolor of a lighthouse", "stormy sea, dramatic light", "blurry, low quality"
+    # base: channels = [encoder 1 | encoder 2]; prompt_2 goes to encoder 2; pooled = encoder 2's projected pooled output
+    got, pooled = pipe._encode_prompt(prompt, prompt_2, True, neg, None)
+    pos = np.concatenate([oracle(prompt, 0)["hidden_embeds"].numpy(), oracle(prompt_2, 1)["hidden_embeds"].numpy()], axis=-1)
+    ng = np.concatenate([oracle(neg, 0)["hidden_embeds"].numpy(), oracle(neg, 1)["hidden_embeds"].numpy()], axis=-1)
+    want = np.concatenate([ng, pos]).transpose(0, 2, 1)[:, :, None, :]
+    assert got.shape == want.shape == (2, c1["hidden_size"] + c2["hidden_size"], 1, 77)
+    assert psnr.compute_psnr(got, want) >= 50.0
+    want_pooled = np.concatenate([oracle(neg, 1)["text_embeds"].numpy(), oracle(prompt_2, 1)["text_embeds"].numpy()])
+    assert pooled.shape == want_pooled.shape == (2, c2["projection_dim"])
+    assert psnr.compute_psnr(pooled, want_pooled) >= 45.0
+    # the two halves really come from different towers / prompts
+    assert psnr.compute_psnr(got[1:, :c1["hidden_size"]], want[1:, c1["hidden_size"]:c1["hidden_size"] * 2]) < 20.0
+    # prompt_2 defaults to prompt (pipeline.py:128-129)
+    got_same, _ = pipe._encode_prompt(prompt, None, True, neg, None)
+    pos_same = np.concatenate([oracle(prompt, 0)["hidden_embeds"].numpy(), oracle(prompt, 1)["hidden_embeds"].numpy()], axis=-1)
+    assert psnr.compute_psnr(got_same[1:], pos_same.transpose(0, 2, 1)[:, :, None, :]) >= 50.0
+    # refiner: encoder 2 alone for both the hidden states and the pooled output (pipeline.py:134-141)
+    got_r, pooled_r = pipe._encode_prompt(prompt, None, True, neg, None, for_refiner=True)
+    want_r = np.concatenate([oracle(neg, 1)["hidden_embeds"].numpy(), oracle(prompt, 1)["hidden_embeds"].numpy()])
+    assert got_r.shape == (2, c2["hidden_size"], 1, 77)
+    assert psnr.compute_psnr(got_r, want_r.transpose(0, 2, 1)[:, :, None, :]) >= 50.0
+    assert psnr.compute_psnr(pooled_r, np.concatenate([oracle(neg, 1)["text_embeds"].numpy(),
+                                                        oracle(prompt, 1)["text_embeds"].numpy()])) >= 45.0
+    # force_zeros_for_empty_prompt (pipeline.py:183-187): an absent negative prompt conditions on zeros, pooled too
+    pipe.force_zeros_for_empty_prompt = True
+    got_z, pooled_z = pipe._encode_prompt(prompt, None, True, None, None)
+    assert not got_z[0].any() and not pooled_z[0].any() and psnr.compute_psnr(got_z[1:], got_same[1:]) >= 80.0
+    for e in encs:
+        e.close()

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box session, parameterised (replaces the per-session scripts of rounds 1-2):
 #   tools/gpu_session.sh <tag> <step> [<step> ...]
-# steps: new (round-3 kernel tests)  tests (full -m gpu suite)  smoke  bench  ab:<ENV=VAL> (bench with an env switch)
+# steps: new (round-3 kernel tests)  tests (full -m gpu suite)  smoke  bench  bench:<flags>  ab:<ENV=VAL> (bench with an env switch)  pmc
 #        profile (per-op table)  trace (rocprofv3 kernel trace of the bench)  py:<script and args> (python tools/<script>)
 # Logs go to gpurun_out/<name>_<tag>.*; a one-line verdict per step is echoed (what gpurun shows at the end).
 set -u
@@ -39,6 +39,26 @@ for step in "$@"; do
       [ -n "$DB" ] && python tools/timeline.py $DB > $OUT/step_timeline_$TAG.txt 2>&1 && head -n 30 $OUT/step_timeline_$TAG.txt | cut -c1-160
       [ -n "$DB" ] && python tools/rocpd_stats.py $DB $OUT/kernel_stats_$TAG.csv > /dev/null 2>&1
       rm -rf $OUT/prof_$TAG ;;
+    pmc)   # HBM traffic + MFMA-busy + stall counters of the eager step: separate --pmc passes (never with trace domains other than kernel-trace)
+      for SET in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES"; do
+        T=$(echo $SET | cut -d' ' -f1)
+        rm -rf $OUT/pmc_$T
+        (cd /tmp && timeout 300 rocprofv3 --pmc $SET --kernel-trace -d $OUT/pmc_$T -o r -- python /root/repo/tools/pmc_probe.py sd21 4 > $OUT/pmc_${T}_$TAG.log 2>&1); note "pmc $T rc=$?"
+      done
+      python tools/pmc_reduce.py $OUT/hbm_traffic_$TAG.json $(find $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES -name "*.db") 2>&1 | tail -n 20
+      rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES ;;
+    bench:*)   # bench with extra flags, e.g. "bench:--model sdxl-base --latent 96"
+      fl=${step#bench:}
+      timeout 900 python bench.py $fl > $OUT/bench_${TAG}_$i.log 2> $OUT/bench_${TAG}_$i.err; note "bench[$fl] rc=$?"
+      tail -n 1 $OUT/bench_${TAG}_$i.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print(d['metric'], d['ms_per_step'], 'ms', d['value'], 'it/s frac', r['frac'], 'dominant', r.get('dominant_kernel',{}).get('kernel'), r.get('dominant_kernel',{}).get('share'), r.get('dominant_kernel',{}).get('frac'))" 2>&1 | cut -c1-400 ;;
+    pytest:*)   # one test file / selection
+      sel=${step#pytest:}
+      timeout 1700 python -m pytest $sel -m gpu -q -x > $OUT/pytest_${TAG}_$i.log 2>&1; note "pytest[$sel] rc=$? $(tail -n 1 $OUT/pytest_${TAG}_$i.log | cut -c1-200)"
+      grep -E "^(FAILED|ERROR)|Error|assert" $OUT/pytest_${TAG}_$i.log | head -n 12 | cut -c1-400 ;;
+    tune:*)   # end-to-end plan tuner: "tune:<candidates.json> [model] [latent]" -> gpurun_out/tuned_e2e_<tag>.inc
+      ar=${step#tune:}
+      SD_TUNE=1 timeout 1200 python tools/tune_e2e.py ${ar%% *} $OUT/tuned_e2e_$TAG.inc $OUT/tune_e2e_report_$TAG.json $( [ "$ar" != "${ar#* }" ] && echo ${ar#* } ) > $OUT/tune_e2e_$TAG.log 2>&1; note "tune_e2e rc=$?"
+      tail -n 25 $OUT/tune_e2e_$TAG.log | cut -c1-200 ;;
     py:*)
       cmd=${step#py:}
       timeout 900 python tools/$cmd > $OUT/py_${TAG}_$i.log 2>&1; note "py[$cmd] rc=$?"; tail -n 40 $OUT/py_${TAG}_$i.log | cut -c1-200 ;;

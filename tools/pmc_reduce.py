@@ -8,7 +8,9 @@ FETCH_SIZE tallies the 128-B requests of wide coalesced reads at 64 B -> doubled
 (uncalibrated).  Both count memory-side (fabric) requests, Infinity-Cache hits included.
 MFMA utilisation: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x kernel duration x clock), with the clock taken
 from GRBM_GUI_ACTIVE / duration when that counter is in the same pass, else 2.4 GHz."""
+import hashlib
 import json
+import os
 import re
 import sqlite3
 import sys
@@ -74,6 +76,11 @@ for k, f in result["families"].items():
         clk = f["GRBM_GUI_ACTIVE"] / f["duration_ns"] if f.get("GRBM_GUI_ACTIVE") else 2.4
         f["clock_ghz_from_grbm"] = clk if f.get("GRBM_GUI_ACTIVE") else None
         f["mfma_busy_frac_at_2p4ghz"] = f["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * f["duration_ns"] * 2.4)
+# identity of what was profiled (bench.py reports the traffic only for the same library and workload)
+_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ml-stable-diffusion_amd", "lib", "libsdmi355.so")
+with open(_lib, "rb") as _f:
+    result["build_id"] = hashlib.sha256(_f.read()).hexdigest()[:16]
+result.update({"model": "sd21-base", "latent": 64, "prompts_per_gpu": 1, "attention": os.environ.get("SD_ATTN", "ORIGINAL")})
 json.dump(result, open(out_path, "w"), indent=1)
 for k in ("read_bytes_per_step", "write_bytes_per_step", "bytes_per_step"):
     if k in result:
