@@ -124,6 +124,10 @@ typedef struct sd_unet_io {
   void* noise_pred;                  /* UNet out: (B, out_channels, H, W) f32                        */
   void* const* residual_outputs;     /* ControlNet out: N pointers, f32 NCHW                         */
   int32_t flags;
+  const float* step_noise;           /* sd_unet_denoise_loop only, optional (HOST pointer): (n_steps, n_images, C, H, W) f32
+                                      * added to the latents at the end of step i - the fresh noise of the ancestral
+                                      * samplers (EulerAncestralDiscrete, pipeline.py:592-604), already scaled by the
+                                      * step's sigma_up, drawn by the host's seeded generator like the reference does */
 } sd_unet_io;
 
 /* replaces CoreMLModel.__call__ -> MLModel.predict (coreml_model.py:118-120; call site

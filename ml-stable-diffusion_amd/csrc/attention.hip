@@ -39,6 +39,7 @@ struct AttnArgs {
   int heads, d, Sq, Sk;
   int ldq, ldk, ldv, ldo;
   float scale_log2;   // d^-0.5 * log2(e)
+  int q_tiles;        // query tiles per (sample, head): set by launch_one
 };
 
 template <int CTRL>
@@ -121,8 +122,20 @@ __global__ __launch_bounds__(WAVES * 64) void attn_kernel(AttnArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int q_wave0 = (blockIdx.x * WAVES + wave) * QT * 32;
+  // 1-D grid of (sample, head, query tile) with the query tile fastest, XCD-aware: the dispatcher deals consecutive
+  // workgroup ids round-robin over the 8 XCDs, so id -> (id % 8) * (n / 8) + id / 8 hands every XCD a CONTIGUOUS run of
+  // that order - the query tiles of one (sample, head) share its K / V in ONE XCD's L2 instead of pulling all keys and
+  // values of every head through the fabric into all eight
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = ((xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;   // bijective for any nwg
+  }
+  const int qtile = bid % a.q_tiles;
+  const int bh = bid / a.q_tiles;
+  const int b = bh / a.heads, h = bh - b * a.heads;
+  const int q_wave0 = (qtile * WAVES + wave) * QT * 32;
 
   const half_t* qbase = a.q + (size_t)b * a.Sq * a.ldq + (size_t)h * a.d;
   const half_t* kbase = a.k + (size_t)b * a.Sk * a.ldk + (size_t)h * a.d;
@@ -513,8 +526,10 @@ void launch_one(const AttnArgs& a, int B, hipStream_t s) {
   auto k = attn_kernel<DK16, DC32, MODE, WAVES, QT>;
   static DynLdsOnce once;   // per instantiation, per device
   once.set(k, lds);
-  dim3 grid(cdiv(a.Sq, WAVES * QT * 32), a.heads, B);
-  hipLaunchKernelGGL(k, grid, dim3(WAVES * 64), lds, s, a);
+  AttnArgs aa = a;
+  aa.q_tiles = cdiv(a.Sq, WAVES * QT * 32);
+  dim3 grid(aa.q_tiles * a.heads * B);
+  hipLaunchKernelGGL(k, grid, dim3(WAVES * 64), lds, s, aa);
 }
 
 template <int DK16, int DC32>

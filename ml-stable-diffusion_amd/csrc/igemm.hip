@@ -2185,18 +2185,9 @@ Plan choose_plan(const ConvDesc& d, const IgemmArgs& a) {
       p.splitk = hit->splitk;
     }
   }
-  static const bool no_pipe_heur = getenv("SD_NO_PIPE_HEURISTIC") != nullptr;   // A/B switch
-  if (p.tile == 0 && !pinned && !no_pipe_heur && a.ksize == 1 && a.M >= 8192 && gemm_pipe_ok(a) && d.out_mode != kOutHalfT) {
-    // no measured plan and many tokens (batched prompts, larger latents): the software-pipelined GEMM kernel on the 128x64
-    // tile - two workgroups per CU - won 7 of 9 layer shapes at UNet batch 16 by 10-25 % (profiles/r03_gemm_pipe_bench_b16.txt);
-    // GEGLU needs 64 n-columns per wave: 64x128
-    const int c = geglu ? 4 : 2;
-    if (tile_ok(c)) {
-      p.tile = c;
-      p.staging = 6;
-      p.splitk = 1;
-    }
-  }
+  // (measured and dropped, round 3: sending every untuned 1x1 GEMM with M >= 8192 to the software-pipelined kernel's 128x64
+  // tile - 10-25 % faster stand-alone at UNet batch 16 - made the batch-16 step 1.3 % and the batch-4 step 0.6 % SLOWER in
+  // sequence; the pipelined kernel is only used where tools/tune_e2e.py accepted it end to end)
   if (p.tile == 0 && tile_ok(7)) {
     // no measured plan for this shape: the K-split halo kernel with the 4-stage ring won every 3x3 / stride-1 shape that was
     // tuned (SD2.1-base, SDXL-base, SD1.5: tuned_convs.inc); split-K below as for the other kernels

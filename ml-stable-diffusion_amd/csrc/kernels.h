@@ -192,6 +192,8 @@ struct LoopTables {
   const float* temb_tab;
   float* temb_dst;
   int temb_rows, temb_ld, temb_n;
+  // ancestral samplers: [n_steps][Bimg * CHW] noise (already scaled by sigma_up) added to the latents after step `step`, or null
+  const float* noise_tab = nullptr;
 };
 // latents fp32 NCHW [Bimg][4][H][W] -> UNet sample fp16 NHWC [cfg*Bimg][H][W][4], timestep buffer
 void launch_loop_prep(const float* latents, half_t* sample, float* tbuf, LoopTables t, int Bimg, int C, int H,

@@ -233,7 +233,7 @@ __global__ void loop_prep_kernel(const float* __restrict__ latents, half_t* __re
 
 // pipeline.py:539, 561-569.  noise_pred fp32 NCHW [cfg*Bimg][CHW]; rows [0,Bimg) uncond, [Bimg,2Bimg) text.
 // Generic linear-multistep update on the device (DDIM / PLMS / DPM-Solver++ 2M are all instances):
-//   eps = u + g*(c-u);  m = a*x + b*eps;  x <- cx*x + cm*m + sum_j ch[j]*hist[j];  hist <- [m, hist[0..]]
+//   eps = u + g*(c-u);  m = a*x + b*eps;  x <- cx*x + cm*m + sum_j ch[j]*hist[j] [+ noise_tab[step]];  hist <- [m, hist[0..]]
 // coef row: [cx, cm, ch0, ch1, ch2, a, b, flags]; flags != 0: m is NOT pushed into the history (the second
 // evaluation of the PLMS warm-up, Scheduler.swift:228-236).  The workgroup that arrives last at the ticket
 // advances the device step counter (every workgroup read it before arriving), so the step needs no second
@@ -263,6 +263,7 @@ __global__ __launch_bounds__(256) void cfg_sched_step_kernel(const float* __rest
       if (push && j + 1 < hist) eps_hist[(size_t)(j + 1) * total + idx] = old;
     }
     if (push && hist > 0) eps_hist[idx] = m;
+    if (t.noise_tab) x += t.noise_tab[(size_t)step * total + idx];   // ancestral step: + sigma_up * fresh noise
     latents[idx] = x;
   }
   __syncthreads();

@@ -1423,6 +1423,16 @@ void UNet::denoise_loop(const sd_unet_io& io, float* latents, int n_images, int 
   }
   LoopTables tab{tab_timesteps_, tab_coef_, step_, sample_scale ? tab_scale_ : nullptr,
                  reinterpret_cast<unsigned*>(step_ + 1), hoist ? temb_tab_ : nullptr, temb_all_, cfg_.batch, kTembCap, temb_used_};
+  if (io.step_noise) {   // ancestral samplers: the host's pre-drawn, pre-scaled noise of every step
+    const size_t need = (size_t)n_steps * lat_n;
+    if (noise_cap_ < need) {
+      noise_tab_ = arena_.alloc_n<float>(need);
+      noise_cap_ = need;
+      if (loop_graph_) { (void)hipGraphExecDestroy(loop_graph_); loop_graph_ = nullptr; }   // the address is baked in
+    }
+    SD_HIP(hipMemcpyAsync(noise_tab_, io.step_noise, need * sizeof(float), hipMemcpyHostToDevice, stream_));
+    tab.noise_tab = noise_tab_;
+  }
   auto step_ops = [&]() {
     launch_loop_prep(latents_, x_in_.p, tbuf_, tab, n_images, C, H, W, cfgmul, stream_);
     run_attached();
@@ -1431,7 +1441,7 @@ void UNet::denoise_loop(const sd_unet_io& io, float* latents, int n_images, int 
     launch_cfg_sched_step(noise_pred_, latents_, eps_hist_, tab, guidance, n_images, C * H * W, cfgmul, history,
                           stream_);
   };
-  const int key = n_images * 64 + (hoist ? 32 : 0) + history * 4 + (cfgmul - 1) * 2 + (sample_scale ? 1 : 0);
+  const int key = n_images * 128 + (io.step_noise ? 64 : 0) + (hoist ? 32 : 0) + history * 4 + (cfgmul - 1) * 2 + (sample_scale ? 1 : 0);
   std::unique_ptr<EventList> ev;
   if (ms_per_step) ev = std::make_unique<EventList>((size_t)n_steps + 1);
   if (cfg_.use_graph) {

@@ -201,6 +201,8 @@ class UNet {
   float* tab_scale_ = nullptr;
   int* step_ = nullptr;
   int tab_cap_ = 0;
+  float* noise_tab_ = nullptr;      // ancestral samplers: per-step noise of the current call
+  size_t noise_cap_ = 0;            // in floats
 };
 
 }  // namespace sd

@@ -49,6 +49,7 @@ class UNetIO(C.Structure):
         ("time_ids", C.c_void_p), ("text_embeds", C.c_void_p), ("controlnet_cond", C.c_void_p),
         ("additional_residuals", C.POINTER(C.c_void_p)), ("num_additional_residuals", C.c_int32),
         ("noise_pred", C.c_void_p), ("residual_outputs", C.POINTER(C.c_void_p)), ("flags", C.c_int32),
+        ("step_noise", C.c_void_p),
     ]
 
 

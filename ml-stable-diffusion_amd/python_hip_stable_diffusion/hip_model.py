@@ -288,13 +288,14 @@ class HipModel:
         return ms.value
 
     def denoise_loop(self, latents, timesteps, coef, guidance_scale, history=0, sample_scale=None, history_state=None,
-                     **kwargs):
+                     step_noise=None, **kwargs):
         """Device-resident pipeline.py:500-573.  latents (n_img, C, H, W) float32 -> final latents,
         per-step HIP-event milliseconds.  ``kwargs`` are the loop-invariant model inputs
         (encoder_hidden_states, SDXL time_ids / text_embeds), validated like ``__call__`` validates them
         (coreml_model.py:97-116).  ``history_state`` (history, n_img, C, H, W) float32 carries the
         scheduler's multistep history in and out (updated in place) when a loop continues on another
-        handle (SDXL base -> refiner)."""
+        handle (SDXL base -> refiner).  ``step_noise`` (len(timesteps), n_img, C, H, W) float32: added to the latents at
+        the end of step i - the ancestral samplers' fresh noise, already scaled by sigma_up."""
         if self.kind != "unet":
             raise ValueError("denoise_loop needs a UNet handle")
         loop_inputs = {k: v for k, v in self.expected_inputs.items()
@@ -339,6 +340,12 @@ class HipModel:
             hs = history_state
         keep = []
         io = self._io(kwargs, keep)
+        if step_noise is not None:
+            sn = np.ascontiguousarray(step_noise, dtype=np.float32)
+            if sn.shape != (len(ts),) + lat.shape:
+                raise ValueError(f"step_noise must have shape {(len(ts),) + lat.shape}, got {sn.shape}")
+            keep.append(sn)
+            io.step_noise = sn.ctypes.data
         ms = np.zeros(len(ts), np.float32)
         _lib.check(_lib.lib().sd_unet_denoise_loop(self._h, C.byref(io), _lib.fptr(lat), lat.shape[0], len(ts),
                                                    _lib.fptr(ts), _lib.fptr(cf), _lib.fptr(sc), int(history),

@@ -305,11 +305,13 @@ class HipStableDiffusionPipeline:
             scale = self.scheduler.sample_scale() if hasattr(self.scheduler, "sample_scale") else None
             lat = latents.astype(np.float32)
             state = np.zeros((hist,) + lat.shape, np.float32) if (hist and len(stages) > 1) else None
+            noise = self.scheduler.step_noise(lat.shape) if hasattr(self.scheduler, "step_noise") else None   # ancestral samplers
             step_ms = []
             for model, emb, kw, first, last in stages:
                 lat, ms = model.denoise_loop(lat, ts[first:last], coef[first:last], guidance_scale, history=hist,
                                              sample_scale=None if scale is None else scale[first:last],
-                                             history_state=state, encoder_hidden_states=emb.astype(np.float16), **kw)
+                                             history_state=state, step_noise=None if noise is None else noise[first:last],
+                                             encoder_hidden_states=emb.astype(np.float16), **kw)
                 step_ms.append(ms)
             latents, step_ms = lat, np.concatenate(step_ms)
         else:

@@ -514,9 +514,11 @@ class LMSDiscreteScheduler(_SigmaSpace):
 
 
 class EulerAncestralDiscreteScheduler(_SigmaSpace):
-    """Stochastic: every step adds fresh noise, so the loop is stepped on the host (no
-    ``device_tables``).  diffusers draws that noise from torch's global generator; here it comes from a
-    numpy legacy stream seeded by ``seed`` so that a run is reproducible."""
+    """Stochastic: every step adds fresh noise.  diffusers draws that noise from torch's global generator; here it comes
+    from a numpy legacy stream seeded by ``seed`` so that a run is reproducible.  On the device loop the deterministic
+    half of the step is a coefficient row (Euler to sigma_down) and the noise of ALL steps is drawn up front, in step
+    order from the same stream, scaled by sigma_up and handed over as ``step_noise`` (``sd_unet_io.step_noise``): the
+    host-stepped and the device-resident loop consume identical numbers."""
 
     NAME = "EulerAncestralDiscreteScheduler"
     EXTRA_KEYS = ("seed",)
@@ -525,11 +527,27 @@ class EulerAncestralDiscreteScheduler(_SigmaSpace):
         super().__init__(**kwargs)
         self._rng = np.random.RandomState(seed)
 
-    def step(self, model_output, timestep, sample, **kwargs):
-        i = self._index(timestep)
+    def _up_down(self, i):
         s_from, s_to = float(self.sigmas[i]), float(self.sigmas[i + 1])
         s_up = (s_to ** 2 * (s_from ** 2 - s_to ** 2) / s_from ** 2) ** 0.5
-        s_down = (s_to ** 2 - s_up ** 2) ** 0.5
+        return s_from, s_up, (s_to ** 2 - s_up ** 2) ** 0.5
+
+    def device_tables(self):
+        rows = []
+        for i in range(len(self.timesteps)):
+            s_from, _, s_down = self._up_down(i)
+            a, b = self._deriv_ab(self.sigmas[i])
+            rows.append(_row(1.0, s_down - s_from, a=a, b=b))
+        return self.timesteps, np.stack(rows), 0
+
+    def step_noise(self, shape):
+        """(n_steps, *shape) float32: sigma_up[i] * randn(*shape), one draw per step in step order."""
+        return np.stack([np.float32(self._up_down(i)[1]) * self._rng.randn(*shape).astype(np.float32)
+                         for i in range(len(self.timesteps))])
+
+    def step(self, model_output, timestep, sample, **kwargs):
+        i = self._index(timestep)
+        s_from, s_up, s_down = self._up_down(i)
         x = np.asarray(sample, np.float32)
         x = x + np.float32(s_down - s_from) * self._derivative(i, model_output, sample)
         x = x + np.float32(s_up) * self._rng.randn(*x.shape).astype(np.float32)

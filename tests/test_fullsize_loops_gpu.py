@@ -82,6 +82,6 @@ def test_sdxl_base_to_refiner_full_size_loop_matches_reference_modules():
     assert p_swap >= GATE_XL_SWAP and p_final >= GATE_XL_FINAL, (p_swap, p_final)
 
 
-# gates = measured - 6 dB (first GPU run of round 3: see profiles/r03_fullsize_loops.txt)
-GATE_CN10, GATE_CN20 = 35.0, 35.0
-GATE_XL_SWAP, GATE_XL_FINAL = 35.0, 35.0
+# gates = measured - 6 dB (first GPU run of round 3: profiles/r03_psnr_measured.tsv)
+GATE_CN10, GATE_CN20 = 59.5, 59.5        # measured 65.9 / 65.9 dB
+GATE_XL_SWAP, GATE_XL_FINAL = 61.0, 61.0  # measured 67.2 / 67.1 dB

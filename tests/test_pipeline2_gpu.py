@@ -118,7 +118,7 @@ def test_controlnet_residuals_stay_on_the_device_inside_the_loop():
     lat0 = np.random.randn(1, 4, hw, hw).astype(np.float16)
     want = scheduler_ref.denoise_loop(oracle_step, scheduler_ref.DDIM(), lat0.astype(np.float32), emb, steps, gs)
     p = psnr.compute_psnr(fused.images, want)
-    assert p >= 35.0, f"device-resident ControlNet loop: PSNR {p:.1f} dB vs the oracle loop"
+    assert p >= 52.0, f"device-resident ControlNet loop: PSNR {p:.1f} dB vs the oracle loop"   # measured 58.2 (r3)
     # one forward through the boundary with the ControlNets attached: no residual inputs needed
     unet.attach_controlnets(cns)
     x = np.concatenate([lat0, lat0]).astype(np.float16)
@@ -202,5 +202,5 @@ def test_sdxl_base_to_refiner_swap_with_scheduler_history_carried_over():
         u, c = np.split(eps, 2)
         lat = sch.step((u + gs * (c - u)).astype(np.float32), int(t), lat).astype(np.float32)
     p = psnr.compute_psnr(fused.images, lat)
-    assert p >= 35.0, f"base -> refiner loop: PSNR {p:.1f} dB vs the oracle loop"
+    assert p >= 59.0, f"base -> refiner loop: PSNR {p:.1f} dB vs the oracle loop"   # measured 65.0 (r3)
     base.close(), refiner.close()

@@ -68,8 +68,8 @@ def test_prompt_to_image_matches_oracle_pipeline():
     lat = scheduler_ref.denoise_loop(unet, scheduler_ref.DDIM(), lat0.astype(np.float32), emb, steps, g)
     img = vae_ref.vae_decode(vsd, vcfg, torch.from_numpy(lat / 0.18215)).numpy()
     img = np.clip(img / 2 + 0.5, 0, 1).transpose(0, 2, 3, 1)               # pipeline.py:317-318
-    assert psnr.compute_psnr(out.latents, lat) >= 35.0
-    assert psnr.compute_psnr(out.images, img) >= 35.0                      # tests/test_stable_diffusion.py:33
+    assert psnr.compute_psnr(out.latents, lat) >= 51.0                     # measured 57.5 (r3): gate = measured - 6
+    assert psnr.compute_psnr(out.images, img) >= 70.0                      # measured 76.2 (reference floor 35 dB, tests/test_stable_diffusion.py:33)
 
 
 def test_callback_path_steps_through_the_boundary_and_agrees_with_device_loop():

@@ -46,7 +46,7 @@ def test_sd21_base_20_step_ddim_loop_matches_reference_loop():
         lat, ms = model.denoise_loop(lat0.astype(np.float32), ts, coef, gs, history=hist, encoder_hidden_states=ehs)
         p = psnr.compute_psnr(lat, g["final"])
         report[impl] = p
-        assert p >= 35.0, f"{impl}: 20-step final latents PSNR {p:.1f} dB vs the reference loop"
+        assert p >= 60.0, f"{impl}: 20-step final latents PSNR {p:.1f} dB vs the reference loop"   # measured 66.4-67.3 (r3): gate = measured - 6
     # host-stepped loop through the boundary, with a per-step PSNR trace against the reference trajectory
     model.set_attention_implementation("ORIGINAL")
     trace = []
@@ -57,7 +57,7 @@ def test_sd21_base_20_step_ddim_loop_matches_reference_loop():
     p_host = psnr.compute_psnr(host, g["final"])
     print("loop20 PSNR vs reference: device loop", {k: round(v, 1) for k, v in report.items()},
           "host-stepped", round(p_host, 1), "per-step", [round(v, 1) for v in trace])
-    assert p_host >= 35.0 and min(trace) >= 35.0
+    assert p_host >= 60.0 and min(trace) >= 58.0                             # measured 66.4 / 64.8 (r3)
     assert psnr.compute_psnr(host, lat) >= 45.0                               # the two HIP paths agree with each other
     model.close()
 
@@ -221,7 +221,7 @@ def test_vae_decoder_at_the_benchmarked_64x64_latents_matches_oracle():
     ref = vae_ref.vae_decode(sd, cfg, torch.from_numpy(z.astype(np.float32))).numpy()
     assert out.shape == ref.shape == (1, 3, 512, 512)
     p = psnr.compute_psnr(out, ref)
-    assert p >= 45.0, f"VAE decoder at 64x64 latents: PSNR {p:.1f} dB"
+    assert p >= 73.0, f"VAE decoder at 64x64 latents: PSNR {p:.1f} dB"   # measured 79.4 (r3)
     vae.close()
 
 
@@ -261,7 +261,7 @@ def test_every_deterministic_scheduler_runs_the_fused_device_loop(name, oracle):
                                  sample_scale=sch.sample_scale(), encoder_hidden_states=ehs)
     assert len(ms) == len(ts) == (n + 1 if name == "PNDM" else n)
     p = psnr.compute_psnr(got, want)
-    assert p >= 35.0, f"{name}: device loop PSNR {p:.1f} dB vs the oracle loop"
+    assert p >= 52.0, f"{name}: device loop PSNR {p:.1f} dB vs the oracle loop"   # measured 58.6-59.2 (r3)
     # the host-stepped path of the same scheduler object agrees with the device tables
     host = scheduler_ref.denoise_loop(lambda x, t, e: model(sample=x, timestep=t, encoder_hidden_states=e)["noise_pred"],
                                       oracle(), lat0, ehs, n, gs)
@@ -355,7 +355,7 @@ def test_vae_encoder_matches_oracle(name, hw):
     ref = vae_ref.vae_encode(sd, cfg, torch.from_numpy(x.astype(np.float32))).numpy()
     assert out.shape == ref.shape == (1, 8, hw // 8, hw // 8)
     p = psnr.compute_psnr(out, ref)
-    assert p >= 45.0, f"VAE encoder {name}: PSNR {p:.1f} dB"
+    assert p >= 67.0, f"VAE encoder {name}: PSNR {p:.1f} dB"   # measured 73.3 / 74.4 (r3)
     again = enc(x=x.astype(np.float16))["latent"]
     assert np.array_equal(out, again)
     with pytest.raises(TypeError):

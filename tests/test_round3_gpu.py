@@ -190,3 +190,43 @@ def test_pipelined_gemm_groupnorm_statistics(tile):
     y, z = conv_gn_ref(x, w, bias, res, gw, gb, 32, 1e-5, True)
     close(conv_out, y, f"conv tile {tile}")
     close(out, z, f"conv + GroupNorm tile {tile}")
+
+
+def test_euler_ancestral_runs_inside_the_device_loop():
+    """EulerAncestralDiscrete (pipeline.py:592-604): the deterministic half of the step as a coefficient row, the fresh noise
+    of every step pre-drawn from the seeded stream and handed over scaled by sigma_up (sd_unet_io.step_noise): the fused
+    device loop must agree with the host-stepped loop that consumes the same stream one step() at a time."""
+    from oracle import unet_ref, weights
+    from python_hip_stable_diffusion import HipModel, schedulers
+    cfg = unet_ref.CONFIGS["mini"]
+    sd16 = weights.make_state_dict(unet_ref.unet_param_shapes(cfg), seed=21, dtype=np.float16)
+    model = HipModel(cfg, sd16, batch=2, attention_implementation="SPLIT_EINSUM")
+    hw = cfg["sample_size"]
+    lat0 = weights.seeded_normal((1, 4, hw, hw), 93)
+    ehs = weights.seeded_normal((2, cfg["cross_attention_dim"], 1, 77), 94).astype(np.float16)
+    n, gs = 6, 7.5
+    dev = schedulers.EulerAncestralDiscreteScheduler(seed=5)
+    dev.set_timesteps(n)
+    ts, coef, hist = dev.device_tables()
+    got, ms = model.denoise_loop(lat0 * np.float32(dev.init_noise_sigma), ts, coef, gs, history=hist, sample_scale=dev.sample_scale(),
+                                 step_noise=dev.step_noise(lat0.shape), encoder_hidden_states=ehs)
+    assert len(ms) == n
+    host = schedulers.EulerAncestralDiscreteScheduler(seed=5)
+    host.set_timesteps(n)
+    x = lat0 * np.float32(host.init_noise_sigma)
+    for t in host.timesteps:
+        xin = np.asarray(host.scale_model_input(np.concatenate([x, x]), t)).astype(np.float16)
+        eps = model(sample=xin, timestep=np.array([t, t], np.float16), encoder_hidden_states=ehs)["noise_pred"]
+        u, c = np.split(eps, 2)
+        x = host.step(u + gs * (c - u), t, x).prev_sample
+    p = psnr.compute_psnr(got, x)
+    assert p >= 50.0, f"ancestral device loop vs host-stepped loop: PSNR {p:.1f} dB"
+    # a second call with another seed gives another sample; without step_noise the loop is plain Euler to sigma_down
+    other = schedulers.EulerAncestralDiscreteScheduler(seed=6)
+    other.set_timesteps(n)
+    got2, _ = model.denoise_loop(lat0 * np.float32(dev.init_noise_sigma), ts, coef, gs, history=hist, sample_scale=dev.sample_scale(),
+                                 step_noise=other.step_noise(lat0.shape), encoder_hidden_states=ehs)
+    assert psnr.compute_psnr(got2, got) < 30.0
+    with pytest.raises(ValueError):
+        model.denoise_loop(lat0, ts, coef, gs, history=hist, step_noise=np.zeros((n - 1,) + lat0.shape, np.float32), encoder_hidden_states=ehs)
+    model.close()

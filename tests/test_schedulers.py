@@ -214,8 +214,24 @@ def test_schedule_shapes_of_the_reference_map():
     e.set_timesteps(20)
     assert e.init_noise_sigma > 10 and e.sigmas[-1] == 0 and len(e.sample_scale()) == 20
     a = schedulers.EulerAncestralDiscreteScheduler(seed=3)
-    assert not hasattr(a, "device_tables")                                              # stochastic -> host loop
     x0 = np.random.RandomState(5).randn(1, 4, 8, 8).astype(np.float32)
     assert np.array_equal(host_loop(a, x0, 5), host_loop(schedulers.EulerAncestralDiscreteScheduler(seed=3), x0, 5))
+    # stochastic, still device-resident: coefficient rows for the deterministic half + the pre-drawn, sigma_up-scaled noise of
+    # every step (sd_unet_io.step_noise) reproduce step() exactly when the same stream is consumed in step order
+    host, dev = schedulers.EulerAncestralDiscreteScheduler(seed=9), schedulers.EulerAncestralDiscreteScheduler(seed=9)
+    for s_ in (host, dev):
+        s_.set_timesteps(6)
+    ts, coef, hist = dev.device_tables()
+    noise = dev.step_noise(x0.shape)
+    assert hist == 0 and coef.shape == (6, 8) and noise.shape == (6,) + x0.shape
+    x = x0 * np.float32(host.init_noise_sigma)
+    y = x.copy()
+    rs = np.random.RandomState(11)
+    for i, t in enumerate(ts):
+        eps = rs.randn(*x0.shape).astype(np.float32)
+        x = host.step(eps, t, x).prev_sample
+        cx, cm, _, _, _, ma, mb, _ = coef[i]
+        y = cx * y + cm * (ma * y + mb * eps) + noise[i]
+    np.testing.assert_allclose(y, x, rtol=2e-5, atol=2e-5)
     with pytest.raises(NotImplementedError):
         schedulers.DDIMScheduler().step(x0, 1, x0, eta=0.5)

@@ -79,7 +79,10 @@ def write_checkpoint_dir(root):
         json.dump({k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()}, open(os.path.join(root, sub, "config.json"), "w"))
         parts[sub] = weights.to_torch({k: v.astype(np.float32) for k, v in sd16.items()})
     os.makedirs(os.path.join(root, "scheduler"))
-    json.dump({"_class_name": "PNDMScheduler", "beta_schedule": "scaled_linear", "skip_prk_steps": True, "steps_offset": 1},
+    # what an SD checkpoint's scheduler/scheduler_config.json holds; get_hip_pipe builds the scheduler from it
+    # (pipeline.py:738-741), missing keys take the diffusers class defaults (beta 1e-4 .. 0.02), so the betas are spelled out
+    json.dump({"_class_name": "PNDMScheduler", "beta_schedule": "scaled_linear", "beta_start": 0.00085, "beta_end": 0.012,
+               "num_train_timesteps": 1000, "skip_prk_steps": True, "steps_offset": 1, "set_alpha_to_one": False},
               open(os.path.join(root, "scheduler", "scheduler_config.json"), "w"))
     alpha = _bytes_to_unicode()
     vocab = {}

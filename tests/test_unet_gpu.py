@@ -153,7 +153,7 @@ def test_device_resident_denoise_loop_matches_oracle_loop():
                                  encoder_hidden_states=ehs)
     assert lat.shape == ref.shape and len(ms) == n_steps and (ms > 0).all()
     p = psnr.compute_psnr(lat, ref)
-    assert p >= 35.0, f"final latents PSNR {p:.1f} dB"
+    assert p >= 51.0, f"final latents PSNR {p:.1f} dB"   # measured 57.7 (r3): gate = measured - 6
     # and the host-stepped path through the boundary gives the same trajectory
     host = scheduler_ref.denoise_loop(lambda x, t, e: model(sample=x, timestep=t, encoder_hidden_states=e)["noise_pred"],
                                       scheduler_ref.DDIM(), latents0.astype(np.float32), ehs, n_steps, g)
@@ -194,7 +194,7 @@ def test_vae_decoder_matches_oracle(name, hw):
     ref = vae_ref.vae_decode(sd, cfg, torch.from_numpy(z.astype(np.float32))).numpy()
     assert out.shape == ref.shape == (1, 3, hw * 8, hw * 8)
     p = psnr.compute_psnr(out, ref)
-    assert p >= 50.0, f"VAE decoder {name}: PSNR {p:.1f} dB"
+    assert p >= 68.0, f"VAE decoder {name}: PSNR {p:.1f} dB"   # measured 74.4 / 79.6 (r3)
     with pytest.raises(TypeError):
         vae(z=z.astype(np.float32))
     vae.close()

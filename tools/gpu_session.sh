@@ -27,9 +27,10 @@ for step in "$@"; do
       timeout 900 python bench.py > $OUT/bench_$TAG.log 2> $OUT/bench_$TAG.err; note "bench rc=$?"
       tail -n 1 $OUT/bench_$TAG.log | cut -c1-600 ;;
     ab:*)
-      kv=${step#ab:}
-      r=$(env ${kv//,/ } timeout 300 python bench.py --cpu-steps 0 --repeats 5 2>/dev/null | tail -n 1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])" 2>&1)
-      note "ab[$kv] ms/step, it/s: $r" ;;
+      kv=${step#ab:}; fl=""
+      case "$kv" in *@*) fl=${kv#*@}; kv=${kv%%@*} ;; esac      # "ab:ENV=VAL@--prompts-per-gpu 8": extra bench flags behind @
+      r=$(env ${kv//,/ } timeout 300 python bench.py --cpu-steps 0 --repeats 5 $fl 2>/dev/null | tail -n 1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])" 2>&1)
+      note "ab[$kv $fl] ms/step, it/s: $r" ;;
     profile)
       timeout 300 python tools/op_profile.py $OUT/op_profile_$TAG.json 2 ORIGINAL > $OUT/op_profile_$TAG.txt 2>&1; note "profile rc=$?"; head -n 28 $OUT/op_profile_$TAG.txt | cut -c1-150 ;;
     trace)
