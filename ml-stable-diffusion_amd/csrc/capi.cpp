@@ -216,7 +216,7 @@ int sd_unet_denoise_loop(sd_unet* u, const sd_unet_io* io, float* latents, int n
 int sd_tune_set_candidate(int tile, int staging, int splitk) {
   return guarded([&] {
     require_tune_env();
-    SD_REQUIRE(tile >= 0 && tile <= 8 && staging >= 0 && staging <= 8 && splitk >= 0 && splitk <= 64, kInvalidArgument,
+    SD_REQUIRE(tile >= 0 && tile <= 9 && staging >= 0 && staging <= 8 && splitk >= 0 && splitk <= 64, kInvalidArgument,
                "tune candidate (tile %d, staging %d, splitk %d)", tile, staging, splitk);
     conv_tune_set_candidate(tile, staging, splitk);
   });

@@ -1730,6 +1730,208 @@ __global__ __launch_bounds__(256) void gemm_pipe_kernel(IgemmArgs a) {
                                                                     n_blk, wave, split, temb_uniform, resv, use_resv);
 }
 
+// ---------------------------------------------------------------------------------------------
+// 256 x 256 tile of the software-pipelined 1x1 GEMM (plan tile 9): the tile that passes the LDS-fill wall.
+// Every byte DMA'd into LDS feeds 128 FLOP here (64 on the 128 x 128 tile), and the chip-wide L2 -> LDS fill rate
+// (6.5-9 TB/s measured) is what bounds the GEMMs: SDXL's 1280 -> 10240 GEGLU projection at 1152 tokens sits at exactly
+// 64 FLOP/B x 6.7 TB/s = 427 TFLOP/s on the 128-wide tiles (profiles/r03_op_profile_sdxl.txt).
+// Four waves as 2 x 2, a wave owns 128 x 128 outputs: 256 accumulator registers (the whole AGPR file), fragments
+// ping-pong per 16-deep k sub-step (8 x 16 B in, 16 MFMAs out), two LDS stages of 64 KB: the DMA of step s+1 is issued
+// right behind the barrier of step s into the stage whose last reads that barrier has just retired.  Epilogue: the shared
+// tile_epilogue (the staged 256 x 264 tile re-uses the K-loop buffers; the per-column constants live behind it).
+// ---------------------------------------------------------------------------------------------
+constexpr size_t kBigStagedBytes = (size_t)256 * (256 + 8) * sizeof(half_t) + 16 + (kGnScratchFloats + 2 * 256) * sizeof(float);
+constexpr size_t kBigLoopBytes = (size_t)2 * (256 + 256) * BK * sizeof(half_t);
+constexpr size_t kBigConstOff = ((kBigStagedBytes > kBigLoopBytes ? kBigStagedBytes : kBigLoopBytes) + 255) & ~(size_t)255;
+constexpr size_t kBigLdsBytes = kBigConstOff + 2 * 256 * sizeof(float);
+static_assert(kBigLdsBytes <= 160 * 1024, "LDS");
+
+template <bool LNF>
+__global__ __launch_bounds__(256) void gemm_big_kernel(IgemmArgs a) {
+  constexpr int BM = 256, BN = 256, WGN = 2, TM = 4, TN = 4, XR = BM / 32, WR = BN / 32, ROWB = BK * 2, KK = BK / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Xs = smem;                                   // [2][BM][BK] halves
+  char* const Ws = smem + 2 * BM * ROWB;                   // [2][BN][BK]
+  float* sconst = reinterpret_cast<float*>(smem + kBigConstOff);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
+  const int nwg = nbm * nbn;
+  int bid = blockIdx.x;
+  {
+    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    bid = base + idx;
+  }
+  const int bn_idx = a.n_fast ? bid % nbn : bid / nbm, bm_idx = a.n_fast ? bid / nbn : bid % nbm;
+  const int m_blk = bm_idx * BM, n_blk = bn_idx * BN;
+  const int split = blockIdx.y;
+  const int kt_begin = split * a.nk_per_split;
+  int kt_end = kt_begin + a.nk_per_split;
+  if (kt_end > a.nk_total) kt_end = a.nk_total;
+  const int T = kt_end - kt_begin;
+
+  constexpr unsigned kOob = 0x80000000u;
+  const int pchunk = tid & 7, lrow = tid >> 3;
+  const unsigned lchunk = (unsigned)(pchunk ^ ((lrow >> 1) & 7)) * 16u;
+  unsigned xoff0[XR], xoff1[XR], woff[WR];
+#pragma unroll
+  for (int i = 0; i < XR; ++i) {
+    const int m = m_blk + lrow + 32 * i;
+    xoff0[i] = m < a.M ? (unsigned)m * (unsigned)a.C0 * 2u + lchunk : kOob;
+    xoff1[i] = m < a.M ? (unsigned)m * (unsigned)a.C1 * 2u + lchunk : kOob;
+  }
+#pragma unroll
+  for (int i = 0; i < WR; ++i) {
+    int n = n_blk + lrow + 32 * i;
+    if (n > a.N - 1) n = a.N - 1;
+    woff[i] = (unsigned)n * (unsigned)a.K * 2u + lchunk;
+  }
+  const unsigned x0_bytes = (unsigned)((size_t)a.M * a.C0 * 2), x1_bytes = (unsigned)((size_t)a.M * a.C1 * 2);
+  const unsigned w_bytes = (unsigned)((size_t)a.N * a.K * 2);
+  // DMA of one K tile, issued in four groups of (2 activation + 2 weight) pieces so that they spread over the step's MFMAs;
+  // tiles past the end of K go through zero-sized resources: nothing is fetched, the loop body stays one basic block
+  struct TileSrc {
+    __amdgpu_buffer_rsrc_t rs_x, rs_w;
+    int xs_off, w_off;
+    bool second;
+  };
+  auto tile_src = [&](int kt) {
+    const bool live = kt < kt_end;
+    const int k = kt * BK;
+    TileSrc t;
+    t.second = k >= a.C0;
+    t.rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(t.second ? a.x1 : a.x0), 0,
+                                               (int)(live ? (t.second ? x1_bytes : x0_bytes) : 0u), 0x00020000);
+    t.rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.w), 0, (int)(live ? w_bytes : 0u), 0x00020000);
+    t.xs_off = (t.second ? k - a.C0 : k) * 2;
+    t.w_off = k * 2;
+    return t;
+  };
+  auto issue_group = [&](const TileSrc& t, int stage, int g) {
+    char* xs = Xs + stage * (BM * ROWB) + wave * 1024;
+    char* ws = Ws + stage * (BN * ROWB) + wave * 1024;
+#pragma unroll
+    for (int i = 2 * g; i < 2 * g + 2; ++i) dma16_to_lds(t.rs_x, xs + i * 4096, t.second ? xoff1[i] : xoff0[i], t.xs_off);
+#pragma unroll
+    for (int i = 2 * g; i < 2 * g + 2; ++i) dma16_to_lds(t.rs_w, ws + i * 4096, woff[i], t.w_off);
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float ln_s1[TM] = {}, ln_s2[TM] = {};
+
+  const int frow = lane & 31, hi = lane >> 5;
+  const int fsw = (frow >> 1) & 7;
+  int foff[KK];
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) foff[kk] = ((kk * 2 + hi) ^ fsw) * 16;
+  const int xrow = (wm * TM * 32 + frow) * ROWB, wrow = (wn * TN * 32 + frow) * ROWB;
+
+  const bool temb_uniform = a.temb != nullptr && (a.HoWo % BM) == 0;
+  float const_b = 0.f, const_t = 0.f, const_c = 0.f;
+  if (a.splitk == 1 && tid < BN) {
+    const int n = n_blk + tid;
+    if (n < a.N) {
+      if (a.bias) const_b = a.bias[n];
+      if (temb_uniform) const_t = a.temb[(size_t)(m_blk / a.HoWo) * a.temb_stride + n];
+      if constexpr (LNF) const_c = a.ln_colsum[n];
+    }
+  }
+
+  struct Frag {
+    half8 x[TM];
+    half8 w[TN];
+  };
+  auto read_kk = [&](Frag& f, const char* xs, const char* ws, int kk) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) f.x[i] = *reinterpret_cast<const half8*>(xs + i * 32 * ROWB + foff[kk]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) f.w[j] = *reinterpret_cast<const half8*>(ws + j * 32 * ROWB + foff[kk]);
+  };
+  auto mfma_kk = [&](const Frag& f) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.w[j], f.x[i], acc[i][j], 0, 0, 0);
+    if constexpr (LNF) {
+      const half2v one2 = {(half_t)1.f, (half_t)1.f};
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const half2v p2 = {f.x[i][2 * e], f.x[i][2 * e + 1]};
+          ln_s2[i] = __builtin_amdgcn_fdot2(p2, p2, ln_s2[i], false);
+          ln_s1[i] = __builtin_amdgcn_fdot2(p2, one2, ln_s1[i], false);
+        }
+    }
+  };
+
+  {
+    const TileSrc t0 = tile_src(kt_begin);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) issue_group(t0, 0, g);
+  }
+  Frag f0, f1;
+  // one phase = the 16 MFMAs of k sub-step kk on `cur`, with the 8 fragment reads of sub-step kk+1 (into `nxt`) and a quarter
+  // of the next tile's DMA issued between them; sched_barrier fences keep a phase's reads from drifting into another phase
+  auto phase = [&](const Frag& cur, Frag& nxt, const char* xs, const char* ws, int kk_next, const TileSrc& tn, int nstage, int g) {
+    if (kk_next < KK) read_kk(nxt, xs, ws, kk_next);
+    issue_group(tn, nstage, g);
+    mfma_kk(cur);
+    if constexpr (!LNF) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int st = 0; st < T; ++st) {
+    const int stage = st & 1;
+    wait_vmcnt_barrier<0>();                                // tile st has landed; every wave is done with the other stage
+    const TileSrc tn = tile_src(kt_begin + st + 1);         // lands during this step's 64 MFMAs per wave
+    const char* xs = Xs + stage * (BM * ROWB) + xrow;
+    const char* ws = Ws + stage * (BN * ROWB) + wrow;
+    read_kk(f0, xs, ws, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    phase(f0, f1, xs, ws, 1, tn, stage ^ 1, 0);
+    phase(f1, f0, xs, ws, 2, tn, stage ^ 1, 1);
+    phase(f0, f1, xs, ws, 3, tn, stage ^ 1, 2);
+    phase(f1, f0, xs, ws, KK, tn, stage ^ 1, 3);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the zero-sized tail DMA too: the LDS is about to be re-used
+
+  float ln_a[TM] = {}, ln_b[TM] = {};
+  if constexpr (LNF) {
+    const float inv_k = 1.0f / (float)a.K;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const float s1 = xor32_sum(ln_s1[i]), s2 = xor32_sum(ln_s2[i]);
+      const float mean = s1 * inv_k;
+      const float var = fmaxf(s2 * inv_k - mean * mean, 0.f);
+      ln_a[i] = rsqrtf(var + a.ln_eps);
+      ln_b[i] = -ln_a[i] * mean;
+    }
+  }
+  half8 resv[1];
+  tile_epilogue<BM, BN, 2, WGN, TM, TN, LNF, 0>(a, acc, ln_a, ln_b, smem, sconst, const_b, const_t, const_c, m_blk, n_blk, wave, split,
+                                                temb_uniform, resv, false);
+}
+
 // split-K combine + the same epilogue (bias, temb broadcast, residual) -> fp16
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmArgs a) {
   const size_t total4 = (size_t)a.M * a.N / 4;
@@ -2068,6 +2270,7 @@ void tile_dims(int tile, int& bm, int& bn) {
     case 2: bm = 128; bn = 64; break;
     case 3: bm = 64; bn = 64; break;
     case 8: bm = 256; bn = 128; break;   // software-pipelined 1x1 GEMM only (gemm_pipe_kernel): 87 FLOP per LDS-fill byte
+    case 9: bm = 256; bn = 256; break;   // ... gemm_big_kernel: 128 FLOP per LDS-fill byte
     default: bm = 64; bn = 128; break;
   }
 }
@@ -2138,12 +2341,12 @@ Plan choose_plan(const ConvDesc& d, const IgemmArgs& a) {
   const bool can_split = d.out_mode == kOutHalf && !d.ln_colsum && !d.out_t;
   auto is_halo = [](int c) { return c == 5 || c == 6 || c == 7; };
   auto tile_ok = [&](int c) {
-    if (c < 1 || c > 8) return false;
+    if (c < 1 || c > 9) return false;
     if (is_halo(c)) return (c == 7 ? halo_ks_ok(d) : halo_ok(d)) && !d.ln_colsum && !d.out_t && !geglu;
-    if (c == 8 && (!gemm_pipe_ok(a) || d.out_mode == kOutHalfT)) return false;
+    if ((c == 8 || c == 9) && (!gemm_pipe_ok(a) || d.out_mode == kOutHalfT)) return false;
     int bm, bn;
     tile_dims(c, bm, bn);
-    if (geglu && c != 1 && c != 4 && c != 8) return false;       // GEGLU value/gate pairs need 64 n-columns per wave
+    if (geglu && c != 1 && c != 4 && c != 8 && c != 9) return false;       // GEGLU value/gate pairs need 64 n-columns per wave
     if (d.out_t && d.n_trans % bn != 0) return false;  // the q|k / v boundary must be a tile boundary
     return true;
   };
@@ -2502,13 +2705,16 @@ int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
   }
   const bool trans = d.out_mode == kOutHalfT;
   const int st = p.staging;
-  {   // tile order (IgemmArgs::n_fast): fabric bytes ~ A * n-tiles + 8 W (m fastest) against A + 8 W * ... (n fastest)
+  {   // tile order (IgemmArgs::n_fast): the activation panel first when re-reading the activations once per further n-tile
+      // would cost more fabric bytes than giving every XCD its own copy of the weights.  (A finer model - operands that fit
+      // one L2 are fetched once per XCD, not per tile - chose differently on a third of the SDXL / low-resolution shapes and
+      // measured the same at batch 2 and 0.9 % slower at UNet batch 16, profiles/r03_ab_tile_order_model.txt: not kept.)
     int bm, bn;
     tile_dims(p.tile, bm, bn);
-    const long nbn = cdiv(a.N, bn);
+    const double nbn = (double)cdiv(a.N, bn);
     const double a_bytes = 2.0 * a.B * a.Hi * a.Wi * a.Ctot, w_bytes = 2.0 * a.N * a.K;
     static const int forced = getenv("SD_TILE_ORDER") ? atoi(getenv("SD_TILE_ORDER")) : -1;   // A/B switch: 0 / 1
-    a.n_fast = forced >= 0 ? (forced != 0) : (nbn > 1 && a_bytes * (double)(nbn - 1) > 7.0 * w_bytes);
+    a.n_fast = forced >= 0 ? (forced != 0) : (nbn > 1 && a_bytes * (nbn - 1) > 7.0 * w_bytes);
   }
   static const bool log_plans = getenv("SD_LOG_CONVS") != nullptr;
   if (log_plans)
@@ -2527,10 +2733,25 @@ int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
   } else {
     if (!trans) {
       int bm, bn;
-      tile_dims((p.tile >= 1 && p.tile <= 3) || p.tile == 8 ? p.tile : 4, bm, bn);
+      tile_dims((p.tile >= 1 && p.tile <= 3) || p.tile == 8 || p.tile == 9 ? p.tile : 4, bm, bn);
       gn_entries = setup_gn_stats(d, a, bm);
     }
     switch (p.tile) {
+      case 9: {
+        dim3 grid(cdiv(a.M, 256) * cdiv(a.N, 256), a.splitk);
+        if (a.ln_colsum) {
+          auto k = gemm_big_kernel<true>;
+          static DynLdsOnce once;
+          once.set(k, kBigLdsBytes);
+          hipLaunchKernelGGL(k, grid, dim3(256), kBigLdsBytes, s, a);
+        } else {
+          auto k = gemm_big_kernel<false>;
+          static DynLdsOnce once;
+          once.set(k, kBigLdsBytes);
+          hipLaunchKernelGGL(k, grid, dim3(256), kBigLdsBytes, s, a);
+        }
+        break;
+      }
       case 8:
         if (a.ln_colsum) launch_pipe<256, 128, 2, 2, 3, true>(a, s);
         else launch_pipe<256, 128, 2, 2, 3, false>(a, s);

@@ -12,7 +12,8 @@
 // softmax over keys in registers (lane = query; attention.py:24-72 "bkhq" orientation), no running maximum, P feeds
 // P . V straight from registers.  Replaces a GEMM launch + an attention launch and the q round trip through HBM; the
 // three schedules of attention.py differ in how they walk LONG key axes and coincide for a single key tile, so this kernel
-// serves all three (the 512-query chunks of SPLIT_EINSUM_V2 are a multiple of its 128-query workgroups).
+// serves all three (the 512-query chunks of SPLIT_EINSUM_V2 are a multiple of its 128-query workgroups).  A sample whose token
+// count is not a multiple of 128 (SDXL's 24x24 level: 576) ends in a ragged tile whose surplus rows are computed and dropped.
 #include "kernels.h"
 
 namespace sd {
@@ -70,15 +71,17 @@ __global__ __launch_bounds__(256, xattn_lds_bytes(NST) <= 80 * 1024 ? 2 : 1) voi
 
   // XCD-aware order (block b runs on XCD b % 8): each XCD walks a contiguous run of (m-tile, head) pairs, heads fastest, so
   // the heads of one m-tile - which share its 128 x C activation rows - meet in one L2
-  const int nwg = (a.M / XBM) * a.heads;
+  const int tps = (a.S + XBM - 1) / XBM;                 // query tiles per sample; the last one may be ragged (SDXL: 576 = 4.5 x 128)
+  const int nwg = (a.M / a.S) * tps * a.heads;
   int bid = blockIdx.x;
   {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int mt = bid / a.heads, h = bid - mt * a.heads;
-  const int m_blk = mt * XBM;
-  const int b = m_blk / a.S;                             // XBM divides S: one sample per workgroup
+  const int b = mt / tps;                                // one sample per workgroup (its K / V)
+  const int m_blk = b * a.S + (mt - b * tps) * XBM;
+  const int rows_valid = min(XBM, a.S - (mt - b * tps) * XBM);   // rows past it belong to the next sample: computed, never stored
   const int nk = a.C / BK;
 
   // ---- prompt K / V^T of this head: requested first (oldest VMEM ops), written to LDS after the projection loop ----
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(256, xattn_lds_bytes(NST) <= 80 * 1024 ? 2 : 1) voi
   const half_t* xp[XR];
   const half_t* wp[WR];
 #pragma unroll
-  for (int i = 0; i < XR; ++i) xp[i] = a.x + (size_t)(m_blk + lrow + 32 * i) * a.C + chunk * 8;
+  for (int i = 0; i < XR; ++i) xp[i] = a.x + (size_t)min(m_blk + lrow + 32 * i, a.M - 1) * a.C + chunk * 8;   // clamped past the tensor
 #pragma unroll
   for (int i = 0; i < WR; ++i) wp[i] = a.wq + (size_t)(h * XD + lrow + 32 * i) * a.C + chunk * 8;
   auto load_tile = [&](int stage) {
@@ -288,6 +291,7 @@ __global__ __launch_bounds__(256, xattn_lds_bytes(NST) <= 80 * 1024 ? 2 : 1) voi
     }
 
   // ---- normalise + store: oacc[ct][r] = channel ct*32 + (r&3) + 8*(r>>2) + 4*hi of token (lane & 31) ----
+  if (wave * 32 + l31 >= rows_valid) return;             // ragged last tile of a sample
   half_t* orow = a.out + (size_t)(m_blk + wave * 32 + l31) * a.C + (size_t)h * XD;
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct)
@@ -306,14 +310,14 @@ void launch_nst(const XAttnArgs& a, hipStream_t s) {
   auto k = xattn_fused_kernel<NST>;
   static DynLdsOnce once;
   once.set(k, lds);
-  hipLaunchKernelGGL(k, dim3((a.M / XBM) * a.heads), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(k, dim3((a.M / a.S) * ((a.S + XBM - 1) / XBM) * a.heads), dim3(256), lds, s, a);
 }
 
 }  // namespace
 
 bool xattn_fused_ok(int C, int heads, int S, int L) {
   static const bool off = getenv("SD_NO_XATTN_FUSED") != nullptr;   // A/B switch
-  return !off && heads >= 1 && C == heads * XD && C % BK == 0 && S % XBM == 0 && L >= 1 && L <= XKEYS;
+  return !off && heads >= 1 && C == heads * XD && C % BK == 0 && S >= 1 && L >= 1 && L <= XKEYS;
 }
 
 void launch_xattn_fused(const XAttnDesc& d, hipStream_t s) {

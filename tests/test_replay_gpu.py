@@ -22,4 +22,4 @@ def test_full_size_graph_replay_is_bit_identical_to_eager_for_every_ring_and_spl
     rep = json.loads(lines[-1][len("REPLAY_GUARD "):])
     assert rep["failures"] == [] and r.returncode == 0, rep["failures"]
     assert set(rep["default"]) == {"ORIGINAL", "SPLIT_EINSUM", "SPLIT_EINSUM_V2"} and not any(rep["default"].values())
-    assert len(rep["forced"]) == 102 and rep["loop20_equal"]
+    assert len(rep["forced"]) == 105 and rep["loop20_equal"]

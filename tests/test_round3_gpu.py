@@ -102,6 +102,8 @@ def xattn_ref(x, lw, lb, wq, k, v, heads, eps):
 
 XATTN_CASES = [  # (B, heads, Sq, Sk)
     (2, 5, 4096, 77), (2, 10, 1024, 77), (2, 20, 256, 77), (1, 5, 128, 77), (1, 2, 256, 96), (1, 2, 128, 1), (1, 3, 384, 33),
+    # token counts that are not a multiple of the 128-query tile: SDXL's 24x24 level, the 8x8 level, an odd count
+    (2, 20, 576, 77), (2, 20, 64, 77), (2, 3, 200, 50),
 ]
 
 
@@ -142,7 +144,7 @@ def test_cross_attention_fused_peaked_softmax_and_rejects():
         _lib.cross_attention_fused(x, lw, lb, wq, np.zeros((b, c, 1, 97), np.float16), np.zeros((b, c, 1, 97), np.float16), heads)
 
 
-# ---- software-pipelined 1x1 GEMM kernel (gemm_pipe_kernel): plan codes 6x / 7x = ring of 3 / 4 stages on tile x, 8 = 256x128 ----
+# ---- software-pipelined 1x1 GEMM kernel (gemm_pipe_kernel): plan codes 6x / 7x = ring of 3 / 4 stages on tile x, 8 = 256x128, 9 = 256x256 (gemm_big_kernel) ----
 PIPE_SHAPES = [  # (B, Cin, H, W, Cout)
     (2, 320, 32, 32, 320),     # K = 5 steps, N = 2.5 n-tiles of 128
     (1, 64, 16, 16, 128),      # K = 1 step: prologue + peeled final step only
@@ -160,7 +162,7 @@ def conv1x1_ref(x, w, bias, res):
 
 @pytest.mark.parametrize("shape", PIPE_SHAPES, ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("splitk", [1, 2, 3])
-@pytest.mark.parametrize("tile", [61, 62, 63, 64, 71, 72, 73, 74, 8])
+@pytest.mark.parametrize("tile", [61, 62, 63, 64, 71, 72, 73, 74, 8, 9])
 def test_conv1x1_pipelined_gemm_matches_torch(tile, splitk, shape):
     b, cin, hh, ww, cout = shape
     rs = np.random.RandomState(cin + cout + tile)
@@ -174,7 +176,7 @@ def test_conv1x1_pipelined_gemm_matches_torch(tile, splitk, shape):
     assert np.array_equal(out, again)
 
 
-@pytest.mark.parametrize("tile", [61, 62, 63, 64, 71, 8])
+@pytest.mark.parametrize("tile", [61, 62, 63, 64, 71, 8, 9])
 def test_pipelined_gemm_groupnorm_statistics(tile):
     """proj_out + residual feeding a GroupNorm: statistics from the pipelined kernel's (shared) tile epilogue."""
     rs = np.random.RandomState(tile)

@@ -14,8 +14,10 @@ from python_hip_stable_diffusion import _lib  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 SHAPES = [(320, 320, 64), (1280, 320, 64), (640, 640, 32), (2560, 640, 32), (1280, 1280, 16), (5120, 1280, 16), (320, 960, 64),
-          (640, 1920, 32), (1280, 3840, 16)]
-CODES = [0, 8, 1, 61, 71, 2, 62, 4, 64, 3, 63]
+          (640, 1920, 32), (1280, 3840, 16), (320, 2560, 64), (1280, 10240, 16)]
+if len(sys.argv) > 2 and sys.argv[2] == "sdxl":   # the 24x24 / 48x48 levels of SDXL-base at 768x768 (B = 2: 1152 / 4608 tokens)
+    SHAPES = [(1280, 10240, 24), (1280, 3840, 24), (5120, 1280, 24), (1280, 1280, 24), (640, 5120, 48), (2560, 640, 48), (640, 1920, 48)]
+CODES = [0, 9, 8, 1, 61, 2, 62, 4, 64, 3]
 rs = np.random.RandomState(0)
 print(f"UNet batch {B}; columns: plan code -> us (TFLOP/s)")
 for cin, cout, hw in SHAPES:

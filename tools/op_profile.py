@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Per-op timing of one SD2.1-base UNet forward (sd_unet_profile: HIP events around every launch-list entry,
 eager launches) -> JSON + a table aggregated by op family.
-usage: op_profile.py [out.json] [batch] [attention]"""
+usage: op_profile.py [out.json] [batch] [attention] [model: sd21 | sdxl | sdxl-refiner | sd15] [latent]"""
 import json
 import os
 import re
@@ -18,12 +18,20 @@ from python_hip_stable_diffusion import HipModel, checkpoint  # noqa: E402
 out = sys.argv[1] if len(sys.argv) > 1 else None
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 impl = sys.argv[3] if len(sys.argv) > 3 else "ORIGINAL"
-MODEL = "stabilityai/stable-diffusion-2-1-base"
+WHICH = sys.argv[4] if len(sys.argv) > 4 else "sd21"
+MODEL = {"sd21": "stabilityai/stable-diffusion-2-1-base", "sdxl": "stabilityai/stable-diffusion-xl-base-1.0",
+         "sdxl-refiner": "stabilityai/stable-diffusion-xl-refiner-1.0", "sd15": "runwayml/stable-diffusion-v1-5"}[WHICH]
+HW = int(sys.argv[5]) if len(sys.argv) > 5 else (96 if WHICH.startswith("sdxl") else 64)
 ck = checkpoint.random_checkpoint(checkpoint.unet_param_shapes(MODEL), seed=0)
-m = HipModel(MODEL, ck, batch=B, attention_implementation=impl)
-x = np.random.RandomState(1).randn(B, 4, 64, 64).astype(np.float16)
-e = np.random.RandomState(2).randn(B, 1024, 1, 77).astype(np.float16)
-m(sample=x, timestep=np.full((B,), 951, np.float16), encoder_hidden_states=e)
+m = HipModel(MODEL, ck, batch=B, latent_height=HW, latent_width=HW, attention_implementation=impl)
+del ck
+kw = {}
+for k, v in m.expected_inputs.items():
+    kw[k] = np.random.RandomState(len(k)).randn(*v["shape"]).astype(np.float16)
+kw["timestep"] = np.full((B,), 951, np.float16)
+if "time_ids" in kw:
+    kw["time_ids"] = np.tile(np.asarray([HW * 8, HW * 8, 0, 0, HW * 8, HW * 8][:kw["time_ids"].shape[1]], np.float16), (B, 1))
+m(**kw)
 graph_ms = m.time_forward(3, 20)
 ops = m.profile(iters=9)
 total = sum(o[2] for o in ops)

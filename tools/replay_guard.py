@@ -69,7 +69,7 @@ g.set_attention_implementation("ORIGINAL")
 e.set_attention_implementation("ORIGINAL")
 cands = [(7, s, k) for s in (0, 2, 3, 4, 5) for k in (1, 2, 4)]
 cands += [(t, s, k) for t in (1, 2, 3, 4) for s in (0, 2, 3, 4, 5, 6, 7) for k in (1, 2, 4)]
-cands += [(8, 0, k) for k in (1, 2, 4)]
+cands += [(8, 0, k) for k in (1, 2, 4)] + [(9, 0, k) for k in (1, 2, 4)]
 if QUICK:
     cands = cands[::7]
 for tile, staging, splitk in cands:
