@@ -503,7 +503,7 @@ int sd_op_cross_attention_fused(const void* x, const float* ln_weight, const flo
     SD_REQUIRE(x && ln_weight && ln_bias && wq && k && v && out, kInvalidArgument, "NULL argument");
     const int C = heads * 64;
     SD_REQUIRE(B > 0 && heads > 0 && xattn_fused_ok(C, heads, Sq, Sk), kUnsupported,
-               "cross_attention_fused: heads %d x 64 channels, Sq %d (need Sq %% 128 == 0), Sk %d (<= 96)", heads, Sq, Sk);
+               "cross_attention_fused: heads %d x 64 channels, Sq %d, Sk %d (<= 96)", heads, Sq, Sk);
     Scratch sc;
     const int ldv = (Sk + 7) / 8 * 8;
     const half_t* xh = reinterpret_cast<const half_t*>(x);

@@ -24,8 +24,8 @@ out_table = sys.argv[2]
 out_report = sys.argv[3] if len(sys.argv) > 3 else None
 WHICH = sys.argv[4] if len(sys.argv) > 4 else "sd21"
 MODEL = {"sd21": "stabilityai/stable-diffusion-2-1-base", "sdxl": "stabilityai/stable-diffusion-xl-base-1.0",
-         "sd15": "runwayml/stable-diffusion-v1-5"}[WHICH]
-HW = int(sys.argv[5]) if len(sys.argv) > 5 else (96 if WHICH == "sdxl" else 64)
+         "sdxl-refiner": "stabilityai/stable-diffusion-xl-refiner-1.0", "sd15": "runwayml/stable-diffusion-v1-5"}[WHICH]
+HW = int(sys.argv[5]) if len(sys.argv) > 5 else (96 if WHICH.startswith("sdxl") else 64)
 B = 2
 ck = checkpoint.random_checkpoint(checkpoint.unet_param_shapes(MODEL), seed=0)
 m = HipModel(MODEL, ck, batch=B, latent_height=HW, latent_width=HW, attention_implementation="ORIGINAL", use_graph=True)
@@ -33,7 +33,8 @@ ctx = m.expected_inputs["encoder_hidden_states"]["shape"][1]
 kw = dict(sample=np.random.RandomState(1).randn(B, 4, HW, HW).astype(np.float16), timestep=np.full((B,), 951, np.float16),
           encoder_hidden_states=np.random.RandomState(2).randn(B, ctx, 1, 77).astype(np.float16))
 if "time_ids" in m.expected_inputs:
-    kw["time_ids"] = np.tile(np.array([[HW * 8, HW * 8, 0, 0, HW * 8, HW * 8]], np.float16), (B, 1))
+    nid = m.expected_inputs["time_ids"]["shape"][1]
+    kw["time_ids"] = np.tile(np.array([[HW * 8, HW * 8, 0, 0, HW * 8, HW * 8][:nid]], np.float16), (B, 1))
     kw["text_embeds"] = np.random.RandomState(3).randn(*m.expected_inputs["text_embeds"]["shape"]).astype(np.float16)
 ref = m(**kw)["noise_pred"]
 lib = _lib.lib()
