@@ -1141,6 +1141,10 @@ void UNet::attach_controlnets(const std::vector<UNet*>& cns) {
   }
   SD_HIP(hipSetDevice(device_));
   SD_HIP(hipStreamSynchronize(stream_));
+  // a ControlNet that leaves this handle forgets its conditioning image: re-attaching it later without a fresh
+  // sd_controlnet_set_cond must fail loudly instead of running with the previous generation's image
+  for (UNet* old : attached_)
+    if (std::find(cns.begin(), cns.end(), old) == cns.end()) old->have_cond_ = false;
   attached_ = cns;
   for (UNet* cn : attached_) cn->set_attention(cfg_.attention_impl);
   invalidate_graphs();     // the captured launches bake in which residual sources are read

@@ -45,6 +45,12 @@ def test_sd15_controlnet_full_size_device_loop_matches_reference_modules():
     print(f"config 5 full size: PSNR vs reference modules {p10:.1f} dB after 10 steps, {p20:.1f} dB after 20; {np.median(ms):.2f} ms/step")
     assert len(ms) == L.STEPS_CN and np.isfinite(final).all()
     assert p10 >= GATE_CN10 and p20 >= GATE_CN20, (p10, p20)
+    # a ControlNet that leaves the handle forgets its conditioning image: re-attached without a fresh set_controlnet_cond it
+    # must fail loudly, not run with the previous generation's image
+    unet.attach_controlnets([])
+    unet.attach_controlnets([cn])
+    with pytest.raises(ValueError, match="conditioning image"):
+        unet.denoise_loop(lat0, ts[:1], coef[:1], L.GS_CN, history=hist, encoder_hidden_states=_f16(inp["ehs"]))
     unet.attach_controlnets([])
     unet.close(), cn.close()
 
