@@ -2705,16 +2705,23 @@ int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
   }
   const bool trans = d.out_mode == kOutHalfT;
   const int st = p.staging;
-  {   // tile order (IgemmArgs::n_fast): the activation panel first when re-reading the activations once per further n-tile
-      // would cost more fabric bytes than giving every XCD its own copy of the weights.  (A finer model - operands that fit
-      // one L2 are fetched once per XCD, not per tile - chose differently on a third of the SDXL / low-resolution shapes and
-      // measured the same at batch 2 and 0.9 % slower at UNet batch 16, profiles/r03_ab_tile_order_model.txt: not kept.)
+  {   // tile order (IgemmArgs::n_fast) from an estimate of the bytes each order pulls through the fabric into the 8 XCD L2s:
+      //   m fastest: every weight panel once; the activations once per XCD when they fit an L2, else once per n-tile
+      //   n fastest: the activations once; the weights once per XCD when they fit an L2, else once per m-tile
+      // (SD_TILE_ORDER=2: round 3's first rule, activations x (n-tiles - 1) > 7 x weights - same step time at batch 2, but it
+      // sent the 1280 -> 1280 GEMMs of the 16x16 level n-fast: 27 MB of fabric reads per launch for 4.6 MB of operands)
     int bm, bn;
     tile_dims(p.tile, bm, bn);
+    const bool halo_tile = p.tile == 5 || p.tile == 6 || p.tile == 7;
     const double nbn = (double)cdiv(a.N, bn);
+    const double nbm = halo_tile ? (double)a.B * a.tiles_x * a.tiles_y : (double)cdiv(a.M, bm);
     const double a_bytes = 2.0 * a.B * a.Hi * a.Wi * a.Ctot, w_bytes = 2.0 * a.N * a.K;
-    static const int forced = getenv("SD_TILE_ORDER") ? atoi(getenv("SD_TILE_ORDER")) : -1;   // A/B switch: 0 / 1
-    a.n_fast = forced >= 0 ? (forced != 0) : (nbn > 1 && a_bytes * (nbn - 1) > 7.0 * w_bytes);
+    const double l2 = 3.5e6;   // what one 4-MB L2 keeps of an operand next to the other one's stream
+    const double m_fast_cost = w_bytes + a_bytes * (a_bytes <= l2 ? std::min(8.0, nbn) : nbn);
+    const double n_fast_cost = a_bytes + w_bytes * (w_bytes <= l2 ? std::min(8.0, nbm) : nbm);
+    static const int forced = getenv("SD_TILE_ORDER") ? atoi(getenv("SD_TILE_ORDER")) : -1;   // A/B switch: 0 / 1 / 2
+    if (forced == 2) a.n_fast = nbn > 1 && a_bytes * (nbn - 1) > 7.0 * w_bytes;
+    else a.n_fast = forced >= 0 ? (forced != 0) : (nbn > 1 && n_fast_cost < m_fast_cost);
   }
   static const bool log_plans = getenv("SD_LOG_CONVS") != nullptr;
   if (log_plans)

@@ -82,7 +82,8 @@ def write_checkpoint_dir(root):
     # what an SD checkpoint's scheduler/scheduler_config.json holds; get_hip_pipe builds the scheduler from it
     # (pipeline.py:738-741), missing keys take the diffusers class defaults (beta 1e-4 .. 0.02), so the betas are spelled out
     json.dump({"_class_name": "PNDMScheduler", "beta_schedule": "scaled_linear", "beta_start": 0.00085, "beta_end": 0.012,
-               "num_train_timesteps": 1000, "skip_prk_steps": True, "steps_offset": 1, "set_alpha_to_one": False},
+               "num_train_timesteps": 1000, "skip_prk_steps": True, "steps_offset": 1, "set_alpha_to_one": False,
+               "clip_sample": False, "trained_betas": None},   # the keys of SD 1.x / 2.x checkpoints' scheduler_config.json
               open(os.path.join(root, "scheduler", "scheduler_config.json"), "w"))
     alpha = _bytes_to_unicode()
     vocab = {}
@@ -131,8 +132,8 @@ def test_get_hip_pipe_and_cli_generate_an_image_from_a_text_prompt(tmp_path):
     lat = scheduler_ref.denoise_loop(unet, scheduler_ref.PNDM(), lat0.astype(np.float32), emb, steps, gs)
     img = vae_ref.vae_decode(parts["vae"], vcfg, torch.from_numpy(lat / 0.18215)).numpy()
     img = np.clip(img / 2 + 0.5, 0, 1).transpose(0, 2, 3, 1)
-    assert psnr.compute_psnr(out.latents, lat) >= 35.0
-    assert psnr.compute_psnr(out.images, img) >= 35.0                                          # tests/test_stable_diffusion.py:33
+    assert psnr.compute_psnr(out.latents, lat) >= 54.0                                         # measured 60.5 (r3): gate = measured - 6
+    assert psnr.compute_psnr(out.images, img) >= 70.0                                          # measured 77.9 (reference floor 35 dB, tests/test_stable_diffusion.py:33)
     pipe.unet.close(), pipe.vae_decoder.close(), pipe.text_encoder.close()
 
     # the CLI: same flags as the reference's `python -m python_coreml_stable_diffusion.pipeline`
