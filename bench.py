@@ -212,7 +212,7 @@ def main():
         "dtype": "fp16", "data": "synthetic",
         "config": {"workload": f"{spec['config']}: {spec['name']}, random-init, denoising iteration at {px}x{px} "
                                f"({lat_hw}x{lat_hw} latents), CFG batch 2 per prompt, DDIM, device-resident loop",
-                   "model": args.model, "latent": lat_hw,
+                   "unet": args.model, "latent": lat_hw,
                    "attention": args.attention, "prompts_per_gpu": ppg, "global_batch": 2 * ppg * world,
                    "guidance_scale": args.guidance_scale, "hip_graph": not args.no_graph,
                    "parallelism": f"dp{world} (independent prompts per rank, no data-path collective)"},

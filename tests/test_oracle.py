@@ -215,3 +215,30 @@ def test_tokenizer_reproduces_the_reference_test_vectors(tmp_path):
                          ("Apple CoreML developer tools on a Macbook Air are fast",
                           [49406, 3055, 19622, 5780, 10929, 5771, 525, 320, 20617, 1922, 631, 1953, 49407])):
         assert tok(prompt)["input_ids"] == want
+
+
+def test_fullsize_loop_goldens_carry_the_seeds_the_gpu_tests_regenerate_inputs_from():
+    """tests/golden/loop20_{sdxl_base_refiner,sd15_controlnet}_golden.npz (oracle/pin_round3.py, the reference's own
+    modules) store only output latents + the seeds of oracle/loop_inputs.py: the two must agree, and the generators must be
+    deterministic and fp16-exact (what crosses the model boundary)."""
+    from oracle import loop_inputs as L
+    g4, g5 = load_golden("loop20_sdxl_base_refiner_golden.npz"), load_golden("loop20_sd15_controlnet_golden.npz")
+    for k, v in L.SEEDS_XL.items():
+        assert int(g4[f"seed_{k}"]) == v
+    for k, v in L.SEEDS_CN.items():
+        assert int(g5[f"seed_{k}"]) == v
+    assert int(g4["hw"]) == L.HW_XL and int(g4["steps"]) == L.STEPS_XL and float(g4["guidance_scale"]) == L.GS_XL
+    assert int(g4["swap"]) == int((L.STEPS_XL + 1) * L.SWAP_FRAC) == 16            # PNDM: steps + 1 evaluations
+    assert int(g5["hw"]) == L.HW_CN and int(g5["steps"]) == L.STEPS_CN and float(g5["guidance_scale"]) == L.GS_CN
+    assert g4["final"].shape == g4["latents_at_swap"].shape == (1, 4, L.HW_XL, L.HW_XL) and np.isfinite(g4["final"]).all()
+    assert g5["final"].shape == g5["latents_step10"].shape == (1, 4, L.HW_CN, L.HW_CN) and np.isfinite(g5["final"]).all()
+    a, b = L.xl_inputs(), L.xl_inputs()
+    for k in a:
+        assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], a[k].astype(np.float16).astype(np.float32))
+    assert a["ehs_base"].shape == (2, 2048, 1, 77) and a["ehs_refiner"].shape == (2, 1280, 1, 77) and a["ids_refiner"].shape == (2, 5)
+    c = L.cn_inputs()
+    assert c["cond"].shape == (2, 3, 512, 512) and 0.0 <= c["cond"].min() and c["cond"].max() <= 1.0
+    assert np.array_equal(c["cond"][0], c["cond"][1])                                # the same image for both CFG rows
+    lat = L.initial_latents(L.SEEDS_CN["latents"], L.HW_CN)
+    np.random.seed(93)
+    assert np.array_equal(lat, np.random.randn(1, 4, 64, 64).astype(np.float16).astype(np.float32))
