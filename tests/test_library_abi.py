@@ -120,3 +120,29 @@ def test_tune_abi_is_dead_without_the_environment_switch():
             "print('RC', rc, _lib.lib().sd_last_error().decode())\n") % (ROOT, os.path.join(ROOT, "ml-stable-diffusion_amd"))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert "RC -4" in r.stdout and "SD_TUNE" in r.stdout, r.stdout + r.stderr
+
+
+def _header_struct_fields(name):
+    """Field names (arrays as 'name[N]' -> name) of `typedef struct <name> { ... } <name>;` in include/sd_mi355x.h, in order."""
+    text = open(os.path.join(ROOT, "include", "sd_mi355x.h")).read()
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), text, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for part in decl.split(","):
+            m = re.search(r"([A-Za-z_][A-Za-z0-9_]*)\s*(\[[^\]]*\])?\s*$", part.strip())
+            fields.append(m.group(1))
+    return fields
+
+
+def test_ctypes_struct_mirrors_follow_the_header_field_for_field():
+    """sd_unet_config / sd_unet_io cross the ABI by pointer: the ctypes mirrors must list the header's fields in the header's
+    order (round 3 appended compute_fp32 and step_noise), and their sizes must be what a C compiler lays out."""
+    assert [f[0] for f in _lib.UNetConfig._fields_] == _header_struct_fields("sd_unet_config")
+    assert [f[0] for f in _lib.UNetIO._fields_] == _header_struct_fields("sd_unet_io")
+    n = _lib.SD_MAX_LEVELS
+    assert C.sizeof(_lib.UNetConfig) == 4 * (6 + 3 * n + 1 + 2 * n + 15)     # all members 4 bytes wide: no padding
+    assert C.sizeof(_lib.UNetIO) % 8 == 0 and _lib.UNetIO.step_noise.offset == C.sizeof(_lib.UNetIO) - 8
