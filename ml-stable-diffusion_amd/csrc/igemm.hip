@@ -1494,7 +1494,7 @@ __global__ __launch_bounds__(256, halo_lds_bytes(64, D) <= 80 * 1024 ? 2 : 1) vo
 // Software-pipelined 1x1 GEMM (every Linear / 1x1 conv of the transformer blocks and the resnet shortcuts at stride 1;
 // unet.py:62-118, :566-617).  igemm_kernel above reads the 16 fragments of a K step, waits for them, then issues its 16
 // MFMAs: with one wave per SIMD the LDS latency and the barrier are exposed once per step and the matrix pipe idles
-// 50-75 % of the loop (245-520 TFLOP/s at UNet batch 16, profiles/r03_op_profile_b16.txt).  Here the loop body is the
+// 50-75 % of the loop (245-520 TFLOP/s at UNet batch 16, profiles/r03_op_profile_b16_before.txt).  Here the loop body is the
 // one of the K-split halo conv kernel:
 //   * fragments are double-buffered in registers - between the MFMAs of step s the wave issues the ds_read_b128 of
 //     step s+1 and the LDS-DMA of step s+D; the body is ONE basic block (no conditionals: tiles past the end of K go
@@ -1731,10 +1731,10 @@ __global__ __launch_bounds__(256) void gemm_pipe_kernel(IgemmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// 256 x 256 tile of the software-pipelined 1x1 GEMM (plan tile 9): the tile that passes the LDS-fill wall.
-// Every byte DMA'd into LDS feeds 128 FLOP here (64 on the 128 x 128 tile), and the chip-wide L2 -> LDS fill rate
-// (6.5-9 TB/s measured) is what bounds the GEMMs: SDXL's 1280 -> 10240 GEGLU projection at 1152 tokens sits at exactly
-// 64 FLOP/B x 6.7 TB/s = 427 TFLOP/s on the 128-wide tiles (profiles/r03_op_profile_sdxl.txt).
+// 256 x 256 tile of the software-pipelined 1x1 GEMM (plan tile 9): MEASURED, CORRECT, SELECTED NOWHERE (DESIGN.md Finding 5).
+// Every byte DMA'd into LDS feeds 128 FLOP here (64 on the 128 x 128 tile), built to test whether LDS fill bounds the GEMMs: it
+// lands where the 128-wide tiles do (556 TFLOP/s on 1280 -> 10240 at 4096 tokens, profiles/r03_gemm_big_bench.txt) - with one
+// workgroup per CU and ONE tile in flight the DMA landing cadence paces the step; hipBLASLt reaches 1.0-1.2 PFLOP/s there.
 // Four waves as 2 x 2, a wave owns 128 x 128 outputs: 256 accumulator registers (the whole AGPR file), fragments
 // ping-pong per 16-deep k sub-step (8 x 16 B in, 16 MFMAs out), two LDS stages of 64 KB: the DMA of step s+1 is issued
 // right behind the barrier of step s into the stage whose last reads that barrier has just retired.  Epilogue: the shared
