@@ -146,3 +146,15 @@ def test_ctypes_struct_mirrors_follow_the_header_field_for_field():
     n = _lib.SD_MAX_LEVELS
     assert C.sizeof(_lib.UNetConfig) == 4 * (6 + 3 * n + 1 + 2 * n + 15)     # all members 4 bytes wide: no padding
     assert C.sizeof(_lib.UNetIO) % 8 == 0 and _lib.UNetIO.step_noise.offset == C.sizeof(_lib.UNetIO) - 8
+
+
+def test_vae_compute_precision_is_validated_before_any_device_work():
+    """HipVaeDecoder / HipVaeEncoder(dtype=...) select the compute precision (fp16 MFMA kernels or the fp32 path the reference
+    converts the SDXL VAE with, torch2coreml.py:570-578): anything else is refused on the host, without touching a GPU."""
+    from python_hip_stable_diffusion import HipVaeDecoder, HipVaeEncoder
+    cfg = dict(latent_channels=4, out_channels=3, block_out_channels=(32, 32), layers_per_block=1)
+    for cls in (HipVaeDecoder, HipVaeEncoder):
+        with pytest.raises(ValueError, match="float16 or float32"):
+            cls(cfg, {}, dtype=np.float64)
+    c = _lib.UNetConfig()
+    assert c.compute_fp32 == 0                       # default-constructed configs keep the fp16-storage kernels
