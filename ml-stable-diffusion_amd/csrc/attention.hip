@@ -577,6 +577,14 @@ void launch_attention(const AttnDesc& d, hipStream_t s) {
                  "SPLIT_EINSUM_V2 needs S_q %% 512 == 0 (got %d); the reference would silently drop the tail "
                  "(attention.py:86)", d.Sq);
   }
+  if (d.vt_perm) {   // d = 64, whole key tiles: the software-pipelined two-waves-per-SIMD kernel (attention8.hip)
+    SD_REQUIRE(attention8_ok(d), kInvalidArgument, "attention: permuted V^T but the shape is not attention8's (d %d Sq %d Sk %d)", d.d,
+               d.Sq, d.Sk);
+    AttnDesc d8 = d;
+    d8.impl = impl;
+    launch_attention8(d8, s);
+    return;
+  }
   AttnArgs a{d.q, d.k, d.vt, d.out, d.heads, d.d, d.Sq, d.Sk, d.ldq, d.ldk, d.ldv, d.ldo,
              1.4426950408889634f / sqrtf((float)d.d)};
   const int dk16 = cdiv(d.d, 16), dc32 = cdiv(d.d, 32);

@@ -303,6 +303,9 @@ int sd_op_attention(int impl, const void* q, const void* k, const void* v, void*
     Scratch sc;
     const int C = heads * d;
     const int ldv = (Sk + 7) / 8 * 8;
+    // the software-pipelined d = 64 kernel reads V^T with the middle 4-key blocks of every 16 keys swapped (AttnDesc::vt_perm)
+    const bool perm = variant != 1 && attention8_shape_ok(d, Sq, Sk);
+    auto vpos = [perm](int s) { const int o = s & 15; return perm && o >= 4 && o < 12 ? s + (o < 8 ? 4 : -4) : s; };
     const half_t* qh = reinterpret_cast<const half_t*>(q);
     const half_t* kh = reinterpret_cast<const half_t*>(k);
     const half_t* vh = reinterpret_cast<const half_t*>(v);
@@ -313,7 +316,7 @@ int sd_op_attention(int impl, const void* q, const void* k, const void* v, void*
         for (int s = 0; s < Sq; ++s) qt[((size_t)b * Sq + s) * C + c] = qh[((size_t)b * C + c) * Sq + s];
         for (int s = 0; s < Sk; ++s) {
           kt[((size_t)b * Sk + s) * C + c] = kh[((size_t)b * C + c) * Sk + s];
-          vt[((size_t)b * C + c) * ldv + s] = vh[((size_t)b * C + c) * Sk + s];
+          vt[((size_t)b * C + c) * ldv + vpos(s)] = vh[((size_t)b * C + c) * Sk + s];
         }
       }
     AttnDesc a;
@@ -326,6 +329,7 @@ int sd_op_attention(int impl, const void* q, const void* k, const void* v, void*
     a.ldq = C; a.ldk = C; a.ldv = ldv; a.ldo = C;
     a.impl = impl;
     a.variant = variant;
+    a.vt_perm = perm ? 1 : 0;
     sc.timed(iters, ms, [&] { launch_attention(a, sc.stream); });
     std::vector<half_t> ot((size_t)B * Sq * C);
     SD_HIP(hipMemcpy(ot.data(), o, ot.size() * 2, hipMemcpyDeviceToHost));

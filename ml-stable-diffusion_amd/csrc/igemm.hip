@@ -57,6 +57,7 @@ struct IgemmArgs {
   // (the V^T operand of attention); columns below it to out with row length ldo
   int n_trans, ldo;
   half_t* out_t;
+  int vt_perm;   // 1: out_t rows leave with the two middle 4-token blocks of every 16 tokens swapped (AttnDesc::vt_perm)
   int res_pre;   // 1: igemm_kernel fetches its residual tile at kernel entry (SD_RES_PREFETCH=0 switches it off, A/B)
   // GroupNorm statistics of the OUTPUT tensor from this kernel's epilogue (the consumer is torch.nn.GroupNorm of
   // unet.py:430-451 / :528-531): per (sample, group, m-tile) partial (sum, sumsq) of the fp16-rounded outputs, written to
@@ -283,8 +284,15 @@ __device__ __forceinline__ void tile_epilogue(const IgemmArgs& a, floatx16 (&acc
         const int nv = n_blk + r - a.n_trans, m = m_blk + c * 8;
         if (nv < NV && m < a.M) {
           const int b = m / a.HoWo, sp = m - b * a.HoWo;
-          *reinterpret_cast<half8*>(a.out_t + ((size_t)b * NV + nv) * a.ldT + sp) =
-              *reinterpret_cast<const half8*>(ot + r * TROW + c * 8);
+          half8 v;
+          if (a.vt_perm) {   // 16-B chunk c of the row = tokens 16 j + 4 o + {0..3} and 16 j + 8 + 4 o + {0..3}  (j = c >> 1, o = c & 1)
+            const half_t* src = ot + r * TROW + (c >> 1) * 16 + (c & 1) * 4;
+            const half4 lo = *reinterpret_cast<const half4*>(src), up = *reinterpret_cast<const half4*>(src + 8);
+            v = half8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+          } else {
+            v = *reinterpret_cast<const half8*>(ot + r * TROW + c * 8);
+          }
+          *reinterpret_cast<half8*>(a.out_t + ((size_t)b * NV + nv) * a.ldT + sp) = v;
         }
       }
       return;
@@ -2229,6 +2237,7 @@ IgemmArgs make_args(const ConvDesc& d) {
   a.n_trans = d.out_t ? d.n_trans : 0x7fffffff;
   a.ldo = d.out_t ? d.n_trans : d.N;
   a.out_t = d.out_t;
+  a.vt_perm = d.out_t ? d.vt_perm : 0;
   static const int res_pre = !(getenv("SD_RES_PREFETCH") && atoi(getenv("SD_RES_PREFETCH")) == 0);
   a.res_pre = res_pre;
   a.gn_partial = nullptr;
@@ -2685,6 +2694,7 @@ int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
   SD_REQUIRE(!d.out_t || (d.out_mode == kOutHalf && d.n_trans % 64 == 0 && d.n_trans < d.N && (d.Ho * d.Wo) % 8 == 0 &&
                           d.ldT % 8 == 0 && !d.res && !d.temb),
              kInvalidArgument, "fused q|k|v: n_trans %d N %d HoWo %d ldT %d", d.n_trans, d.N, d.Ho * d.Wo, d.ldT);
+  SD_REQUIRE(!d.vt_perm || (d.out_t && (d.Ho * d.Wo) % 16 == 0), kInvalidArgument, "permuted V^T needs the fused q|k|v epilogue and HoWo %% 16 == 0");
   IgemmArgs a = make_args(d);
   Plan p = choose_plan(d, a);
   const bool halo = p.tile == 5 || p.tile == 6 || p.tile == 7;

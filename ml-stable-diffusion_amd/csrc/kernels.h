@@ -47,6 +47,7 @@ struct ConvDesc {
   // (attention's V^T), columns [0, n_trans) to out with row length n_trans.  Needs Ho*Wo % 8 == 0.
   half_t* out_t = nullptr;
   int n_trans = 0;
+  int vt_perm = 0;              // out_t in the key order of AttnDesc::vt_perm (needs Ho*Wo % 16 == 0)
   // GroupNorm statistics of the output from the conv's own epilogue (the consumer is a GroupNorm over exactly this
   // tensor, gn_groups groups): partial sums go to gn_partial [B][gn_groups][kGnMaxSlabs][2].  launch_conv returns how
   // many entries per (sample, group) it wrote - 0 when the chosen plan cannot (split-K, ragged tiles): the GroupNorm
@@ -92,10 +93,20 @@ struct AttnDesc {
   int B = 1, heads = 1, d = 64, Sq = 0, Sk = 0;
   int ldq = 0, ldk = 0, ldv = 0, ldo = 0;
   int impl = kAttnOriginal;
-  int variant = 0;   // reserved for A/B testing of kernel variants (currently unused)
+  int variant = 0;   // A/B testing: 1 = never use the attention8.hip kernel
+  // 1: every 16-key group of a vt row is stored [k0-3 | k8-11 | k4-7 | k12-15] - the order in which a lane of the key-major
+  // P.V MFMA consumes keys, so its V^T fragment is ONE 16-byte LDS read (attention8.hip; written so by the fused q|k|v GEMM,
+  // ConvDesc::vt_perm).  Only attention8 reads this layout; the general kernels need 0.
+  int vt_perm = 0;
 };
 void launch_attention(const AttnDesc& d, hipStream_t s);
 bool attention_supported(int d);
+// attention8.hip: head dim 64, S_k a multiple of 64 (the UNet's self-attention): LDS-DMA ring, two waves per SIMD, software-
+// pipelined across key tiles.  launch_attention dispatches to it; AttnDesc::variant == 1 (or SD_ATTN8=0) keeps the general kernels.
+bool attention8_ok(const AttnDesc& d);
+// build-time decision (UNet builder, sd_op_attention): will attention8 run this shape?  Then V^T must be produced permuted.
+bool attention8_shape_ok(int d, int Sq, int Sk);
+void launch_attention8(const AttnDesc& d, hipStream_t s);
 
 // Cross-attention front half in one launch (xattn.hip): out = softmax(to_q(LayerNorm(x)) k^T / sqrt(d)) v per head,
 // head dim 64, <= 96 keys (unet.py:87-118 with the prompt's K / V hoisted).  x [M][C] is the UN-normalised input; wq /

@@ -246,6 +246,7 @@ Tensor UNet::conv_w(std::vector<Op>& ops, const std::string& name, const half_t*
   d.ldT = ldT;
   Tensor out;
   if (ex) d.ln_colsum = ex->ln_colsum;
+  if (ex) d.vt_perm = ex->vt_perm ? 1 : 0;
   if (ex && ex->n_trans > 0) {   // fused q|k|v: [M][n_trans] row-major + V^T [B][cout - n_trans][ldT]
     out = new_tensor(x.B, d.Ho, d.Wo, ex->n_trans);
     ex->vt = arena_.alloc_n<half_t>((size_t)x.B * (cout - ex->n_trans) * ldT);
@@ -401,7 +402,7 @@ Tensor UNet::resnet(std::vector<Op>& ops, const std::string& p, const Tensor& x,
 }
 
 Tensor UNet::attention(std::vector<Op>& ops, const Tensor& q, const half_t* k, const half_t* vt, int heads, int Sq,
-                       int Sk, int ldk, int ldv, int ldq) {
+                       int Sk, int ldk, int ldv, int ldq, bool vt_perm) {
   Tensor o = new_tensor(q.B, q.H, q.W, q.C);
   AttnDesc d;
   d.q = q.p;
@@ -417,6 +418,7 @@ Tensor UNet::attention(std::vector<Op>& ops, const Tensor& q, const half_t* k, c
   d.ldk = ldk;
   d.ldv = ldv;
   d.ldo = q.C;
+  d.vt_perm = vt_perm ? 1 : 0;
   SD_REQUIRE(attention_supported(d.d), kUnsupported, "head dim %d (C=%d, heads=%d) unsupported", d.d, q.C, heads);
   ops.push_back([this, d](hipStream_t s) {
     AttnDesc dd = d;
@@ -436,12 +438,15 @@ Tensor UNet::transformer_block(std::vector<Op>& ops, const std::string& b, const
   // columns leave token-transposed (attention's V^T operand); otherwise LN + stacked q|k + V^T GEMMs.
   const int ldv = round_up(S, 8);
   Tensor qk;
+  bool vt_perm = false;   // attention8.hip will run this self-attention: the fused q|k|v GEMM writes V^T in its key order
   half_t* vtp;
   if (can_fold_ln(h, 3 * C, false) && S % 8 == 0 && (2 * C) % 64 == 0) {
     LnFold f = fold_layernorm(b + ".norm1", {b + ".attn1.to_q", b + ".attn1.to_k", b + ".attn1.to_v"}, C, C, false);
     ConvExtra ex;
     ex.ln_colsum = f.colsum;
     ex.n_trans = 2 * C;
+    vt_perm = attention8_shape_ok(C / heads, S, S) && S % 16 == 0;
+    ex.vt_perm = vt_perm;
     qk = conv_w(ops, b + ".attn1.to_qkv", f.w, f.bias, h, nullptr, 3 * C, 1, 1, 1, nullptr, nullptr, kOutHalf, ldv,
                 false, &ex);
     vtp = ex.vt;
@@ -452,7 +457,7 @@ Tensor UNet::transformer_block(std::vector<Op>& ops, const std::string& b, const
   }
   Tensor q = qk;
   q.C = C;   // logical width of q; rows are 2C apart
-  Tensor a1 = attention(ops, q, qk.p + C, vtp, heads, S, S, 2 * C, ldv, 2 * C);
+  Tensor a1 = attention(ops, q, qk.p + C, vtp, heads, S, S, 2 * C, ldv, 2 * C, vt_perm);
   Tensor h1 = conv(ops, b + ".attn1.to_out.0", a1, nullptr, C, 1, 1, 1, true, nullptr, h.p);
   // --- cross attention: K / V^T of the prompt are computed by ctx_ops_ when the prompt changes
   const int ldvc = round_up(L, 8);
