@@ -268,7 +268,8 @@ int sd_op_conv2d_groupnorm(const void* x, const void* w, const float* bias, cons
                            const float* gn_bias, void* conv_out, void* out, int B, int Cin, int H, int W, int Cout, int ksize,
                            int groups, float eps, int silu, int tile, int producer_stats, int* entries, int iters, float* ms);
 /* Cross-attention front half as one launch (unet.py:87-118 inside :586-591): out = softmax(to_q(LayerNormANE(x)) k^T / 8) v
- * per head, head dim 64, Sk <= 96 (the prompt), Sq % 128 == 0.  x (B, heads*64, 1, Sq), k / v (B, heads*64, 1, Sk) f16 BC1S,
+ * per head, head dim 64, Sk <= 96 (the prompt), any Sq >= 1 (ragged last token tile).  V^T columns [Sk, round_up(Sk, 8)) must be
+ * zero (this entry point zero-fills them; the masked probabilities there are 0 but 0 * inf would be NaN).  x (B, heads*64, 1, Sq), k / v (B, heads*64, 1, Sk) f16 BC1S,
  * ln_weight / ln_bias (C) f32 as in the checkpoint (x_hat * w + b), wq (C, C) f16 -> out (B, C, 1, Sq) f16.  nst: LDS-DMA
  * ring depth 2-4 (0 = heuristic). */
 int sd_op_cross_attention_fused(const void* x, const float* ln_weight, const float* ln_bias, const void* wq, const void* k,

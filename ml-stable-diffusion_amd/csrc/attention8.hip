@@ -15,10 +15,11 @@
 //     computes the scores of tile j+1 (second score accumulator), and the row max of tile j+1 is taken in the shadow of
 //     P.V of tile j - every phase pairs 4-8 MFMAs with 20-60 independent VALU instructions (sched_group_barrier), so the
 //     two co-resident waves of a SIMD fill each other's pipes whatever their relative phase.
-// The three reference schedules keep their numerical signatures: ORIGINAL refreshes the running max lazily (only when a
-// tile exceeds it by more than 2^8: P <= 256 is fp16-safe and the softmax is invariant to the stabiliser), the SPLIT_EINSUM
-// schedules refresh it on every tile where any row's max moved; SPLIT_EINSUM_V2's 512-query chunks are two 256-query
-// workgroups.  fp32 running max / sum / accumulators, fp16 operands, scale * log2(e) folded into one FMA before v_exp_f32.
+// All three reference schedules of these shapes run here (the score tile never leaves registers, so "bhqk" vs "bkhq" is a
+// choice of register layout, not of arithmetic): the running max is refreshed lazily - only when a tile exceeds it by more
+// than 2^8; P <= 256 is fp16-safe and the softmax is invariant to the stabiliser (a refresh on every tile where any row's
+// max moved, the SPLIT_EINSUM kernels' rule, measured 89 vs 70 us on the L0 shape: the refresh is 80 VALU instructions);
+// SPLIT_EINSUM_V2's 512-query chunks are two 256-query workgroups.  fp32 running max / sum / accumulators, fp16 operands.
 #include "kernels.h"
 
 #include <cstdlib>
@@ -65,7 +66,7 @@ __device__ __forceinline__ float xor32_sum(float v) {
 }
 __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }   // one v_max3_f32
 
-// EXACT: SPLIT_EINSUM schedules (running max refreshed whenever it moved); else ORIGINAL's lazy refresh.
+// EXACT (kept for A/B, SD_ATTN8_EXACT=1): running max refreshed whenever it moved instead of the lazy refresh.
 //
 // VALU diet.  Measured on the first version of this kernel (profiles/r04_attn8_ablation_v1.txt): the loop was bound by the
 // VECTOR ALU's instruction stream - 186 VALU instructions per key tile and wave against 16 MFMAs, two waves per SIMD - not
@@ -393,7 +394,7 @@ bool attention8_ok(const AttnDesc& d) {
 
 void launch_attention8(const AttnDesc& d, hipStream_t s) {
   Attn8Args a{d.q, d.k, d.vt, d.out, d.heads, d.Sq, d.Sk, d.ldq, d.ldk, d.ldv, d.ldo, 1.4426950408889634f / 8.0f, 0};
-  const bool exact = d.impl != kAttnOriginal;
+  static const bool exact = getenv("SD_ATTN8_EXACT") && atoi(getenv("SD_ATTN8_EXACT")) != 0;
   // 256-query workgroups when they give at least half the CUs one, else 128-query ones: more, smaller workgroups
   const long wg8 = (long)d.B * d.heads * cdiv(d.Sq, 256);
   static const int force = getenv("SD_ATTN8_WAVES") ? atoi(getenv("SD_ATTN8_WAVES")) : 0;
