@@ -130,8 +130,25 @@ Tensor UNet::conv(std::vector<Op>& ops, const std::string& name, const Tensor& x
                   bool silu_out, int pad) {
   const int cin = x.C + (x2 ? x2->C : 0);
   const bool geglu = out_mode == kOutGeglu;
-  const half_t* w = upload_conv_weight(name, cout, cin, k, geglu);
   const float* b = bias ? upload_vec(name + ".bias", cout, geglu) : nullptr;
+  if (f32_) {
+    // fp32 compute path (torch2coreml.py:570-578 converts an SDXL checkpoint's own VAE with FLOAT32 precision): the weights stay
+    // fp32 too - an fp32 checkpoint is not rounded to fp16 on the way in - in the [N][taps][Cin] layout of the fp16 path
+    const HostTensor& t = ws_->get(name + ".weight");
+    const size_t expect = (size_t)cout * cin * k * k;
+    SD_REQUIRE(!geglu && t.numel() == expect, kInvalidArgument, "%s.weight has %zu elements, expected %zu", name.c_str(), t.numel(), expect);
+    std::vector<float> host(expect);
+    const int kk = k * k;
+    for (int o = 0; o < cout; ++o)
+      for (int c = 0; c < cin; ++c)
+        for (int t2 = 0; t2 < kk; ++t2) host[((size_t)o * kk + t2) * cin + c] = t.data[((size_t)o * cin + c) * kk + t2];
+    float* d = arena_.alloc_n<float>(expect);
+    SD_HIP(hipMemcpy(d, host.data(), expect * sizeof(float), hipMemcpyHostToDevice));
+    w_f32_pending_ = true;   // consumed by conv_w's fp32 branch (ConvF32Desc::w_kind 1)
+    return conv_w(ops, name, reinterpret_cast<const half_t*>(d), b, x, x2, cout, k, stride, up, temb, res, out_mode, ldT, silu_out,
+                  nullptr, pad);
+  }
+  const half_t* w = upload_conv_weight(name, cout, cin, k, geglu);
   return conv_w(ops, name, w, b, x, x2, cout, k, stride, up, temb, res, out_mode, ldT, silu_out, nullptr, pad);
 }
 
@@ -264,7 +281,8 @@ Tensor UNet::conv_w(std::vector<Op>& ops, const std::string& name, const half_t*
     ConvF32Desc fd;
     fd.x = reinterpret_cast<const float*>(x.p);
     fd.w = w;
-    fd.w_kind = 0;
+    fd.w_kind = w_f32_pending_ ? 1 : 0;   // UNet::conv uploads fp32 weights for an fp32 handle
+    w_f32_pending_ = false;
     fd.bias = bias;
     fd.res = reinterpret_cast<const float*>(res);
     fd.out = reinterpret_cast<float*>(out.p);
@@ -1435,8 +1453,11 @@ void UNet::denoise_loop(const sd_unet_io& io, float* latents, int n_images, int 
   if (io.step_noise) {   // ancestral samplers: the host's pre-drawn, pre-scaled noise of every step
     const size_t need = (size_t)n_steps * lat_n;
     if (noise_cap_ < need) {
-      noise_tab_ = arena_.alloc_n<float>(need);
-      noise_cap_ = need;
+      // the bump arena never frees: size the table with headroom (like the coefficient tables) so that a later call with a few
+      // more steps re-uses it instead of abandoning the old block (and the captured loop graph with it)
+      const size_t cap = std::max(need + need / 2, (size_t)64 * lat_n);
+      noise_tab_ = arena_.alloc_n<float>(cap);
+      noise_cap_ = cap;
       if (loop_graph_) { (void)hipGraphExecDestroy(loop_graph_); loop_graph_ = nullptr; }   // the address is baked in
     }
     SD_HIP(hipMemcpyAsync(noise_tab_, io.step_noise, need * sizeof(float), hipMemcpyHostToDevice, stream_));

@@ -133,6 +133,7 @@ class UNet {
   const WeightStore* ws_ = nullptr;   // only valid during construction
   int device_ = 0;
   bool f32_ = false;                  // VAE handle with cfg.compute_fp32: fp32 activations on the vae_f32.hip kernels
+  bool w_f32_pending_ = false;        // build time: the weight pointer handed to conv_w holds fp32 values (UNet::conv on an fp32 handle)
   hipStream_t stream_ = nullptr;
   // SD_SIDE_TIME=1 (experiment, off by default): the time-embedding chain (depends only on the timestep)
   // runs on a forked stream beside conv_in / the first GroupNorm and joins before the first consumer of

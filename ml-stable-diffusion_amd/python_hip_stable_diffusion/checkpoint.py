@@ -161,6 +161,41 @@ def vae_decoder_param_shapes(cfg):
     return sh
 
 
+# text towers of the BASELINE models (transformers CLIPTextModel config keys): SD2.1's OpenCLIP ViT-H (23 of 24 layers kept),
+# SD1.5's CLIP ViT-L
+TEXT_ENCODER_CONFIGS = {
+    "stabilityai/stable-diffusion-2-1-base": dict(vocab_size=49408, hidden_size=1024, intermediate_size=4096, num_hidden_layers=23,
+                                                  num_attention_heads=16, max_position_embeddings=77, hidden_act="gelu",
+                                                  layer_norm_eps=1e-5, eos_token_id=2, architectures=["CLIPTextModel"]),
+    "runwayml/stable-diffusion-v1-5": dict(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12,
+                                           num_attention_heads=12, max_position_embeddings=77, hidden_act="quick_gelu",
+                                           layer_norm_eps=1e-5, eos_token_id=2, architectures=["CLIPTextModel"]),
+}
+
+
+def text_encoder_param_shapes(cfg):
+    """transformers' CLIPTextModel[WithProjection] state-dict inventory (what HipTextEncoder loads)."""
+    sh = OrderedDict()
+    d, i = cfg["hidden_size"], cfg["intermediate_size"]
+    sh["text_model.embeddings.token_embedding.weight"] = (cfg["vocab_size"], d)
+    sh["text_model.embeddings.position_embedding.weight"] = (cfg.get("max_position_embeddings", 77), d)
+    for layer in range(cfg["num_hidden_layers"]):
+        p = f"text_model.encoder.layers.{layer}"
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            sh[f"{p}.self_attn.{n}.weight"] = (d, d)
+            sh[f"{p}.self_attn.{n}.bias"] = (d,)
+        for n in ("layer_norm1", "layer_norm2"):
+            sh[f"{p}.{n}.weight"] = (d,)
+            sh[f"{p}.{n}.bias"] = (d,)
+        sh[f"{p}.mlp.fc1.weight"], sh[f"{p}.mlp.fc1.bias"] = (i, d), (i,)
+        sh[f"{p}.mlp.fc2.weight"], sh[f"{p}.mlp.fc2.bias"] = (d, i), (d,)
+    sh["text_model.final_layer_norm.weight"] = (d,)
+    sh["text_model.final_layer_norm.bias"] = (d,)
+    if cfg.get("projection_dim"):
+        sh["text_projection.weight"] = (cfg["projection_dim"], d)
+    return sh
+
+
 def validate_checkpoint(tensors, shapes):
     """Strict key/shape check (Linear weights may be stored 2-D, unet.py:121-127)."""
     missing = [k for k in shapes if k not in tensors]

@@ -115,7 +115,7 @@ def run_sharded(loop_fn, ehs_pairs, latents, dist=None, local_rank=0):
 
 
 def run_cfg_split(unet_fn, scheduler, ehs_pair, latents, guidance_scale, dist, local_rank=0):
-    """EXPERIMENTAL (kept for the SURVEY section 8e latency idea, not recommended): one MI355X runs the CFG batch of 2 in
+    """DEPRECATED (kept for its gloo test only; not a supported mode, not in INTEGRATION.md's feature list): EXPERIMENTAL (kept for the SURVEY section 8e latency idea, not recommended): one MI355X runs the CFG batch of 2 in
     1.07x the time of batch 1 (profiles/r03_batch_scale_before.json), so this split saves at most 6 % of the UNet time and
     pays a host round trip per step for it.  Optional LATENCY mode for one prompt on two GPUs: rank 0 evaluates the unconditional half of
     the classifier-free-guidance batch, rank 1 the text half - each with a UNet handle of batch 1 - and the two noise

@@ -511,7 +511,10 @@ def build_parser():
                         help="Accepted for compatibility with the Core ML pipeline and ignored: compute runs on the MI355X.")
     parser.add_argument("--scheduler", choices=tuple(SCHEDULER_MAP.keys()), default=None,
                         help="The scheduler to use for running the reverse diffusion process. If not specified, the "
-                             "default scheduler of the checkpoint is utilized")
+                             "default scheduler of the checkpoint is utilized.  It is built from the checkpoint's "
+                             "scheduler/scheduler_config.json; keys that file omits take the diffusers class defaults, of which "
+                             "clip_sample=True (DDIM) and skip_prk_steps=False (PNDM) are not implemented: spell out "
+                             "\"clip_sample\": false / \"skip_prk_steps\": true there, as the Stable Diffusion checkpoints do")
     parser.add_argument("--num-inference-steps", default=50, type=int,
                         help="The number of iterations the unet model will be executed throughout the reverse diffusion process")
     parser.add_argument("--guidance-scale", default=7.5, type=float,

@@ -37,7 +37,12 @@ def test_kernel_families_and_dominant_kernel_by_time_share():
 
 
 def test_traffic_is_reported_only_for_the_profiled_build_and_workload():
-    path = os.path.join(ROOT, "profiles", "r03_final_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", bench.HBM_TRAFFIC_FILE)
+    if not os.path.exists(path):   # no PMC pass committed (yet) for this round's library: nothing may be reported
+        args = argparse.Namespace(model="sd21-base", prompts_per_gpu=1, attention="ORIGINAL")
+        got = bench.hbm_traffic(5.0, args, 64)
+        assert got["traffic"] is None and got["traffic_source"] is None
+        return
     t = json.load(open(path))
     for key in ("build_id", "model", "latent", "prompts_per_gpu", "attention", "bytes_per_step", "read_bytes_per_step"):
         assert key in t, key
@@ -45,6 +50,7 @@ def test_traffic_is_reported_only_for_the_profiled_build_and_workload():
     got = bench.hbm_traffic(5.0, args, t["latent"])
     if bench.build_id() == t["build_id"]:            # the committed file belongs to the committed source
         assert got["traffic"] == t["bytes_per_step"] and 0.1 < got["traffic_detail"]["hbm_frac"] < 1.0
+        assert "replayed from profiles/" in got["traffic_source"] and "NOT measured by this run" in got["traffic_source"]
     else:
         assert got["traffic"] is None
     for other in (argparse.Namespace(model="sdxl-base", prompts_per_gpu=1, attention="ORIGINAL"),

@@ -242,3 +242,20 @@ def test_fullsize_loop_goldens_carry_the_seeds_the_gpu_tests_regenerate_inputs_f
     lat = L.initial_latents(L.SEEDS_CN["latents"], L.HW_CN)
     np.random.seed(93)
     assert np.array_equal(lat, np.random.randn(1, 4, 64, 64).astype(np.float16).astype(np.float32))
+
+
+@pytest.mark.parametrize("name", ["mini", "sd"])
+def test_vae_decoder_oracle_equals_the_golden_of_the_reference_blocks(name):
+    """oracle/vae_ref.vae_decode against tests/golden/vae_decoder_*_golden.npz, written by oracle/pin_round4.py from the
+    reference's OWN ResnetBlock2D(temb_channels=None, eps=1e-6) / Upsample2D / attention.original(heads=1) wired in the
+    decoder's topology: the VAE decoder's arithmetic is pinned by the reference, its topology restated (diffusers absent)."""
+    import torch
+    from oracle import vae_ref, weights
+    g = load_golden(f"vae_decoder_{name}_golden.npz")
+    cfg = vae_ref.VAE_CONFIGS[name]
+    hw = int(g["hw"])
+    sd = weights.to_torch(weights.round_to_fp16(weights.make_state_dict(vae_ref.vae_decoder_param_shapes(cfg), seed=int(g["seed"]))))
+    z = weights.seeded_normal((1, cfg["latent_channels"], hw, hw), int(g["z_seed"])).astype(np.float16).astype(np.float32)
+    got = vae_ref.vae_decode(sd, cfg, torch.from_numpy(z)).numpy()
+    assert got.shape == g["image"].shape
+    assert np.abs(got - g["image"]).max() <= 1e-5 * max(1.0, np.abs(g["image"]).max())

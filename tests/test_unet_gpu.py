@@ -16,6 +16,8 @@ from python_hip_stable_diffusion import HipModel, schedulers
 
 pytestmark = pytest.mark.gpu
 IMPLS = ["ORIGINAL", "SPLIT_EINSUM", "SPLIT_EINSUM_V2"]
+# SD1.5 ControlNet residuals, full size: gate = measured - 6 dB (round 4: the 13 residuals measured %s dB, the minimum sets the gate)
+CONTROLNET_GATE_DB = 50.0
 
 
 def synthetic_checkpoint(shapes, seed):
@@ -249,8 +251,22 @@ def test_full_sd15_control_unet_and_controlnet_match_reference_golden():
              encoder_hidden_states=weights.seeded_normal((2, 768, 1, 77), 73).astype(np.float16),
              controlnet_cond=np.random.RandomState(74).rand(2, 3, 512, 512).astype(np.float16))
     stride = int(gc["stride"])
-    for i in range(13):
+    for i in range(13):   # the reference module's own outputs (a strided channel subset: the fixture stays small)
         ref = gc[f"additional_residual_{i}"].astype(np.float32)
         p = psnr.compute_psnr(out[f"additional_residual_{i}"][:, ::stride], ref)
-        assert p >= 50.0, f"sd15 ControlNet residual {i}: PSNR {p:.1f} dB"
+        assert p >= CONTROLNET_GATE_DB, f"sd15 ControlNet residual {i}: PSNR {p:.1f} dB vs the reference golden"
     cn.close()
+    # ... and the FULL tensors against the oracle run live on the same inputs (the oracle is pinned to the reference on this
+    # very model by oracle/pin_against_reference.py --control, max |oracle - reference| <= 4e-6)
+    sdc = weights.to_torch({k: v.astype(np.float32) for k, v in
+                            synthetic_checkpoint(unet_ref.controlnet_param_shapes(cfg), int(gc["seed"])).items()})
+    full = unet_ref.controlnet_forward(
+        sdc, cfg, torch.from_numpy(weights.seeded_normal((2, 4, 64, 64), 72).astype(np.float16).astype(np.float32)),
+        torch.tensor([981.0, 981.0]), torch.from_numpy(weights.seeded_normal((2, 768, 1, 77), 73).astype(np.float16).astype(np.float32)),
+        torch.from_numpy(np.random.RandomState(74).rand(2, 3, 512, 512).astype(np.float16).astype(np.float32)))
+    for i in range(13):
+        ref = full[i].numpy()
+        assert np.abs(ref[:, ::stride] - gc[f"additional_residual_{i}"]).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+        p = psnr.compute_psnr(out[f"additional_residual_{i}"], ref)
+        assert p >= CONTROLNET_GATE_DB, f"sd15 ControlNet residual {i} (full tensor): PSNR {p:.1f} dB vs the oracle"
+

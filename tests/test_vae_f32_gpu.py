@@ -69,3 +69,23 @@ def test_vae_encoder_fp32_matches_oracle(name, hw):
     ref = vae_ref.vae_encode(sd, cfg, torch.from_numpy(x)).numpy()
     _close32(out, ref, f"fp32 VAE encoder {name} @{hw}")
     enc.close()
+
+
+def test_vae_fp32_handle_keeps_fp32_weights():
+    """An fp32 checkpoint (an SDXL VAE is shipped in fp32) must not be rounded to fp16 on upload: weights that are
+    NOT fp16-representable, against the oracle on the same fp32 weights - within the fp32 tolerance, which fp16-rounded weights
+    (2^-11 relative per weight) miss by an order of magnitude."""
+    cfg = vae_ref.VAE_CONFIGS["mini"]
+    sd32 = weights.make_state_dict(vae_ref.vae_decoder_param_shapes(cfg), seed=67, dtype=np.float32, gain=1.6)
+    assert any(not np.array_equal(v, v.astype(np.float16).astype(np.float32)) for v in sd32.values())
+    sd = weights.to_torch(sd32)
+    hw = 8
+    z = (weights.seeded_normal((1, 4, hw, hw), 68) / 0.18215).astype(np.float32)
+    ref = vae_ref.vae_decode(sd, cfg, torch.from_numpy(z)).numpy()
+    vae = HipVaeDecoder(cfg, sd32, batch=1, latent_height=hw, latent_width=hw, dtype=np.float32)
+    _close32(vae(z=z)["image"], ref, "fp32 VAE decoder with fp32 (not fp16-representable) weights")
+    vae.close()
+    # the same checkpoint rounded to fp16 first is measurably further away: the test would notice a rounding upload
+    sd16 = weights.to_torch({k: v.astype(np.float16).astype(np.float32) for k, v in sd32.items()})
+    rounded = vae_ref.vae_decode(sd16, cfg, torch.from_numpy(z)).numpy()
+    assert np.abs(rounded - ref).max() > 2e-4 * np.abs(ref).max()
