@@ -16,8 +16,9 @@ from python_hip_stable_diffusion import HipModel, schedulers
 
 pytestmark = pytest.mark.gpu
 IMPLS = ["ORIGINAL", "SPLIT_EINSUM", "SPLIT_EINSUM_V2"]
-# SD1.5 ControlNet residuals, full size: gate = measured - 6 dB (round 4: the 13 residuals measured %s dB, the minimum sets the gate)
-CONTROLNET_GATE_DB = 50.0
+# SD1.5 ControlNet residuals at full size: gate = measured - 6 dB (round 4, gpurun_out/psnr_r4e.tsv: the 13 residuals measured
+# 81.7 / 76.3 / 74.3 / 74.4 / 74.1 / 71.9 / 71.3 / 70.7 / 70.7 / 69.7 / 72.5 / 68.6 / 68.6 dB; the minimum sets the gate; was 50)
+CONTROLNET_GATE_DB = 62.5
 
 
 def synthetic_checkpoint(shapes, seed):
@@ -266,7 +267,8 @@ def test_full_sd15_control_unet_and_controlnet_match_reference_golden():
         torch.from_numpy(np.random.RandomState(74).rand(2, 3, 512, 512).astype(np.float16).astype(np.float32)))
     for i in range(13):
         ref = full[i].numpy()
-        assert np.abs(ref[:, ::stride] - gc[f"additional_residual_{i}"]).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+        # (the golden stores the reference module's output rounded to fp16: half an fp16 ulp of the largest value)
+        assert np.abs(ref[:, ::stride] - gc[f"additional_residual_{i}"]).max() <= 1e-3 * max(1.0, np.abs(ref).max())
         p = psnr.compute_psnr(out[f"additional_residual_{i}"], ref)
         assert p >= CONTROLNET_GATE_DB, f"sd15 ControlNet residual {i} (full tensor): PSNR {p:.1f} dB vs the oracle"
 
