@@ -42,6 +42,11 @@ UNet::UNet(const sd_unet_config& cfg, const WeightStore& ws, int device) : cfg_(
     SD_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
     SD_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
   }
+  if (cfg_.support_controlnet && !cfg_.is_controlnet && !(getenv("SD_CN_CONCURRENT") && atoi(getenv("SD_CN_CONCURRENT")) == 0)) {
+    SD_HIP(hipStreamCreateWithFlags(&cn_stream_, hipStreamNonBlocking));
+    SD_HIP(hipEventCreateWithFlags(&ev_cn_fork_, hipEventDisableTiming));
+    SD_HIP(hipEventCreateWithFlags(&ev_cn_join_, hipEventDisableTiming));
+  }
   f32_ = cfg_.compute_fp32 != 0;
   SD_REQUIRE(!f32_ || cfg_.is_vae_decoder, kUnsupported,
              "compute_fp32 is the VAE graphs' option (torch2coreml.py:570-578, :726-733); the UNet kernels store fp16");
@@ -68,6 +73,12 @@ UNet::~UNet() {
     (void)hipStreamDestroy(side_);
     (void)hipEventDestroy(ev_fork_);
     (void)hipEventDestroy(ev_join_);
+  }
+  if (cn_stream_) {
+    (void)hipStreamSynchronize(cn_stream_);
+    (void)hipStreamDestroy(cn_stream_);
+    (void)hipEventDestroy(ev_cn_fork_);
+    (void)hipEventDestroy(ev_cn_join_);
   }
 }
 
@@ -749,6 +760,7 @@ void UNet::build_unet() {
           }
         });
         main_ops_.back().label = "controlnet residual add " + std::to_string(i);
+        if (cn_join_pos_ < 0) cn_join_pos_ = (int)main_ops_.size() - 1;   // first consumer of the ControlNets' outputs
         added.push_back(sum);
       }
       for (size_t i = 0; i < skips.size(); ++i) skips[i] = added[i];
@@ -1128,24 +1140,30 @@ struct EventList {
 };
 }  // namespace
 
-void UNet::run_time_and_main() {
-  if (!side_ || time_ops_.empty() || temb_join_pos_ < 0) {
-    run_ops(time_ops_);
-    run_ops(main_ops_);
-    return;
+void UNet::run_time_and_main() { run_main(true); }
+
+void UNet::run_main(bool with_time) {
+  const bool fork_time = with_time && side_ && !time_ops_.empty() && temb_join_pos_ >= 0;
+  if (with_time && !fork_time) run_ops(time_ops_);
+  if (fork_time) {
+    // fork: the side stream sees everything queued so far (the timestep buffer), runs the embedding
+    // MLP + the batched time_emb_proj GEMV, and the main stream waits for it only where the first
+    // ResNet conv adds its slice.  Works eagerly and under stream capture (the side stream joins the
+    // capture through the event and is joined back before the capture ends).
+    SD_HIP(hipEventRecord(ev_fork_, stream_));
+    SD_HIP(hipStreamWaitEvent(side_, ev_fork_, 0));
+    for (auto& op : time_ops_) op(side_);
+    SD_HIP(hipEventRecord(ev_join_, side_));
   }
-  // fork: the side stream sees everything queued so far (the timestep buffer), runs the embedding
-  // MLP + the batched time_emb_proj GEMV, and the main stream waits for it only where the first
-  // ResNet conv adds its slice.  Works eagerly and under stream capture (the side stream joins the
-  // capture through the event and is joined back before the capture ends).
-  SD_HIP(hipEventRecord(ev_fork_, stream_));
-  SD_HIP(hipStreamWaitEvent(side_, ev_fork_, 0));
-  for (auto& op : time_ops_) op(side_);
-  SD_HIP(hipEventRecord(ev_join_, side_));
   for (size_t i = 0; i < main_ops_.size(); ++i) {
-    if ((int)i == temb_join_pos_) SD_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));
+    if (fork_time && (int)i == temb_join_pos_) SD_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));
+    if (cn_join_pending_ && (int)i == cn_join_pos_) {   // the attached ControlNets (run_attached) are done: their residuals may be read
+      SD_HIP(hipStreamWaitEvent(stream_, ev_cn_join_, 0));
+      cn_join_pending_ = false;
+    }
     main_ops_[i](stream_);
   }
+  SD_REQUIRE(!cn_join_pending_, kInternal, "forked ControlNets were never joined");
 }
 
 // ---- device-resident ControlNet hand-off ---------------------------------------------------------
@@ -1210,7 +1228,17 @@ void UNet::run_as_controlnet(hipStream_t s, const half_t* x_nhwc, const float* t
 }
 
 void UNet::run_attached() {
-  for (UNet* cn : attached_) cn->run_as_controlnet(stream_, x_in_.p, tbuf_);
+  if (attached_.empty()) return;
+  if (!cn_stream_ || cn_join_pos_ < 0) {   // serial (SD_CN_CONCURRENT=0)
+    for (UNet* cn : attached_) cn->run_as_controlnet(stream_, x_in_.p, tbuf_);
+    return;
+  }
+  // fork behind the sample / timestep hand-over (everything queued on stream_ so far); run_main joins in front of the first residual add
+  SD_HIP(hipEventRecord(ev_cn_fork_, stream_));
+  SD_HIP(hipStreamWaitEvent(cn_stream_, ev_cn_fork_, 0));
+  for (UNet* cn : attached_) cn->run_as_controlnet(cn_stream_, x_in_.p, tbuf_);
+  SD_HIP(hipEventRecord(ev_cn_join_, cn_stream_));
+  cn_join_pending_ = true;
 }
 
 void UNet::upload_inputs(const sd_unet_io& io, bool loop_mode) {
@@ -1466,8 +1494,7 @@ void UNet::denoise_loop(const sd_unet_io& io, float* latents, int n_images, int 
   auto step_ops = [&]() {
     launch_loop_prep(latents_, x_in_.p, tbuf_, tab, n_images, C, H, W, cfgmul, stream_);
     run_attached();
-    if (hoist) run_ops(main_ops_);
-    else run_time_and_main();
+    run_main(!hoist);
     launch_cfg_sched_step(noise_pred_, latents_, eps_hist_, tab, guidance, n_images, C * H * W, cfgmul, history,
                           stream_);
   };

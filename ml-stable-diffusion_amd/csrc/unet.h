@@ -127,6 +127,7 @@ class UNet {
   hipGraphExec_t capture(const std::function<void()>& body);
   void run_forward_ops();
   void run_time_and_main();   // time_ops_ (optionally on the forked side stream) + main_ops_
+  void run_main(bool with_time);   // main_ops_ [behind time_ops_] with the joins of the forked time path / ControlNets in place
   void ensure_graph();
 
   sd_unet_config cfg_;
@@ -141,6 +142,14 @@ class UNet {
   hipStream_t side_ = nullptr;
   hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   int temb_join_pos_ = -1;
+  // Attached ControlNets run CONCURRENTLY with this UNet's time path and down / mid blocks (pipeline.py:519-529 evaluates them
+  // back to back; nothing in the UNet depends on them before the residual adds of unet.py:1009-1022): they are forked onto
+  // cn_stream_ behind the sample / timestep hand-over and joined in front of the first residual add (main_ops_[cn_join_pos_]) -
+  // eagerly and inside the captured step graphs alike.  SD_CN_CONCURRENT=0 keeps the serial order (A/B).
+  hipStream_t cn_stream_ = nullptr;
+  hipEvent_t ev_cn_fork_ = nullptr, ev_cn_join_ = nullptr;
+  int cn_join_pos_ = -1;
+  bool cn_join_pending_ = false;
   Arena arena_;
 
   // static-shape input/output device buffers
