@@ -1,4 +1,6 @@
 """Round-4 GPU tests: kernels added this round, called through the C ABI, against the oracle / torch on seeded inputs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -92,3 +94,4 @@ def test_vae_decoder_matches_the_golden_of_the_reference_blocks(name):
     p = psnr.compute_psnr(out, g["image"])
     assert out.shape == g["image"].shape and p >= 60.0, f"VAE decoder {name}: PSNR {p:.1f} dB vs the reference-block golden"
     vae.close()
+
