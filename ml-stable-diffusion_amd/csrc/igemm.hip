@@ -787,8 +787,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
 // not the MFMA pipe - bounds it.  Here a workgroup owns an 8x16-pixel output tile: per 64-channel
 // chunk it stages the 10x18 halo ONCE (23 KB, reused by all nine taps) plus one 16-KB weight tile
 // per tap -> 167 KB instead of 288 KB per nine K steps.  The tap is a shift of the fragment's LDS
-// row; swizzle, MFMA tiling and the LDS-staged epilogue are those of igemm_kernel.  The next chunk's
-// halo streams in as one 1-KB DMA piece per wave per tap.
+// row.  The next chunk's halo streams in as one 1-KB DMA piece per wave per tap.
+// (Round 2's first halo kernel - one wave per 32x64 sub-tile, fragments read and waited for before the MFMAs, plan tiles
+// 5 / 6 - lost to the K-split kernel below on every shape of every model and was removed in round 4; its ablation is
+// profiles/r02_ablate_halo.txt.)
 // ---------------------------------------------------------------------------------------------
 constexpr int HALO_W = 18, HALO_ROWS = 180, HALO_PIECES = 23, HALO_LDS_ROWS = 184, HALO_PPW = 6;
 
@@ -798,292 +800,14 @@ __device__ __forceinline__ void wait_vmcnt_barrier() {   // counted wait + raw b
 }
 constexpr int halo_mod9(int t) { return ((t % 9) + 9) % 9; }
 constexpr int halo_x_issued(int tap) { return halo_mod9(tap) < HALO_PPW ? 1 : 0; }
-// VMEM ops one wave has issued AFTER the weight tile of step s (tap `tap`) in steady state: per step, in order,
-// [WR weight pieces of step s+D-1] then [one halo piece of the next chunk when tap < HALO_PPW].  At tap 0 the halo
-// of this chunk must have landed too; its last piece went out at tap 5 of the previous chunk (3 steps = 3*WR ops ago).
-template <int D, int WR>
-constexpr int halo_wait_count(int tap) {
-  int n = halo_x_issued(tap - D + 1);
-  for (int i = 2; i <= D - 1; ++i) n += WR + halo_x_issued(tap - D + i);
-  if (tap == 0 && n > 3 * WR) n = 3 * WR;
-  return n;
-}
-
-template <int D, int WR>
-__device__ __forceinline__ void halo_wait(int tap) {   // folds to one wait once the tap loop is unrolled
-  switch (tap) {
-    case 0: wait_vmcnt_barrier<halo_wait_count<D, WR>(0)>(); break;
-    case 1: wait_vmcnt_barrier<halo_wait_count<D, WR>(1)>(); break;
-    case 2: wait_vmcnt_barrier<halo_wait_count<D, WR>(2)>(); break;
-    case 3: wait_vmcnt_barrier<halo_wait_count<D, WR>(3)>(); break;
-    case 4: wait_vmcnt_barrier<halo_wait_count<D, WR>(4)>(); break;
-    case 5: wait_vmcnt_barrier<halo_wait_count<D, WR>(5)>(); break;
-    case 6: wait_vmcnt_barrier<halo_wait_count<D, WR>(6)>(); break;
-    case 7: wait_vmcnt_barrier<halo_wait_count<D, WR>(7)>(); break;
-    default: wait_vmcnt_barrier<halo_wait_count<D, WR>(8)>(); break;
-  }
-}
-
 // D = stages of the weight ring (D - 1 tap steps of weights in flight; 2 = the round-1 double buffer).
 constexpr size_t halo_lds_bytes(int bn, int d) {
   return ((size_t)2 * HALO_LDS_ROWS * BK + (size_t)d * bn * BK) * sizeof(half_t) + bn * sizeof(float);
 }
-// two workgroups per CU (two waves per SIMD, <= 256 VGPRs) wherever the LDS footprint allows it
-// DBG (microbench-only instantiations, tools/ablate_halo.py): bit 0 no MFMAs, bit 1 no fragment reads, bit 2 no weight DMA
-// after the prologue, bit 3 no halo DMA after the prologue (results are garbage; only the time is read)
-template <int BN, int D, int DBG = 0>
-__global__ __launch_bounds__(256, halo_lds_bytes(BN, D) <= 80 * 1024 ? 2 : 1) void conv3x3_halo_kernel(IgemmArgs a) {
-  constexpr int BM = 128, TM = 2, TN = BN / 64, WR = BN / 32;
-  static_assert(halo_wait_count<D, WR>(1) <= 63 && (D - 2) * WR + 6 <= 63, "vmcnt range");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  half_t* Xh = reinterpret_cast<half_t*>(smem);                  // [2][HALO_LDS_ROWS][BK]
-  half_t* Ws = Xh + 2 * HALO_LDS_ROWS * BK;                      // [D][BN][BK]
-  float* sconst = reinterpret_cast<float*>(Ws + D * BN * BK);    // [BN] bias + timestep-embedding row of this tile's sample
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int H = a.Hi, W = a.Wi;
-
-  const int n_tiles = (a.N + BN - 1) / BN;
-  const int m_tiles = a.B * a.tiles_y * a.tiles_x;
-  const int nwg = m_tiles * n_tiles;
-  int bid = blockIdx.x;
-  {
-    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    bid = base + idx;
-  }
-  const int bn_idx = a.n_fast ? bid % n_tiles : bid / m_tiles, mt = a.n_fast ? bid / n_tiles : bid % m_tiles;
-  const int b = mt / (a.tiles_y * a.tiles_x);
-  const int trem = mt - b * (a.tiles_y * a.tiles_x);
-  const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
-  const int y0 = ty * 8, x0 = tx * 16;
-  const int n_blk = bn_idx * BN;
-
-  const int nch = a.Ctot / BK;
-  const int split = blockIdx.y;
-  const int ch_begin = split * a.nk_per_split;          // split-K over channel chunks
-  int ch_end = ch_begin + a.nk_per_split;
-  if (ch_end > nch) ch_end = nch;
-
-  const half_t* const zeros = a.zeros;
-  // this wave's halo pieces p = wave + 4j (8 halo rows = 1 KiB each); lane -> (row, 16-B slot)
-  int hpix[HALO_PPW], hchunk[HALO_PPW];
-#pragma unroll
-  for (int j = 0; j < HALO_PPW; ++j) {
-    const int p = (wave + 4 * j < HALO_PIECES) ? wave + 4 * j : HALO_PIECES - 1;
-    const int hr = 8 * p + (lane >> 3);
-    const int hy = hr / HALO_W, hx = hr - hy * HALO_W;
-    const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-    const bool ok = (hr < HALO_ROWS) && iy >= 0 && iy < H && ix >= 0 && ix < W;
-    hpix[j] = ok ? (b * H + iy) * W + ix : -1;
-    hchunk[j] = (lane & 7) ^ ((hr >> 1) & 7);
-  }
-  const int pchunk = tid & 7, lrow = tid >> 3;
-  const int wchunk = pchunk ^ ((lrow >> 1) & 7);
-  const half_t* wrow[WR];
-#pragma unroll
-  for (int i = 0; i < WR; ++i) {
-    const int n = n_blk + lrow + 32 * i;
-    wrow[i] = (n < a.N) ? a.w + (size_t)n * a.K + wchunk * 8 : nullptr;
-  }
-
-  auto issue_x_piece = [&](int j, int ch, int xstage) {
-    // every wave issues exactly HALO_PPW pieces per chunk (the counted vmcnt waits rely on it): the one piece
-    // index past the halo (wave 3, j = 5) re-loads piece 22 - same bytes to the same LDS rows
-    const int p = wave + 4 * j;
-    int cc = ch * BK;
-    const half_t* src = a.x0;
-    int Csrc = a.C0;
-    if (cc >= a.C0) {
-      src = a.x1;
-      cc -= a.C0;
-      Csrc = a.C1;
-    }
-    const half_t* ptr = (hpix[j] >= 0) ? src + (size_t)hpix[j] * Csrc + cc + hchunk[j] * 8 : zeros;
-    char* dst = reinterpret_cast<char*>(Xh + xstage * HALO_LDS_ROWS * BK) + (p < HALO_PIECES ? p : HALO_PIECES - 1) * 1024;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ptr,
-                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-  };
-  auto issue_w = [&](int ch, int tap, int wstage) {
-    const int koff = tap * a.Ctot + ch * BK;
-    char* ws = reinterpret_cast<char*>(Ws + wstage * BN * BK) + wave * 1024;
-#pragma unroll
-    for (int i = 0; i < WR; ++i) {
-      const half_t* ptr = wrow[i] ? wrow[i] + koff : zeros;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ptr,
-                                       (__attribute__((address_space(3))) void*)(ws + i * 4096), 16, 0, 0);
-    }
-  };
-
-  floatx16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int frow = lane & 31, hi = lane >> 5;
-  const int fsw = (frow >> 1) & 7;
-  int hr0[TM];                                          // halo row of this lane's pixel for the (0,0) tap
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int ml = (wm * TM + i) * 32 + frow;
-    hr0[i] = (ml >> 4) * HALO_W + (ml & 15);
-  }
-
-  // per-column epilogue constants: loaded first (oldest VMEM ops), used after the K loop
-  float const_b = 0.f, const_t = 0.f;
-  if (a.splitk == 1 && tid < BN && n_blk + tid < a.N) {
-    if (a.bias) const_b = a.bias[n_blk + tid];
-    if (a.temb) const_t = a.temb[(size_t)b * a.temb_stride + n_blk + tid];
-  }
-  // weight-ring issue cursor: the next (chunk, tap) to fetch and the ring stage it goes to
-  const int total_steps = (ch_end - ch_begin) * 9;
-  int iw_ch = ch_begin, iw_tap = 0, iw_step = 0;
-  auto issue_next_w = [&]() {
-    if (iw_step >= total_steps) return;                 // wave-uniform
-    issue_w(iw_ch, iw_tap, iw_step % D);
-    ++iw_step;
-    if (++iw_tap == 9) {
-      iw_tap = 0;
-      ++iw_ch;
-    }
-  };
-  if (ch_begin < ch_end) {
-#pragma unroll
-    for (int j = 0; j < HALO_PPW; ++j) issue_x_piece(j, ch_begin, 0);
-#pragma unroll
-    for (int p = 0; p < D - 1; ++p) issue_next_w();
-  }
-  int step = 0;
-  for (int ch = ch_begin; ch < ch_end; ++ch) {
-    const int xst = (ch - ch_begin) & 1;
-    const bool next_chunk = ch + 1 < ch_end;
-    const half_t* xs = Xh + xst * HALO_LDS_ROWS * BK;
-    // first chunk: fewer halo pieces precede the weight tiles than in steady state -> the conservative count;
-    // the last D-2 steps: no newer weight tiles behind the one waited for -> drain
-    const bool first_chunk = ch == ch_begin;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap, ++step) {
-      const int wst = step % D;
-      // this step's weight tile (and, at tap 0, this chunk's halo) have landed for every wave; every wave is done
-      // reading the stage the next DMA overwrites
-      if (step + D - 2 >= total_steps) wait_vmcnt_barrier<0>();
-      else if (first_chunk) wait_vmcnt_barrier<(D - 2) * WR>();
-      else halo_wait<D, WR>(tap);
-      const half_t* ws = Ws + wst * BN * BK + (wn * TN * 32 + frow) * BK;
-      const int toff = (tap / 3) * HALO_W + (tap % 3);
-      // keep the 72 (tap, k, tile) fragment addresses from being hoisted out of the chunk loop into
-      // registers (they would push the kernel past 256 VGPRs): re-derive them from hr0 at every tap
-#pragma unroll
-      for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(hr0[i]));
-      half8 xf[BK / 16][TM], wf[BK / 16][TN];
-#pragma unroll
-      for (int kk = 0; kk < BK / 16; ++kk) {
-        const int kc = kk * 2 + hi;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int hr = hr0[i] + toff;
-          if constexpr ((DBG & 2) != 0) asm volatile("" : "=v"(xf[kk][i]));
-          else xf[kk][i] = *reinterpret_cast<const half8*>(xs + hr * BK + ((kc ^ ((hr >> 1) & 7)) * 8));
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          if constexpr ((DBG & 2) != 0) asm volatile("" : "=v"(wf[kk][j]));
-          else wf[kk][j] = *reinterpret_cast<const half8*>(ws + j * 32 * BK + ((kc ^ fsw) * 8));
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr ((DBG & 4) == 0) issue_next_w();                // weight tile of step + D - 1
-      if constexpr ((DBG & 8) == 0)
-        if (tap < HALO_PPW) issue_x_piece(tap, next_chunk ? ch + 1 : ch, xst ^ 1);   // always issued: uniform op count
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // fragments in registers before the MFMAs (and before
-      __builtin_amdgcn_sched_barrier(0);                           // the next barrier lets a DMA overwrite their stage)
-#pragma unroll
-      for (int kk = 0; kk < BK / 16; ++kk)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            if constexpr ((DBG & 1) != 0) asm volatile("" ::"v"(wf[kk][j]), "v"(xf[kk][i]));
-            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kk][j], xf[kk][i], acc[i][j], 0, 0, 0);
-          }
-    }
-  }
-
-  // ---- epilogue: acc[i][j][r]: n = n0 + (r&3) + 8*(r>>2) + 4*hi ; pixel = tile-local ml ----
-  if (a.splitk > 1) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int ml = (wm * TM + i) * 32 + frow;
-      const int y = y0 + (ml >> 4), x = x0 + (ml & 15);
-      if (y >= H || x >= W) continue;
-      const int m = (b * H + y) * W + x;
-      float* prow = a.partial + ((size_t)split * a.M + m) * a.N;
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = n_blk + (wn * TN + j) * 32 + 8 * q + 4 * hi;
-          if (n < a.N) {
-            floatx4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-            *reinterpret_cast<floatx4*>(prow + n) = v;
-          }
-        }
-    }
-    return;
-  }
-  constexpr int OROW = BN + 8;
-  half_t* ot = reinterpret_cast<half_t*>(smem);   // [BM][OROW]
-  if (tid < BN) sconst[tid] = const_b + const_t;
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int ml = (wm * TM + i) * 32 + frow;
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int nl = (wn * TN + j) * 32 + 8 * q + 4 * hi;
-        const int n = n_blk + nl;
-        float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-        const floatx4 bb = *reinterpret_cast<const floatx4*>(sconst + nl);   // 0 beyond N
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += bb[e];
-        half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-        *reinterpret_cast<half4*>(ot + ml * OROW + nl) = o;
-      }
-  }
-  __syncthreads();
-  constexpr int WC = BN / 8;
-  for (int idx = tid; idx < BM * WC; idx += 256) {
-    const int r = idx / WC, c = idx - r * WC;
-    const int y = y0 + (r >> 4), x = x0 + (r & 15);
-    const int n = n_blk + c * 8;
-    if (y < H && x < W && n < a.N) {
-      const size_t m = (size_t)(b * H + y) * W + x;
-      half8 v = *reinterpret_cast<const half8*>(ot + r * OROW + c * 8);
-      half_t* dst = a.out + m * a.N + n;
-      if (n + 8 <= a.N) {
-        if (a.res) {
-          const half8 rr = *reinterpret_cast<const half8*>(a.res + m * a.N + n);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
-        }
-        *reinterpret_cast<half8*>(dst) = v;
-      } else {
-        for (int e = 0; e < a.N - n; ++e) dst[e] = a.res ? (half_t)((float)v[e] + (float)a.res[m * a.N + n + e]) : v[e];
-      }
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------------------------
 // Software-pipelined, K-split variant of the halo kernel (plan tile 7).  Measured on the kernel above
-// (tools/ablate_halo.py, profiles/r02_ablate_halo.txt): ONE workgroup alone on a CU needs 23 us for its 45 tap
+// (round 2's ablation builds of that kernel, profiles/r02_ablate_halo.txt): ONE workgroup alone on a CU needs 23 us for its 45 tap
 // steps and every phase of a step is exposed - fragment reads 9-11 us, MFMAs 5 us, DMA issue 3 us, barriers and
 // launch 6.5 us - because a wave reads its fragments, waits for them and only then issues its MFMAs; overlap
 // exists only between two co-resident workgroups.  Here
@@ -1188,7 +912,7 @@ __global__ __launch_bounds__(256, halo_lds_bytes(64, D) <= 80 * 1024 ? 2 : 1) vo
 
   // DMA through buffer_load_dwordx4 ... lds: the per-lane part of an address is a loop-invariant 32-bit VGPR offset, the
   // part that advances per tap / chunk is the scalar soffset, so a DMA instruction costs NO vector ALU work inside the
-  // tap loop (the 64-bit global_load_lds form needs ~6 VALU per piece; measured, tools/ablate_halo.py: DMA issue was
+  // tap loop (the 64-bit global_load_lds form needs ~6 VALU per piece; measured in round 2, profiles/r02_ablate_halo.txt: DMA issue was
   // the largest exposed cost of the loop, 4.4 of 16.8 us).  Rows outside the image read as zeros through the buffer
   // range check (offset >= num_records -> 0); weight rows past N are clamped to row N-1 (their outputs are not stored).
   constexpr unsigned kOob = 0x80000000u;
@@ -1518,7 +1242,7 @@ __global__ __launch_bounds__(256, halo_lds_bytes(64, D) <= 80 * 1024 ? 2 : 1) vo
 // GEGLU / residual / fused q|k|v / GroupNorm statistics / split-K slabs).
 // ---------------------------------------------------------------------------------------------
 template <int BM, int BN, int WGM, int WGN, int D, bool LNF>
-__global__ __launch_bounds__(256) void gemm_pipe_kernel(IgemmArgs a) {
+__global__ __launch_bounds__(256, D == 2 ? 2 : 1) void gemm_pipe_kernel(IgemmArgs a) {   // D = 2: 64 KB of LDS on the 128 x 128 tile, two workgroups per CU
   static_assert(WGM * WGN == 4, "4 waves");
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
   constexpr int XR = BM / 32, WR = BN / 32, PER = XR + WR, ROWB = BK * 2, KK = BK / 16;
@@ -1736,208 +1460,6 @@ __global__ __launch_bounds__(256) void gemm_pipe_kernel(IgemmArgs a) {
   }
   tile_epilogue<BM, BN, WGM, WGN, TM, TN, LNF, (RES_PRE ? RIT : 0)>(a, acc, ln_a, ln_b, smem, sconst, const_b, const_t, const_c, m_blk,
                                                                     n_blk, wave, split, temb_uniform, resv, use_resv);
-}
-
-// ---------------------------------------------------------------------------------------------
-// 256 x 256 tile of the software-pipelined 1x1 GEMM (plan tile 9): MEASURED, CORRECT, SELECTED NOWHERE (DESIGN.md Finding 5).
-// Every byte DMA'd into LDS feeds 128 FLOP here (64 on the 128 x 128 tile), built to test whether LDS fill bounds the GEMMs: it
-// lands where the 128-wide tiles do (556 TFLOP/s on 1280 -> 10240 at 4096 tokens, profiles/r03_gemm_big_bench.txt) - with one
-// workgroup per CU and ONE tile in flight the DMA landing cadence paces the step; hipBLASLt reaches 1.0-1.2 PFLOP/s there.
-// Four waves as 2 x 2, a wave owns 128 x 128 outputs: 256 accumulator registers (the whole AGPR file), fragments
-// ping-pong per 16-deep k sub-step (8 x 16 B in, 16 MFMAs out), two LDS stages of 64 KB: the DMA of step s+1 is issued
-// right behind the barrier of step s into the stage whose last reads that barrier has just retired.  Epilogue: the shared
-// tile_epilogue (the staged 256 x 264 tile re-uses the K-loop buffers; the per-column constants live behind it).
-// ---------------------------------------------------------------------------------------------
-constexpr size_t kBigStagedBytes = (size_t)256 * (256 + 8) * sizeof(half_t) + 16 + (kGnScratchFloats + 2 * 256) * sizeof(float);
-constexpr size_t kBigLoopBytes = (size_t)2 * (256 + 256) * BK * sizeof(half_t);
-constexpr size_t kBigConstOff = ((kBigStagedBytes > kBigLoopBytes ? kBigStagedBytes : kBigLoopBytes) + 255) & ~(size_t)255;
-constexpr size_t kBigLdsBytes = kBigConstOff + 2 * 256 * sizeof(float);
-static_assert(kBigLdsBytes <= 160 * 1024, "LDS");
-
-template <bool LNF>
-__global__ __launch_bounds__(256) void gemm_big_kernel(IgemmArgs a) {
-  constexpr int BM = 256, BN = 256, WGN = 2, TM = 4, TN = 4, XR = BM / 32, WR = BN / 32, ROWB = BK * 2, KK = BK / 16;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const Xs = smem;                                   // [2][BM][BK] halves
-  char* const Ws = smem + 2 * BM * ROWB;                   // [2][BN][BK]
-  float* sconst = reinterpret_cast<float*>(smem + kBigConstOff);
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WGN, wn = wave % WGN;
-  const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
-  const int nwg = nbm * nbn;
-  int bid = blockIdx.x;
-  {
-    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    bid = base + idx;
-  }
-  const int bn_idx = a.n_fast ? bid % nbn : bid / nbm, bm_idx = a.n_fast ? bid / nbn : bid % nbm;
-  const int m_blk = bm_idx * BM, n_blk = bn_idx * BN;
-  const int split = blockIdx.y;
-  const int kt_begin = split * a.nk_per_split;
-  int kt_end = kt_begin + a.nk_per_split;
-  if (kt_end > a.nk_total) kt_end = a.nk_total;
-  const int T = kt_end - kt_begin;
-
-  constexpr unsigned kOob = 0x80000000u;
-  const int pchunk = tid & 7, lrow = tid >> 3;
-  const unsigned lchunk = (unsigned)(pchunk ^ ((lrow >> 1) & 7)) * 16u;
-  unsigned xoff0[XR], xoff1[XR], woff[WR];
-#pragma unroll
-  for (int i = 0; i < XR; ++i) {
-    const int m = m_blk + lrow + 32 * i;
-    xoff0[i] = m < a.M ? (unsigned)m * (unsigned)a.C0 * 2u + lchunk : kOob;
-    xoff1[i] = m < a.M ? (unsigned)m * (unsigned)a.C1 * 2u + lchunk : kOob;
-  }
-#pragma unroll
-  for (int i = 0; i < WR; ++i) {
-    int n = n_blk + lrow + 32 * i;
-    if (n > a.N - 1) n = a.N - 1;
-    woff[i] = (unsigned)n * (unsigned)a.K * 2u + lchunk;
-  }
-  const unsigned x0_bytes = (unsigned)((size_t)a.M * a.C0 * 2), x1_bytes = (unsigned)((size_t)a.M * a.C1 * 2);
-  const unsigned w_bytes = (unsigned)((size_t)a.N * a.K * 2);
-  // DMA of one K tile, issued in four groups of (2 activation + 2 weight) pieces so that they spread over the step's MFMAs;
-  // tiles past the end of K go through zero-sized resources: nothing is fetched, the loop body stays one basic block
-  struct TileSrc {
-    __amdgpu_buffer_rsrc_t rs_x, rs_w;
-    int xs_off, w_off;
-    bool second;
-  };
-  auto tile_src = [&](int kt) {
-    const bool live = kt < kt_end;
-    const int k = kt * BK;
-    TileSrc t;
-    t.second = k >= a.C0;
-    t.rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(t.second ? a.x1 : a.x0), 0,
-                                               (int)(live ? (t.second ? x1_bytes : x0_bytes) : 0u), 0x00020000);
-    t.rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.w), 0, (int)(live ? w_bytes : 0u), 0x00020000);
-    t.xs_off = (t.second ? k - a.C0 : k) * 2;
-    t.w_off = k * 2;
-    return t;
-  };
-  auto issue_group = [&](const TileSrc& t, int stage, int g) {
-    char* xs = Xs + stage * (BM * ROWB) + wave * 1024;
-    char* ws = Ws + stage * (BN * ROWB) + wave * 1024;
-#pragma unroll
-    for (int i = 2 * g; i < 2 * g + 2; ++i) dma16_to_lds(t.rs_x, xs + i * 4096, t.second ? xoff1[i] : xoff0[i], t.xs_off);
-#pragma unroll
-    for (int i = 2 * g; i < 2 * g + 2; ++i) dma16_to_lds(t.rs_w, ws + i * 4096, woff[i], t.w_off);
-  };
-
-  floatx16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  float ln_s1[TM] = {}, ln_s2[TM] = {};
-
-  const int frow = lane & 31, hi = lane >> 5;
-  const int fsw = (frow >> 1) & 7;
-  int foff[KK];
-#pragma unroll
-  for (int kk = 0; kk < KK; ++kk) foff[kk] = ((kk * 2 + hi) ^ fsw) * 16;
-  const int xrow = (wm * TM * 32 + frow) * ROWB, wrow = (wn * TN * 32 + frow) * ROWB;
-
-  const bool temb_uniform = a.temb != nullptr && (a.HoWo % BM) == 0;
-  float const_b = 0.f, const_t = 0.f, const_c = 0.f;
-  if (a.splitk == 1 && tid < BN) {
-    const int n = n_blk + tid;
-    if (n < a.N) {
-      if (a.bias) const_b = a.bias[n];
-      if (temb_uniform) const_t = a.temb[(size_t)(m_blk / a.HoWo) * a.temb_stride + n];
-      if constexpr (LNF) const_c = a.ln_colsum[n];
-    }
-  }
-
-  struct Frag {
-    half8 x[TM];
-    half8 w[TN];
-  };
-  auto read_kk = [&](Frag& f, const char* xs, const char* ws, int kk) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i) f.x[i] = *reinterpret_cast<const half8*>(xs + i * 32 * ROWB + foff[kk]);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) f.w[j] = *reinterpret_cast<const half8*>(ws + j * 32 * ROWB + foff[kk]);
-  };
-  auto mfma_kk = [&](const Frag& f) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.w[j], f.x[i], acc[i][j], 0, 0, 0);
-    if constexpr (LNF) {
-      const half2v one2 = {(half_t)1.f, (half_t)1.f};
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const half2v p2 = {f.x[i][2 * e], f.x[i][2 * e + 1]};
-          ln_s2[i] = __builtin_amdgcn_fdot2(p2, p2, ln_s2[i], false);
-          ln_s1[i] = __builtin_amdgcn_fdot2(p2, one2, ln_s1[i], false);
-        }
-    }
-  };
-
-  {
-    const TileSrc t0 = tile_src(kt_begin);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) issue_group(t0, 0, g);
-  }
-  Frag f0, f1;
-  // one phase = the 16 MFMAs of k sub-step kk on `cur`, with the 8 fragment reads of sub-step kk+1 (into `nxt`) and a quarter
-  // of the next tile's DMA issued between them; sched_barrier fences keep a phase's reads from drifting into another phase
-  auto phase = [&](const Frag& cur, Frag& nxt, const char* xs, const char* ws, int kk_next, const TileSrc& tn, int nstage, int g) {
-    if (kk_next < KK) read_kk(nxt, xs, ws, kk_next);
-    issue_group(tn, nstage, g);
-    mfma_kk(cur);
-    if constexpr (!LNF) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  for (int st = 0; st < T; ++st) {
-    const int stage = st & 1;
-    wait_vmcnt_barrier<0>();                                // tile st has landed; every wave is done with the other stage
-    const TileSrc tn = tile_src(kt_begin + st + 1);         // lands during this step's 64 MFMAs per wave
-    const char* xs = Xs + stage * (BM * ROWB) + xrow;
-    const char* ws = Ws + stage * (BN * ROWB) + wrow;
-    read_kk(f0, xs, ws, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    phase(f0, f1, xs, ws, 1, tn, stage ^ 1, 0);
-    phase(f1, f0, xs, ws, 2, tn, stage ^ 1, 1);
-    phase(f0, f1, xs, ws, 3, tn, stage ^ 1, 2);
-    phase(f1, f0, xs, ws, KK, tn, stage ^ 1, 3);
-  }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the zero-sized tail DMA too: the LDS is about to be re-used
-
-  float ln_a[TM] = {}, ln_b[TM] = {};
-  if constexpr (LNF) {
-    const float inv_k = 1.0f / (float)a.K;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const float s1 = xor32_sum(ln_s1[i]), s2 = xor32_sum(ln_s2[i]);
-      const float mean = s1 * inv_k;
-      const float var = fmaxf(s2 * inv_k - mean * mean, 0.f);
-      ln_a[i] = rsqrtf(var + a.ln_eps);
-      ln_b[i] = -ln_a[i] * mean;
-    }
-  }
-  half8 resv[1];
-  tile_epilogue<BM, BN, 2, WGN, TM, TN, LNF, 0>(a, acc, ln_a, ln_b, smem, sconst, const_b, const_t, const_c, m_blk, n_blk, wave, split,
-                                                temb_uniform, resv, false);
 }
 
 // split-K combine + the same epilogue (bias, temb broadcast, residual) -> fp16
@@ -2251,12 +1773,6 @@ struct Plan {
   int staging = 0;   // from the tuned table (tile / 10): 0 two-stage LDS-DMA, 2 / 3 = 3- / 4-stage ring
 };
 
-bool halo_ok(const ConvDesc& d) {
-  const int c1 = d.x1 ? d.C1 : 0;
-  return d.ksize == 3 && d.stride == 1 && d.up == 1 && d.pad < 0 && d.out_mode == kOutHalf && d.Wi >= 16 && d.Hi >= 8 &&
-         d.C0 % BK == 0 && c1 % BK == 0 && d.N % 4 == 0;
-}
-
 // the K-split halo kernel also folds the nearest-x2 upsample into its gather and takes 8-pixel-wide images (half of each
 // 8x16 tile is then padding: the 8x8 level streams weights, MFMA work is not what bounds it)
 bool halo_ks_ok(const ConvDesc& d) {
@@ -2272,14 +1788,10 @@ bool gemm_pipe_ok(const IgemmArgs& a) {
 
 void tile_dims(int tile, int& bm, int& bn) {
   switch (tile) {
-    case 5: bm = 128; bn = 128; break;   // halo kernel, 8x16-pixel tile
-    case 6: bm = 128; bn = 64; break;
-    case 7: bm = 128; bn = 64; break;    // halo, K-split waves + register double buffering
+    case 7: bm = 128; bn = 64; break;    // halo conv (8x16-pixel tile), K-split waves + register double buffering
     case 1: bm = 128; bn = 128; break;
     case 2: bm = 128; bn = 64; break;
     case 3: bm = 64; bn = 64; break;
-    case 8: bm = 256; bn = 128; break;   // software-pipelined 1x1 GEMM only (gemm_pipe_kernel): 87 FLOP per LDS-fill byte
-    case 9: bm = 256; bn = 256; break;   // ... gemm_big_kernel: 128 FLOP per LDS-fill byte
     default: bm = 64; bn = 128; break;
   }
 }
@@ -2348,14 +1860,16 @@ Plan choose_plan(const ConvDesc& d, const IgemmArgs& a) {
   const bool geglu = d.out_mode == kOutGeglu;
   // the LayerNorm fold needs whole rows per workgroup, the fused q|k|v epilogue has no slab path
   const bool can_split = d.out_mode == kOutHalf && !d.ln_colsum && !d.out_t;
-  auto is_halo = [](int c) { return c == 5 || c == 6 || c == 7; };
+  // plan tiles: 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128 (igemm_kernel / gemm_pipe_kernel), 7 = the halo conv.  Codes 5 / 6
+  // (round 2's first halo kernel) and 8 / 9 (256x128 / 256x256 GEMM tiles, measured in round 3 and selected nowhere) were removed
+  // in round 4: a caller or table row that names them gets the heuristic.
+  auto is_halo = [](int c) { return c == 7; };
   auto tile_ok = [&](int c) {
-    if (c < 1 || c > 9) return false;
-    if (is_halo(c)) return (c == 7 ? halo_ks_ok(d) : halo_ok(d)) && !d.ln_colsum && !d.out_t && !geglu;
-    if ((c == 8 || c == 9) && (!gemm_pipe_ok(a) || d.out_mode == kOutHalfT)) return false;
+    if (!((c >= 1 && c <= 4) || c == 7)) return false;
+    if (is_halo(c)) return halo_ks_ok(d) && !d.ln_colsum && !d.out_t && !geglu;
     int bm, bn;
     tile_dims(c, bm, bn);
-    if (geglu && c != 1 && c != 4 && c != 8 && c != 9) return false;       // GEGLU value/gate pairs need 64 n-columns per wave
+    if (geglu && c != 1 && c != 4) return false;       // GEGLU value/gate pairs need 64 n-columns per wave
     if (d.out_t && d.n_trans % bn != 0) return false;  // the q|k / v boundary must be a tile boundary
     return true;
   };
@@ -2426,59 +1940,7 @@ Plan choose_plan(const ConvDesc& d, const IgemmArgs& a) {
   return p;
 }
 
-template <int BN, int D>
-void launch_halo_d(const IgemmArgs& a, hipStream_t s) {
-  const size_t lds = halo_lds_bytes(BN, D);
-  static_assert(halo_lds_bytes(BN, D) <= 160 * 1024, "LDS");
-  auto k = conv3x3_halo_kernel<BN, D>;
-  static DynLdsOnce once;   // per instantiation, per device
-  once.set(k, lds);
-  dim3 grid(a.B * a.tiles_x * a.tiles_y * cdiv(a.N, BN), a.splitk);
-  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
-}
-
-// staging (the table's ring code): 0 = 2 weight stages (two workgroups per CU), 2 / 3 = 3 / 4 stages,
-// 4 / 5 = 6 / 8 stages (BN = 64 only: 8-KB stages); deeper rings keep more weight bytes in flight per CU
-template <int DBG>
-void launch_halo_dbg(const IgemmArgs& a, hipStream_t s) {
-  const size_t lds = halo_lds_bytes(64, 4);
-  auto k = conv3x3_halo_kernel<64, 4, DBG>;
-  SD_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  dim3 grid(a.B * a.tiles_x * a.tiles_y * cdiv(a.N, 64), a.splitk);
-  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
-}
-
-template <int BN>
-void launch_halo(IgemmArgs a, int splitk, int staging, hipStream_t s) {
-  const int nch = a.Ctot / BK;
-  a.nk_total = nch;
-  a.nk_per_split = cdiv(nch, splitk);
-  a.splitk = cdiv(nch, a.nk_per_split);
-  if constexpr (BN == 64) {
-    if (a.debug >= 32) {   // ablation builds of the BN = 64, 4-stage kernel: debug = 32 + DBG bits
-      switch (a.debug - 32) {
-        case 1: launch_halo_dbg<1>(a, s); return;
-        case 2: launch_halo_dbg<2>(a, s); return;
-        case 3: launch_halo_dbg<3>(a, s); return;
-        case 4: launch_halo_dbg<4>(a, s); return;
-        case 8: launch_halo_dbg<8>(a, s); return;
-        case 12: launch_halo_dbg<12>(a, s); return;
-        case 13: launch_halo_dbg<13>(a, s); return;
-        case 14: launch_halo_dbg<14>(a, s); return;
-        case 15: launch_halo_dbg<15>(a, s); return;
-        default: break;
-      }
-    }
-  }
-  if constexpr (BN == 64) {
-    if (staging >= 5) { launch_halo_d<BN, 8>(a, s); return; }
-    if (staging >= 4) { launch_halo_d<BN, 6>(a, s); return; }
-  }
-  if (staging >= 3) { launch_halo_d<BN, 4>(a, s); return; }
-  if (staging >= 2) { launch_halo_d<BN, 3>(a, s); return; }
-  launch_halo_d<BN, 2>(a, s);
-}
-
+// staging (the table's ring code): 0 = 2 weight stages (two workgroups per CU), 2 / 3 = 3 / 4 stages, 4 / 5 = 6 / 8 stages
 template <int D, int DBG = 0>
 void launch_halo_ks_d(const IgemmArgs& a, hipStream_t s) {
   const size_t lds = halo_lds_bytes(64, D);
@@ -2554,13 +2016,12 @@ bool launch_debug_mode(const IgemmArgs& a, int dbg, hipStream_t s) {
 
 // staging: 0 = LDS-DMA 2 stages, 1 = register staging (A/B reference), 2 / 3 / 4 / 5 = LDS-DMA ring of
 // 3 / 4 / 6 / 8 stages (a ring that would not fit the 160 KB of LDS falls back to the deepest one that does),
-// (codes 6-8 belonged to a software-pipelined 1x1 GEMM kernel that was measured and dropped; they run the 4-stage ring)
 constexpr size_t kLdsBudget = 160 * 1024;
 template <int BM, int BN>
 constexpr bool ring_fits(int nst) {
   return (size_t)nst * (BM + BN) * BK * sizeof(half_t) + 2 * BN * sizeof(float) <= kLdsBudget;
 }
-// staging 6 / 7: the software-pipelined 1x1 GEMM kernel with a ring of 3 / 4 stages (1x1, stride 1, non-transposed
+// staging 6 / 7 / 8: the software-pipelined 1x1 GEMM kernel with a ring of 3 / 4 / 2 stages (1x1, stride 1, non-transposed
 // output; 32-bit buffer offsets); anything else that asks for them runs the 4-stage ring of igemm_kernel
 template <int BM, int BN, int WGM, int WGN, int D, bool LNF>
 void launch_pipe(const IgemmArgs& a, hipStream_t s) {
@@ -2577,6 +2038,10 @@ void launch_pipe(const IgemmArgs& a, hipStream_t s) {
 }
 template <int BM, int BN, int WGM, int WGN, bool LNF>
 void launch_ring(const IgemmArgs& a, int staging, hipStream_t s) {
+  if (staging == 8 && gemm_pipe_ok(a)) {   // 2-stage ring, two workgroups per CU (three on 128 x 64): profiles/r03_exp_pipe_d2.txt
+    launch_pipe<BM, BN, WGM, WGN, 2, LNF>(a, s);
+    return;
+  }
   if ((staging == 6 || staging == 7) && gemm_pipe_ok(a)) {
     if (staging == 7) {
       if constexpr (ring_fits<BM, BN>(4)) { launch_pipe<BM, BN, WGM, WGN, 4, LNF>(a, s); return; }
@@ -2697,7 +2162,7 @@ int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
   SD_REQUIRE(!d.vt_perm || (d.out_t && (d.Ho * d.Wo) % 16 == 0), kInvalidArgument, "permuted V^T needs the fused q|k|v epilogue and HoWo %% 16 == 0");
   IgemmArgs a = make_args(d);
   Plan p = choose_plan(d, a);
-  const bool halo = p.tile == 5 || p.tile == 6 || p.tile == 7;
+  const bool halo = p.tile == 7;
   if (halo) {
     const int nch = a.Ctot / BK;
     a.nk_per_split = cdiv(nch, p.splitk);
@@ -2722,7 +2187,7 @@ int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
       // sent the 1280 -> 1280 GEMMs of the 16x16 level n-fast: 27 MB of fabric reads per launch for 4.6 MB of operands)
     int bm, bn;
     tile_dims(p.tile, bm, bn);
-    const bool halo_tile = p.tile == 5 || p.tile == 6 || p.tile == 7;
+    const bool halo_tile = p.tile == 7;
     const double nbn = (double)cdiv(a.N, bn);
     const double nbm = halo_tile ? (double)a.B * a.tiles_x * a.tiles_y : (double)cdiv(a.M, bm);
     const double a_bytes = 2.0 * a.B * a.Hi * a.Wi * a.Ctot, w_bytes = 2.0 * a.N * a.K;
@@ -2739,10 +2204,8 @@ int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
             a.C0, a.C1, a.M, a.N, a.K, d.out_mode, p.tile, a.splitk);
   int gn_entries = 0;
   if (halo) {
-    if (p.tile == 7) gn_entries = setup_gn_stats(d, a, 0);
-    if (p.tile == 5) launch_halo<128>(a, a.splitk, st, s);
-    else if (p.tile == 7) launch_halo_ks(a, a.splitk, st, s);
-    else launch_halo<64>(a, a.splitk, st, s);
+    gn_entries = setup_gn_stats(d, a, 0);
+    launch_halo_ks(a, a.splitk, st, s);
   } else if (d.debug) {   // ablation builds exist for two tiles only (tools/prof_conv.py)
     const bool ok = p.tile == 1 ? launch_debug_mode<128, 128>(a, d.debug, s) : launch_debug_mode<64, 64>(a, d.debug, s);
     SD_REQUIRE(ok && !trans, kInvalidArgument, "no ablation kernel for debug mode %d", d.debug);
@@ -2750,29 +2213,10 @@ int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
   } else {
     if (!trans) {
       int bm, bn;
-      tile_dims((p.tile >= 1 && p.tile <= 3) || p.tile == 8 || p.tile == 9 ? p.tile : 4, bm, bn);
+      tile_dims(p.tile >= 1 && p.tile <= 3 ? p.tile : 4, bm, bn);
       gn_entries = setup_gn_stats(d, a, bm);
     }
     switch (p.tile) {
-      case 9: {
-        dim3 grid(cdiv(a.M, 256) * cdiv(a.N, 256), a.splitk);
-        if (a.ln_colsum) {
-          auto k = gemm_big_kernel<true>;
-          static DynLdsOnce once;
-          once.set(k, kBigLdsBytes);
-          hipLaunchKernelGGL(k, grid, dim3(256), kBigLdsBytes, s, a);
-        } else {
-          auto k = gemm_big_kernel<false>;
-          static DynLdsOnce once;
-          once.set(k, kBigLdsBytes);
-          hipLaunchKernelGGL(k, grid, dim3(256), kBigLdsBytes, s, a);
-        }
-        break;
-      }
-      case 8:
-        if (a.ln_colsum) launch_pipe<256, 128, 2, 2, 3, true>(a, s);
-        else launch_pipe<256, 128, 2, 2, 3, false>(a, s);
-        break;
       case 1: launch_tile<128, 128, 2, 2>(a, trans, st, s); break;
       case 2: launch_tile<128, 64, 2, 2>(a, trans, st, s); break;
       case 3: launch_tile<64, 64, 2, 2>(a, trans, st, s); break;

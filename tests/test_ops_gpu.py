@@ -208,7 +208,7 @@ def test_conv2d_matches_torch(case):
     close(out, conv_ref(x, w, bias, res, stride, ups), f"conv {case}")
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 11, 12, 13, 14, 21, 22, 23, 24, 31, 32, 33, 34, 41, 42, 43, 44, 51, 52, 53, 54, 61, 62, 63, 64, 71, 72, 73, 74])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 11, 12, 13, 14, 21, 22, 23, 24, 31, 32, 33, 34, 41, 42, 43, 44, 51, 52, 53, 54, 61, 62, 63, 64, 71, 72, 73, 74, 81, 82, 83, 84])
 @pytest.mark.parametrize("splitk", [1, 2, 5])
 def test_conv2d_every_tile_and_splitk(tile, splitk):
     rs = np.random.RandomState(tile * 10 + splitk)
@@ -222,12 +222,13 @@ def test_conv2d_every_tile_and_splitk(tile, splitk):
     close(gen, conv_ref(x, w, bias, res, 1, False), "generic conv")
 
 
-# tile % 10: 5 / 6 = halo BN 128 / 64, 7 = K-split software-pipelined halo; tile // 10 = weight-ring code (3 / 4 / 6 / 8 stages)
-@pytest.mark.parametrize("tile", [5, 6, 25, 26, 35, 36, 46, 56, 7, 27, 37, 47, 57])
+# tile % 10: 7 = the K-split software-pipelined halo kernel; tile // 10 = weight-ring code (3 / 4 / 6 / 8 stages).  5 / 6 / 8 / 9 were
+# kernels removed in round 4: asking for them must still give the right answer (the heuristic picks a live kernel)
+@pytest.mark.parametrize("tile", [7, 27, 37, 47, 57, 5, 26, 8, 9])
 @pytest.mark.parametrize("splitk", [0, 1, 2, 3])
 @pytest.mark.parametrize("shape", [(2, 128, 16, 16, 128), (1, 64, 24, 40, 96), (2, 320, 32, 32, 320), (1, 192, 9, 17, 68)],
                          ids=lambda s: "x".join(map(str, s)))
-def test_conv3x3_halo_kernel(tile, splitk, shape):
+def test_conv3x3_halo_conv_and_removed_plan_codes(tile, splitk, shape):
     """LDS-halo 3x3 kernel: full and ragged 8x16 tiles, ragged N, split over channel chunks."""
     b, cin, hh, ww, cout = shape
     rs = np.random.RandomState(cin + ww)
@@ -281,7 +282,7 @@ def test_timestep_embedding_reference_golden():
     np.testing.assert_allclose(_lib.timestep_embedding(ts, 256), unet_ref.timestep_embedding(torch.from_numpy(ts), 256).numpy(), atol=1e-4)
 
 
-@pytest.mark.parametrize("tile,splitk", [(3, 8), (33, 16), (6, 4), (26, 2), (1, 4), (37, 2), (7, 1), (47, 1), (57, 2)])
+@pytest.mark.parametrize("tile,splitk", [(3, 8), (33, 16), (27, 4), (7, 2), (1, 4), (37, 2), (7, 1), (47, 1), (57, 2), (82, 4)])
 def test_splitk_is_complete_and_bit_reproducible(tile, splitk):
     """Split-K: fp32 slabs per K slice, combined in slice order by the reduce kernel (no atomics): repeated launches
     must agree bit for bit, and with torch.  A weight-streaming shape (M = 128 rows, K = 11520), up to 16 slices.

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""K-split software-pipelined halo kernel (plan tile 7) against the halo kernel it replaces (tile 6): resnet conv shapes of
+"""K-split software-pipelined halo kernel (plan tile 7) (the halo kernel it replaced, tile 6, was removed in round 4: profiles/r02_ablate_halo_ks_cold.txt / _warm.txt hold the comparison): resnet conv shapes of
 SD2.1-base at batch 2, ring depths, split-K, and the ablation builds (bit 1 no MFMA, 2 no ds_read, 4 no W DMA, 8 no X DMA)."""
 import os, sys
 import numpy as np
@@ -19,7 +19,7 @@ def run(cin, cout, h, tile, mode=0, iters=30, splitk=1):
 
 
 print("== workgroup-count scaling @64x64, 320 input channels")
-for tile in (36, 7, 27, 37):
+for tile in (7, 27, 37):
     row = []
     for cout in (64, 256, 320, 512):
         row.append(f"{cout}: {run(320, cout, 64, tile):6.1f}")
@@ -35,7 +35,7 @@ print("== layer shapes (us): tile/splitk")
 for cin, cout, h in ((320, 320, 64), (640, 320, 64), (960, 320, 64), (640, 640, 32), (1280, 640, 32), (1920, 640, 32), (960, 640, 32),
                      (320, 640, 32), (1280, 1280, 16), (2560, 1280, 16), (1920, 1280, 16), (640, 1280, 16)):
     row = []
-    for tile, sk in ((36, 1), (36, 2), (36, 4), (27, 1), (37, 1), (37, 2), (37, 4), (37, 5), (47, 1), (47, 2)):
+    for tile, sk in ((27, 1), (37, 1), (37, 2), (37, 4), (37, 5), (47, 1), (47, 2)):
         if sk > cin // 64:
             continue
         t = run(cin, cout, h, tile, splitk=sk)

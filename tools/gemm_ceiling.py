@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Where do the main loops top out?  The 1x1 GEMM kernels of this library (best plan code per shape out of igemm_kernel's
-tiles, gemm_pipe_kernel's rings / tiles and gemm_big_kernel) and the K-split halo 3x3 conv against the vendor libraries
+tiles, gemm_pipe_kernel's rings / tiles) and the K-split halo 3x3 conv against the vendor libraries
 (hipBLASLt through torch F.linear, MIOpen through F.conv2d channels_last fp16 - yardsticks, never linked) at M = 8 192 ...
 131 072 rows, back-to-back launches (operands L2 / Infinity-Cache warm: the ceiling, not the in-sequence time).
 usage: gemm_ceiling.py [out.txt]"""
@@ -17,7 +17,7 @@ for p in (ROOT, os.path.join(ROOT, "ml-stable-diffusion_amd")):
 from python_hip_stable_diffusion import _lib  # noqa: E402
 
 dev = torch.device("cuda")
-CODES = [0, 1, 61, 2, 62, 4, 64, 8, 9]
+CODES = [0, 1, 61, 81, 2, 62, 82, 4, 64, 84]
 lines = []
 
 

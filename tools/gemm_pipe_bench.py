@@ -18,7 +18,7 @@ SHAPES = [(320, 320, 64), (1280, 320, 64), (640, 640, 32), (2560, 640, 32), (128
 if len(sys.argv) > 2 and sys.argv[2] == "sdxl":   # the 24x24 / 48x48 levels of SDXL-base at 768x768 (B = 2: 1152 / 4608 tokens)
     SHAPES = [(1280, 10240, 24), (1280, 3840, 24), (5120, 1280, 24), (1280, 1280, 24), (640, 5120, 48), (2560, 640, 48), (640, 1920, 48)]
 CODES = [0, 9, 8, 1, 61, 2, 62, 4, 64, 3]
-if os.environ.get("EXP_CODES"):   # experiment builds (tools/exp_pipe_d2.py): extra plan codes
+if os.environ.get("EXP_CODES"):   # extra plan codes (e.g. 81,82,84: the 2-stage ring)
     CODES = [0, 61, 62, 64] + [int(c) for c in os.environ["EXP_CODES"].split(",")]
 rs = np.random.RandomState(0)
 print(f"UNet batch {B}; columns: plan code -> us (TFLOP/s)")

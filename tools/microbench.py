@@ -48,7 +48,7 @@ def main():
         m = B * ho * ho
         res = {}
         splitks = [0, 1, 2] if m >= 2048 else [1, 2, 4, 8, 16]
-        tiles = (1, 2, 3, 4, 5, 6) if (k == 3 and s == 1 and not up and w >= 16) else (1, 2, 3, 4)
+        tiles = (1, 2, 3, 4, 7) if (k == 3 and s == 1 and not up and w >= 8) else (1, 2, 3, 4)
         if m <= 2048 and k == 3:
             tiles = tiles + (21, 23, 24, 33)      # LDS-DMA rings (3 / 4 stages) for the weight-streaming levels
         for tile in tiles:

@@ -18,8 +18,8 @@ for key, info in sorted(rep["per_key"].items(), key=lambda kv: -kv[1]["base_ms"]
             continue
         if tile == 7 and not (ks == 3 and st == 1):
             continue                      # not legal there: the candidate silently ran the table's plan
-        if tile in (5, 6) and not (ks == 3 and st == 1 and up == 1):
-            continue
+        if tile not in (1, 2, 3, 4, 7):
+            continue                      # 5 / 6 / 8 / 9: kernels removed in round 4
         if stg >= 6 and tile < 5 and not (ks == 1):
             continue
         if kind != 0 and sk != 1:
