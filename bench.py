@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--model", default="sd21-base", choices=sorted(MODELS), help="UNet of BASELINE configs 2 / 4 / 5")
     ap.add_argument("--latent", type=int, default=0, choices=[0, 64, 96, 128],
                     help="latent height = width (64: 512x512 images, 96: 768x768); 0 = the model's BASELINE size")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="extra measurement (N=1 only): S prompts served by S handles on S HIP streams at the same time; reported "
+                         "as 'concurrent_prompts', never as 'value'")
     ap.add_argument("--stub-model", action="store_true", help=argparse.SUPPRESS)   # tests/test_parallel.py: the launch /
     # rendezvous / barrier / max-over-ranks / gather plumbing of this script under gloo on CPU, with StubModel in the UNet's place
     args = ap.parse_args()
@@ -260,11 +263,53 @@ def main():
     if world == 1 and default_cfg:   # end-to-end latency of one generation: 20 DDIM steps + VAE decode (pipeline.py:500-589)
         out["e2e"].update(e2e_latency(model, checkpoint, my_ehs[[0, ppg]], latents[:1], args.guidance_scale,
                                       local_rank))
+    if world == 1 and args.streams > 1 and control is None:
+        out["concurrent_prompts"] = concurrent_prompts(model, HipModel, ucfg, checkpoint, args, lat_hw, local_rank, loop_inputs, latents)
     if world == 1 and default_cfg and args.cpu_steps > 0:
         out["cpu_baseline"] = cpu_baseline(ckpt, my_ehs[[0, ppg]], latents[:1], args.cpu_steps, args.guidance_scale)
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def concurrent_prompts(model, HipModel, ucfg, checkpoint, args, lat_hw, device, loop_inputs, latents):
+    """S independent prompts on S handles (one HIP stream + one step graph each, weights per handle) looping at the same time
+    (python_hip_stable_diffusion.parallel.run_concurrent) against the same S prompts one after the other on one handle.  The
+    headline `value` stays the one-prompt loop; this is the serving-throughput view of the same path on one GPU."""
+    from python_hip_stable_diffusion import schedulers
+    from python_hip_stable_diffusion.parallel import run_concurrent
+    ppg = args.prompts_per_gpu
+    handles = [model]
+    for i in range(1, args.streams):
+        ck = checkpoint.random_checkpoint(checkpoint.unet_param_shapes(ucfg), seed=0)
+        handles.append(HipModel(ucfg, ck, batch=2 * ppg, latent_height=lat_hw, latent_width=lat_hw,
+                                attention_implementation=args.attention, device=device, use_graph=not args.no_graph))
+        del ck
+    sch = schedulers.DDIMScheduler()
+    sch.set_timesteps(args.steps)
+    ts, coef, hist = sch.device_tables()
+    jobs = []
+    for i, h in enumerate(handles):
+        inp = {k: np.roll(v, i, axis=-1) if k == "encoder_hidden_states" else v for k, v in loop_inputs.items()}
+        lat = np.roll(latents, i, axis=-1) * sch.init_noise_sigma
+        jobs.append(lambda h=h, inp=inp, lat=lat: h.denoise_loop(lat, ts, coef, args.guidance_scale, history=hist, **inp)[0])
+    run_concurrent(jobs)                       # warm: every handle captures its graph
+    serial, conc = [], []
+    for _ in range(max(1, args.repeats)):
+        t0 = time.perf_counter()
+        for j in jobs:
+            j()
+        serial.append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        outs = run_concurrent(jobs)
+        conc.append(time.perf_counter() - t0)
+    assert all(np.isfinite(o).all() for o in outs)
+    s_med, c_med = float(np.median(serial)), float(np.median(conc))
+    n = args.streams * ppg * args.steps
+    return {"streams": args.streams, "prompts": args.streams * ppg,
+            "one_after_the_other_it_s": round(n / s_med, 2), "concurrent_it_s": round(n / c_med, 2),
+            "ms_per_prompt_step_serial": round(s_med / n * 1e3, 4), "ms_per_prompt_step_concurrent": round(c_med / n * 1e3, 4),
+            "note": "host wall clock around whole loops (launch + replay + read-back), S handles = S HIP streams on one GPU"}
 
 
 class StubModel:

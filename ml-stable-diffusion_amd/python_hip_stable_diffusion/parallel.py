@@ -6,8 +6,41 @@ LayerNorm are per-sample - so there is NO data-path collective.  RCCL (torch.dis
 "nccl" on ROCm; "gloo" in the CPU tests) only moves the prompt embeddings out at the start
 (broadcast, 315 KB per prompt) and the results back at the end (all_gather, 64 KB of latents
 per prompt).  Per-step inter-GPU traffic is zero.
+
+Inside ONE GPU the same independence is used a second way (run_concurrent): a CFG-batch-2 step is latency-bound on an MI355X
+(a batch-1 step takes 95 % of a batch-2 step, profiles/r04_shortcut_side_stream_rejected.txt), so several prompts served by
+several handles - each with its own HIP stream and step graph - overlap on the 256 CUs where one stream leaves them idle.
 """
+import threading
+
 import numpy as np
+
+
+def run_concurrent(jobs):
+    """Run the zero-argument callables ``jobs`` at the same time, one host thread each, and return their results in order.
+    Meant for device-resident loops of DIFFERENT handles (``HipModel.denoise_loop``): every handle owns a HIP stream and ctypes
+    releases the GIL for the duration of the call, so the streams' graphs execute concurrently on the GPU.  An exception in
+    any job is re-raised here after all of them have finished.  One job is simply called."""
+    jobs = list(jobs)
+    if len(jobs) == 1:
+        return [jobs[0]()]
+    results, errors = [None] * len(jobs), [None] * len(jobs)
+
+    def work(i):
+        try:
+            results[i] = jobs[i]()
+        except BaseException as e:   # noqa: BLE001 - handed to the caller below
+            errors[i] = e
+
+    threads = [threading.Thread(target=work, args=(i,), name=f"sd-stream-{i}") for i in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for e in errors:
+        if e is not None:
+            raise e
+    return results
 
 
 def shard_prompts(n_prompts, world_size):

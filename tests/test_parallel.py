@@ -297,3 +297,23 @@ def test_bench_py_multi_gpu_launch_path_under_gloo_world_size_two():
         outs[(world, ppg)] = d
     # two prompts on one rank and one prompt on each of two ranks are the same global job: same gathered result
     assert abs(outs[(1, 2)]["checksum"] - outs[(2, 1)]["checksum"]) <= 1e-6 * max(1.0, abs(outs[(1, 2)]["checksum"]))
+
+
+def test_run_concurrent_runs_jobs_at_the_same_time_keeps_order_and_reraises():
+    """python_hip_stable_diffusion.parallel.run_concurrent: one host thread per handle loop (bench.py --streams)."""
+    import threading
+    import time
+    from python_hip_stable_diffusion.parallel import run_concurrent
+    gate = threading.Barrier(3, timeout=20)          # passes only if all three jobs are in flight together
+
+    def job(i):
+        gate.wait()
+        time.sleep(0.01 * (3 - i))                   # finish in reverse order
+        return i * i
+
+    assert run_concurrent([lambda i=i: job(i) for i in range(3)]) == [0, 1, 4]
+    assert run_concurrent([lambda: "only"]) == ["only"]
+    done = []
+    with pytest.raises(ZeroDivisionError):
+        run_concurrent([lambda: done.append(1), lambda: 1 / 0, lambda: done.append(2)])
+    assert sorted(done) == [1, 2]                    # the others still ran to the end
