@@ -394,7 +394,7 @@ def op_family(label):
     if label.startswith(("gemm1x1", "geglu1x1")):
         return "1x1 GEMMs (igemm_kernel)"
     if label.startswith("attention"):
-        return "self-attention (attn_kernel)"
+        return "self-attention (attn8_kernel / attn_kernel)"
     if label.startswith("xattn"):
         return "cross-attention with fused q projection (xattn_kernel)"
     if label.startswith("groupnorm"):
