@@ -293,7 +293,9 @@ def concurrent_prompts(model, HipModel, ucfg, checkpoint, args, lat_hw, device, 
         inp = {k: np.roll(v, i, axis=-1) if k == "encoder_hidden_states" else v for k, v in loop_inputs.items()}
         lat = np.roll(latents, i, axis=-1) * sch.init_noise_sigma
         jobs.append(lambda h=h, inp=inp, lat=lat: h.denoise_loop(lat, ts, coef, args.guidance_scale, history=hist, **inp)[0])
-    run_concurrent(jobs)                       # warm: every handle captures its graph
+    for j in jobs:                             # warm one after the other: every handle captures its graph undisturbed
+        j()
+    run_concurrent(jobs)
     serial, conc = [], []
     for _ in range(max(1, args.repeats)):
         t0 = time.perf_counter()

@@ -95,3 +95,36 @@ def test_vae_decoder_matches_the_golden_of_the_reference_blocks(name):
     assert out.shape == g["image"].shape and p >= 60.0, f"VAE decoder {name}: PSNR {p:.1f} dB vs the reference-block golden"
     vae.close()
 
+
+
+@pytest.mark.gpu
+def test_concurrent_handles_on_one_gpu_give_the_bits_of_the_serial_loops():
+    """python_hip_stable_diffusion.parallel.run_concurrent (bench.py --streams): three handles - different prompts, different
+    attention schedules - loop at the same time from three host threads, each on its own HIP stream and step graph; every result
+    must be bit-identical to the same loop run alone (nothing is shared between handles but read-only kernel state), five times
+    over, including the first concurrent call, in which the three handles capture their graphs at the same time."""
+    from python_hip_stable_diffusion import schedulers
+    from python_hip_stable_diffusion.parallel import run_concurrent
+    from test_round2_gpu import _mini
+    from oracle import weights
+    models = [_mini(batch=2, impl=impl, seed=21 + i)[2] for i, impl in enumerate(("ORIGINAL", "SPLIT_EINSUM", "SPLIT_EINSUM_V2"))]
+    cfg = _mini.__globals__["unet_ref"].CONFIGS["mini"]
+    hw = cfg["sample_size"]
+    sch = schedulers.PNDMScheduler()
+    sch.set_timesteps(8)
+    ts, coef, hist = sch.device_tables()
+    jobs = []
+    for i, m in enumerate(models):
+        lat = weights.seeded_normal((1, 4, hw, hw), 300 + i)
+        e = weights.seeded_normal((2, cfg["cross_attention_dim"], 1, 77), 400 + i).astype(np.float16)
+        jobs.append(lambda m=m, lat=lat, e=e: m.denoise_loop(lat, ts, coef, 7.5, history=hist, encoder_hidden_states=e)[0])
+    first = run_concurrent(jobs)                      # graphs captured concurrently
+    alone = [j() for j in jobs]
+    for a, b in zip(first, alone):
+        assert np.isfinite(a).all() and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert not np.array_equal(alone[0], alone[1])     # different prompts / weights: the jobs are not copies of each other
+    for _ in range(5):
+        for a, b in zip(run_concurrent(jobs), alone):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    for m in models:
+        m.close()
