@@ -172,6 +172,10 @@ def main():
         sync()
 
     gpu_before = gpu_state(local_rank) if rank == 0 and not stub else None
+    calib = None
+    if rank == 0 and not stub:   # what THIS box can do, measured before the warm-up by four fixed micro-kernels (calib.hip)
+        from python_hip_stable_diffusion import _lib as _sdlib
+        calib = _sdlib.calibrate(local_rank)
     if args.warmup > 0:
         run(args.warmup)
     rep_s, rep_ev = [], []
@@ -255,6 +259,8 @@ def main():
         "e2e": {"model_build_s": round(build_s, 1), "final_latents_finite": True,
                 "gathered_latents": list(all_final.shape), "hbm_bytes": int(model.device_bytes)},
     }
+    if calib is not None:
+        out.update(normalised(value, calib))
     if world == 1:
         out["roofline"].update(hbm_traffic(ev_ms_step, args, lat_hw))
         out["roofline"].update(kernel_families(ops, ev_ms_step))
@@ -270,6 +276,27 @@ def main():
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+# Reference calibration: the box every `value_normalised` is expressed on (CALIB_REF) and how much of the step time follows each
+# calibration figure (CALIB_WEIGHTS, fitted over the boxes of round 5: profiles/r05_calibration_fit.txt).
+CALIB_REF = {"copy_gbs": 4800.0, "mfma_tflops": 1600.0, "empty_launch_us": 2.0, "chain_us": 6.0}
+CALIB_WEIGHTS = {"chain_us": 1.0}
+
+
+def normalised(value, calib):
+    """`value` as the reference box would have measured it: the step time is modelled as a weighted sum of terms that scale with
+    the box's calibration figures (time-like figures directly, rate-like figures inversely); `value` itself stays raw."""
+    scale = 0.0
+    for k, w in CALIB_WEIGHTS.items():
+        ratio = calib[k] / CALIB_REF[k] if k.endswith("_us") else CALIB_REF[k] / calib[k]
+        scale += w * ratio            # > 1: this box is slower than the reference on that term
+    return {"calibration": dict(calib, reference=CALIB_REF, weights=CALIB_WEIGHTS,
+                                note="calib.hip: 1-GiB copy GB/s, dense MFMA loop TFLOP/s, us per launch of a 323-launch empty graph, us per "
+                                     "launch of a 323-launch chain of short kernels on cold operands; measured before the warm-up"),
+            "value_normalised": round(value * scale, 3),
+            "value_normalised_note": "value x (this box's modelled step time / the reference box's): comparable across boxes of the pool; "
+                                     "`value` is the raw measurement"}
 
 
 def concurrent_prompts(model, HipModel, ucfg, checkpoint, args, lat_hw, device, loop_inputs, latents):

@@ -382,7 +382,7 @@ void launch8(const Attn8Args& a0, int B, hipStream_t s) {
 // Build-time decision of the producers of V^T (UNet builder, sd_op_attention): d = 64 and whole 64-key tiles run on this
 // kernel, which reads V^T in the permuted key order of AttnDesc::vt_perm.  SD_ATTN8=0 keeps the general kernels (A/B).
 bool attention8_shape_ok(int d, int Sq, int Sk) {
-  static const bool off = getenv("SD_ATTN8") && atoi(getenv("SD_ATTN8")) == 0;
+  static const bool off = tune_env_int("SD_ATTN8", 1) == 0;
   return !off && d == 64 && Sq >= 1 && Sk >= KT && Sk % KT == 0;
 }
 
@@ -394,10 +394,10 @@ bool attention8_ok(const AttnDesc& d) {
 
 void launch_attention8(const AttnDesc& d, hipStream_t s) {
   Attn8Args a{d.q, d.k, d.vt, d.out, d.heads, d.Sq, d.Sk, d.ldq, d.ldk, d.ldv, d.ldo, 1.4426950408889634f / 8.0f, 0};
-  static const bool exact = getenv("SD_ATTN8_EXACT") && atoi(getenv("SD_ATTN8_EXACT")) != 0;
+  static const bool exact = tune_env_int("SD_ATTN8_EXACT", 0) != 0;
   // 256-query workgroups when they give at least half the CUs one, else 128-query ones: more, smaller workgroups
   const long wg8 = (long)d.B * d.heads * cdiv(d.Sq, 256);
-  static const int force = getenv("SD_ATTN8_WAVES") ? atoi(getenv("SD_ATTN8_WAVES")) : 0;
+  static const int force = tune_env_int("SD_ATTN8_WAVES", 0);
   const bool eight = force ? force == 8 : wg8 >= 128;
   if (eight) {
     if (exact) launch8<8, 4, true>(a, d.B, s);

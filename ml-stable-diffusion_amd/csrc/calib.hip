@@ -1,0 +1,159 @@
+// Box calibration for bench.py: boxes of the GPU pool run ONE binary of this library 20 % apart at identical
+// reported clocks, so a single ms-per-step figure says nothing about a code change unless it comes with what the box itself
+// can do.  Four fixed micro-measurements, none of which touches the UNet code:
+//   copy_gbs        float4 copy of 1 GiB (read + written bytes / time): the HBM stream
+//   mfma_tflops     dense v_mfma_f32_32x32x16_f16 register loop, every SIMD busy: the matrix pipe at the box's power state
+//   empty_launch_us a captured graph of 323 empty 256-workgroup launches (the step's launch count): the launch floor
+//   chain_us        the same graph shape, each launch reading 8 MB it has never touched and writing 0.5 MB the next one
+//                   reads back: a dependent chain of short kernels on cold operands - what the batch-2 step actually is
+#include "kernels.h"
+
+namespace sd {
+
+namespace {
+
+__global__ __launch_bounds__(256) void calib_copy_kernel(const floatx4* __restrict__ src, floatx4* __restrict__ dst, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void calib_mfma_kernel(float* out, int iters) {
+  half8 a, b;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    a[e] = (half_t)(0.001f * (float)((threadIdx.x + e) & 7));
+    b[e] = (half_t)(0.002f * (float)((threadIdx.x * 3 + e) & 7));
+  }
+  floatx16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  if (s == 123.456f) out[0] = s;   // keeps the loop alive, never true
+}
+
+__global__ __launch_bounds__(256) void calib_empty_kernel(float* out) {
+  if (out == nullptr) return;   // (always taken apart from the first thread's never-true test below)
+  if (threadIdx.x == 1023) out[0] = 0.f;
+}
+
+// 512 workgroups: each thread reads 4 x 16 B of `cold` it has not seen (8 MB per launch at a rotating offset) plus 16 B of what
+// the previous launch wrote, and writes 16 B for the next one.
+__global__ __launch_bounds__(256) void calib_chain_kernel(const floatx4* __restrict__ cold, size_t off4, const floatx4* __restrict__ prev,
+                                                           floatx4* __restrict__ next) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  floatx4 s = prev[t];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) s += cold[off4 + (size_t)k * 512 * 256 + t];
+  next[t] = s;
+}
+
+float time_graph(hipStream_t st, hipGraphExec_t g, int reps) {
+  hipEvent_t e0, e1;
+  SD_HIP(hipEventCreate(&e0));
+  SD_HIP(hipEventCreate(&e1));
+  SD_HIP(hipGraphLaunch(g, st));
+  SD_HIP(hipStreamSynchronize(st));
+  SD_HIP(hipEventRecord(e0, st));
+  for (int i = 0; i < reps; ++i) SD_HIP(hipGraphLaunch(g, st));
+  SD_HIP(hipEventRecord(e1, st));
+  SD_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  SD_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return ms / (float)reps;
+}
+
+}  // namespace
+
+// out[0..3] = copy_gbs, mfma_tflops, empty_launch_us, chain_us
+void run_calibration(int device, float* out) {
+  SD_HIP(hipSetDevice(device));
+  hipStream_t st;
+  SD_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  const size_t bytes = (size_t)1 << 30, n4 = bytes / 16;
+  floatx4 *src = nullptr, *dst = nullptr;
+  SD_HIP(hipMalloc(reinterpret_cast<void**>(&src), bytes));
+  SD_HIP(hipMalloc(reinterpret_cast<void**>(&dst), bytes));
+  SD_HIP(hipMemsetAsync(src, 1, bytes, st));
+  SD_HIP(hipMemsetAsync(dst, 0, bytes, st));
+  hipEvent_t e0, e1;
+  SD_HIP(hipEventCreate(&e0));
+  SD_HIP(hipEventCreate(&e1));
+  auto timed = [&](int reps, auto&& launch) {
+    launch();
+    SD_HIP(hipStreamSynchronize(st));
+    SD_HIP(hipEventRecord(e0, st));
+    for (int i = 0; i < reps; ++i) launch();
+    SD_HIP(hipEventRecord(e1, st));
+    SD_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    SD_HIP(hipEventElapsedTime(&ms, e0, e1));
+    return ms / (float)reps;
+  };
+  // (a) copy
+  {
+    const float ms = timed(6, [&] { hipLaunchKernelGGL(calib_copy_kernel, dim3(256 * 16), dim3(256), 0, st, src, dst, n4); });
+    out[0] = (float)(2.0 * (double)bytes / (ms * 1e-3) / 1e9);
+  }
+  // (b) dense MFMA loop: 2048 workgroups x 4 waves x iters x 4 MFMAs x 32768 FLOP
+  {
+    const int iters = 1024, wgs = 2048;
+    float* sink = reinterpret_cast<float*>(dst);
+    const float ms = timed(4, [&] { hipLaunchKernelGGL(calib_mfma_kernel, dim3(wgs), dim3(256), 0, st, sink, iters); });
+    out[1] = (float)((double)wgs * 4 * iters * 4 * 32768.0 / (ms * 1e-3) / 1e12);
+  }
+  // (c) / (d): captured graphs of 323 launches
+  const int kLaunches = 323;
+  auto capture = [&](auto&& body) {
+    hipGraph_t g;
+    hipGraphExec_t ge;
+    SD_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    body();
+    SD_HIP(hipStreamEndCapture(st, &g));
+    SD_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g);
+    return ge;
+  };
+  {
+    float* sink = reinterpret_cast<float*>(dst);
+    hipGraphExec_t ge = capture([&] {
+      for (int i = 0; i < kLaunches; ++i) hipLaunchKernelGGL(calib_empty_kernel, dim3(256), dim3(256), 0, st, sink);
+    });
+    out[2] = time_graph(st, ge, 10) * 1e3f / (float)kLaunches;
+    (void)hipGraphExecDestroy(ge);
+  }
+  {
+    // ping-pong hand-over buffers at the start of dst; the cold reads walk src in 8-MB steps with a 3-MB skew (never the same lines
+    // twice inside one replay: 323 x 8 MB > 1 GiB wraps once, onto lines evicted 1 GiB of traffic earlier)
+    floatx4* pp0 = dst;
+    floatx4* pp1 = dst + (size_t)512 * 256;
+    const size_t span4 = (size_t)4 * 512 * 256;   // float4s read per launch
+    hipGraphExec_t ge = capture([&] {
+      size_t off = 0;
+      for (int i = 0; i < kLaunches; ++i) {
+        hipLaunchKernelGGL(calib_chain_kernel, dim3(512), dim3(256), 0, st, src, off, (i & 1) ? pp1 : pp0, (i & 1) ? pp0 : pp1);
+        off += span4 + 196608;
+        if (off + span4 > n4) off = (off + span4) % (n4 - span4);
+      }
+    });
+    out[3] = time_graph(st, ge, 10) * 1e3f / (float)kLaunches;
+    (void)hipGraphExecDestroy(ge);
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(src);
+  (void)hipFree(dst);
+  (void)hipStreamDestroy(st);
+}
+
+}  // namespace sd

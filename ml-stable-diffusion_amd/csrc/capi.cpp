@@ -74,7 +74,7 @@ struct Scratch {
     // SD_BENCH_COLD=1: every timed launch starts with cold caches like a kernel inside the UNet step does (its
     // weights were last touched 1.7 GB of traffic ago): a 512-MiB fill between launches evicts the L2s and the
     // 256-MiB Infinity Cache; each launch gets its own event pair.  Default: back-to-back launches, operands warm.
-    static const bool cold = getenv("SD_BENCH_COLD") != nullptr;
+    static const bool cold = tune_env_set("SD_BENCH_COLD");
     if (cold) {
       const size_t flush_bytes = (size_t)512 << 20;
       void* flush = dev<char>(flush_bytes);
@@ -415,6 +415,12 @@ int sd_op_conv2d(const void* x, const void* w, const float* bias, const void* re
     if (d.debug & 4) d.prof = sc.dev<long long>(8);
     const bool fast = force_generic != 1 && conv_fast_path_ok(d);
     ConvWorkspace ws;
+    if (fast && d.tile == 9) {   // plan tile 9: the weight-streaming kernel reads the fragment-major copy of the weights
+      SD_REQUIRE(wstream_shape_ok(d), kInvalidArgument, "conv2d: shape not eligible for plan tile 9 (wstream.hip)");
+      half_t* wtd = sc.dev<half_t>(wstream_tiled_halves(Cout, Cin, ksize));
+      launch_wstream_retile(d.w, wtd, Cout, Cin, ksize, sc.stream);
+      d.w_tiled = wtd;
+    }
     if (fast) {
       ws.partial_bytes = conv_workspace_bytes(d);
       if (ws.partial_bytes) ws.partial = reinterpret_cast<float*>(sc.dev<char>(ws.partial_bytes));
@@ -477,17 +483,42 @@ int sd_op_conv2d_groupnorm(const void* x, const void* w, const float* bias, cons
       std::vector<float> poison(groupnorm_scratch_floats(B, H * W, groups), 1.0e30f);
       SD_HIP(hipMemcpy(partial, poison.data(), poison.size() * sizeof(float), hipMemcpyHostToDevice));
     }
-    if (producer_stats) {
+    if (producer_stats == 1) {
       d.gn_partial = partial;
       d.gn_groups = groups;
     }
     float* dgw = sc.dev<float>(Cout, gn_weight);
     float* dgb = sc.dev<float>(Cout, gn_bias);
     ConvWorkspace ws;
+    if (fast && d.tile == 9) {   // the weight-streaming kernel reads the fragment-major copy of the weights (wstream.hip)
+      SD_REQUIRE(wstream_shape_ok(d), kInvalidArgument, "conv2d_groupnorm: shape not eligible for plan tile 9");
+      half_t* wtd = sc.dev<half_t>(wstream_tiled_halves(Cout, Cin, ksize));
+      launch_wstream_retile(d.w, wtd, Cout, Cin, ksize, sc.stream);
+      d.w_tiled = wtd;
+    }
+    if (producer_stats == 2) {   // the GroupNorm as a twin of the conv's slab combine: no GroupNorm launch
+      SD_REQUIRE(fast, kInvalidArgument, "conv2d_groupnorm: GroupNorm twins need the MFMA path");
+      d.n_twins = 1;
+      d.twin[0].y = dy;
+      d.twin[0].ld = Cout;
+      d.twin[0].c_off = 0;
+      d.twin[0].cpg = Cout / groups;
+      d.twin[0].gamma = dgw;
+      d.twin[0].beta = dgb;
+      d.twin[0].eps = eps;
+      d.twin[0].silu = silu;
+      SD_REQUIRE(Cout % groups == 0 && reduce_twin_ok(H * W, Cout, 1, d.twin), kInvalidArgument,
+                 "conv2d_groupnorm: shape not eligible for a GroupNorm twin (HW=%d C=%d groups=%d)", H * W, Cout, groups);
+    }
+    if (fast) {
+      ws.partial_bytes = conv_workspace_bytes(d);
+      if (ws.partial_bytes) ws.partial = reinterpret_cast<float*>(sc.dev<char>(ws.partial_bytes));
+    }
     int n_entries = 0;
     sc.timed(iters, ms, [&] {
       n_entries = fast ? launch_conv(d, ws, sc.stream) : launch_conv_generic(d, 0, sc.stream);
-      launch_groupnorm(dconv, Cout, nullptr, 0, partial, dgw, dgb, dy, B, H * W, groups, eps, silu, sc.stream, n_entries);
+      if (producer_stats != 2)
+        launch_groupnorm(dconv, Cout, nullptr, 0, partial, dgw, dgb, dy, B, H * W, groups, eps, silu, sc.stream, n_entries);
     });
     if (entries) *entries = n_entries;
     std::vector<half_t> ot(on);
@@ -747,6 +778,14 @@ int sd_philox_randn(uint64_t seed, uint32_t offset, double* out, size_t n) {
       const double v = (double)c1 * (pi / 2147483648.0) + (pi / 4294967296.0);
       out[i] = std::sqrt(-2.0 * std::log(u)) * std::sin(v);
     }
+  });
+}
+
+int sd_calibrate(int device, float* out4) {
+  return guarded([&] {
+    SD_REQUIRE(out4, kInvalidArgument, "NULL argument");
+    require_device();
+    run_calibration(device, out4);
   });
 }
 

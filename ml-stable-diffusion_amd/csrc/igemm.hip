@@ -44,6 +44,7 @@ struct IgemmArgs {
   int M, N, K;
   int temb_stride;
   int nk_total, nk_per_split, splitk;
+  int slab;   // 1: the tile leaves as an fp32 slab of a.partial (split-K, or a forced slab for reduce_twin_kernel), no epilogue
   int out_mode, ldT;
   int debug;   // ablation (microbench only): bits 0-1: 1 = loads+barriers only, 2 = compute only; bit 2: timestamps
   long long* prof;
@@ -177,7 +178,7 @@ __device__ __forceinline__ void tile_epilogue(const IgemmArgs& a, floatx16 (&acc
   const int wm = wave / WGN, wn = wave % WGN;
   const int frow = lane & 31, hi = lane >> 5;
   // acc[i][j][r]: n = n0 + (r&3) + 8*(r>>2) + 4*hi ; m = m0 + (lane&31)
-  if (a.splitk > 1) {   // fp32 partial slabs; bias/temb/residual are applied by splitk_reduce_kernel
+  if (a.slab) {   // fp32 partial slabs; bias/temb/residual are applied by splitk_reduce_kernel / reduce_twin_kernel
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int m = m_blk + (wm * TM + i) * 32 + frow;
@@ -631,7 +632,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   // issued before the first tile's DMA (oldest VMEM ops of the wave, so the counted vmcnt waits of the ring
   // are unaffected); first used after the K loop, where they are written to LDS ahead of the epilogue barrier
   float const_b = 0.f, const_t = 0.f, const_c = 0.f;   // combined only at the store: no early use, no early wait
-  const bool use_consts = !TRANS_OUT && a.splitk == 1;
+  const bool use_consts = !TRANS_OUT && !a.slab;
   if (use_consts && tid < BN) {
     const int n = n_blk + tid;
     if (n < a.N) {
@@ -645,7 +646,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   constexpr int RIT = BM * BN / 8 / 256;
   constexpr bool RES_PRE = !TRANS_OUT && GLDS && RIT <= 4 && DBG == 0;
   half8 resv[RES_PRE ? RIT : 1];
-  const bool use_resv = RES_PRE && a.res_pre && a.res != nullptr && a.splitk == 1 && a.out_mode == kOutHalf && n_blk < a.n_trans;
+  const bool use_resv = RES_PRE && a.res_pre && a.res != nullptr && !a.slab && a.out_mode == kOutHalf && n_blk < a.n_trans;
   if constexpr (RES_PRE) {
     if (use_resv) {
 #pragma unroll
@@ -1000,7 +1001,7 @@ __global__ __launch_bounds__(256, halo_lds_bytes(64, D) <= 80 * 1024 ? 2 : 1) vo
   }
 
   float const_b = 0.f, const_t = 0.f;
-  if (a.splitk == 1 && tid < BN && n_blk + tid < a.N) {
+  if (!a.slab && tid < BN && n_blk + tid < a.N) {
     if (a.bias) const_b = a.bias[n_blk + tid];
     if (a.temb) const_t = a.temb[(size_t)b * a.temb_stride + n_blk + tid];
   }
@@ -1153,7 +1154,7 @@ __global__ __launch_bounds__(256, halo_lds_bytes(64, D) <= 80 * 1024 ? 2 : 1) vo
       }
   }
   const int ml = (wm * 2 + wk) * 32 + frow;               // tile-local pixel of this lane
-  if (a.splitk > 1) {
+  if (a.slab) {
     const int y = y0 + (ml >> 4), x = x0 + (ml & 15);
     if (y < H && x < W) {
       const int m = (b * H + y) * W + x;
@@ -1329,7 +1330,7 @@ __global__ __launch_bounds__(256, D == 2 ? 2 : 1) void gemm_pipe_kernel(IgemmArg
   // per-column epilogue constants and the residual tile, requested before the first DMA (oldest VMEM ops of the wave)
   const bool temb_uniform = a.temb != nullptr && (a.HoWo % BM) == 0;
   float const_b = 0.f, const_t = 0.f, const_c = 0.f;
-  if (a.splitk == 1 && tid < BN) {
+  if (!a.slab && tid < BN) {
     const int n = n_blk + tid;
     if (n < a.N) {
       if (a.bias) const_b = a.bias[n];
@@ -1340,7 +1341,7 @@ __global__ __launch_bounds__(256, D == 2 ? 2 : 1) void gemm_pipe_kernel(IgemmArg
   constexpr int RIT = BM * BN / 8 / 256;
   constexpr bool RES_PRE = RIT <= 4;
   half8 resv[RES_PRE ? RIT : 1];
-  const bool use_resv = RES_PRE && a.res_pre && a.res != nullptr && a.splitk == 1 && a.out_mode == kOutHalf && n_blk < a.n_trans;
+  const bool use_resv = RES_PRE && a.res_pre && a.res != nullptr && !a.slab && a.out_mode == kOutHalf && n_blk < a.n_trans;
   if constexpr (RES_PRE) {
     if (use_resv) {
 #pragma unroll
@@ -1747,6 +1748,7 @@ IgemmArgs make_args(const ConvDesc& d) {
   a.nk_total = a.K / BK;
   a.nk_per_split = a.nk_total;
   a.splitk = 1;
+  a.slab = 0;
   a.out_mode = d.out_mode;
   a.ldT = d.ldT;
   a.debug = d.debug;
@@ -1760,7 +1762,7 @@ IgemmArgs make_args(const ConvDesc& d) {
   a.ldo = d.out_t ? d.n_trans : d.N;
   a.out_t = d.out_t;
   a.vt_perm = d.out_t ? d.vt_perm : 0;
-  static const int res_pre = !(getenv("SD_RES_PREFETCH") && atoi(getenv("SD_RES_PREFETCH")) == 0);
+  static const int res_pre = tune_env_int("SD_RES_PREFETCH", 1) != 0;
   a.res_pre = res_pre;
   a.gn_partial = nullptr;
   a.gn_G = a.gn_cpg = a.gn_T = 0;
@@ -1824,7 +1826,7 @@ bool parse_plan_row(const char* line, TunedConv& r) {
 std::vector<TunedConv>& runtime_table() {
   static std::vector<TunedConv> table = [] {
     std::vector<TunedConv> t;
-    const char* path = getenv("SD_PLAN_TABLE");
+    const char* path = tune_env_set("SD_PLAN_TABLE") ? getenv("SD_PLAN_TABLE") : nullptr;
     if (!path) return t;
     FILE* f = fopen(path, "r");
     if (!f) {
@@ -1864,7 +1866,11 @@ Plan choose_plan(const ConvDesc& d, const IgemmArgs& a) {
   // (round 2's first halo kernel) and 8 / 9 (256x128 / 256x256 GEMM tiles, measured in round 3 and selected nowhere) were removed
   // in round 4: a caller or table row that names them gets the heuristic.
   auto is_halo = [](int c) { return c == 7; };
+  // plan tile 9 = the weight-streaming kernel of wstream.hip (needs the pre-tiled weights; staging 4 = four waves per workgroup,
+  // anything else eight; its slab count follows from the wave count).  SD_WSTREAM=0 (with SD_TUNE) takes it out of every plan: A/B.
+  static const int ws_mode = tune_env_int("SD_WSTREAM", 1);
   auto tile_ok = [&](int c) {
+    if (c == 9) return ws_mode != 0 && d.w_tiled != nullptr && can_split && wstream_shape_ok(d);
     if (!((c >= 1 && c <= 4) || c == 7)) return false;
     if (is_halo(c)) return halo_ks_ok(d) && !d.ln_colsum && !d.out_t && !geglu;
     int bm, bn;
@@ -1914,6 +1920,12 @@ Plan choose_plan(const ConvDesc& d, const IgemmArgs& a) {
   // (measured and dropped, round 3: sending every untuned 1x1 GEMM with M >= 8192 to the software-pipelined kernel's 128x64
   // tile - 10-25 % faster stand-alone at UNet batch 16 - made the batch-16 step 1.3 % and the batch-4 step 0.6 % SLOWER in
   // sequence; the pipelined kernel is only used where tools/tune_e2e.py accepted it end to end)
+  // 8x8 level at any small batch: a 3x3 conv there is a weight stream (wstream.hip), whatever the table says for M = 128
+  if (p.tile == 0 && tile_ok(9) && a.ksize == 3 && a.HoWo <= 64 && a.M <= 256) p.tile = 9;
+  if (p.tile == 9) {
+    p.splitk = 1;   // (the launch derives the slab count from the wave count)
+    return p;
+  }
   if (p.tile == 0 && tile_ok(7)) {
     // no measured plan for this shape: the K-split halo kernel with the 4-stage ring won every 3x3 / stride-1 shape that was
     // tuned (SD2.1-base, SDXL-base, SD1.5: tuned_convs.inc); split-K below as for the other kernels
@@ -2098,7 +2110,15 @@ size_t conv_workspace_bytes(const ConvDesc& d) {
   // SD_TUNE=1 (tools/tune_plans.py): room for any split-K candidate of the sweep
   static const bool tuning = getenv("SD_TUNE") != nullptr;
   const bool can_split = d.out_mode == kOutHalf && !d.ln_colsum && !d.out_t;
-  const int splits = (tuning && can_split) ? std::max(p.splitk, 16) : p.splitk;
+  int splits = (tuning && can_split) ? std::max(p.splitk, 16) : p.splitk;
+  // the weight-streaming kernel always leaves slabs (one per NW input-channel slices; NW = 4 is the upper bound), and so does
+  // any plan once a GroupNorm twin is attached to the op (d.n_twins: launch_conv then forces the slab path)
+  bool slab = d.n_twins > 0;
+  if (d.w_tiled && can_split && wstream_shape_ok(d)) {
+    splits = std::max(splits, wstream_splits(d, 4));
+    slab = true;
+  }
+  if (splits == 1 && slab) return (size_t)a.M * a.N * sizeof(float);
   return splits > 1 ? (size_t)splits * a.M * a.N * sizeof(float) : 0;   // upper bound (launch may use fewer splits)
 }
 
@@ -2131,7 +2151,7 @@ namespace {
 // or 0 when this launch cannot produce them (bm: rows per m-tile of an igemm tile, 0 for the 8x16-pixel halo tiles)
 int setup_gn_stats(const ConvDesc& d, IgemmArgs& a, int bm) {
   a.gn_partial = nullptr;
-  if (!d.gn_partial || d.gn_groups < 1 || a.splitk > 1 || d.out_mode != kOutHalf || d.out_t || d.debug) return 0;
+  if (!d.gn_partial || d.gn_groups < 1 || a.splitk > 1 || a.slab || d.out_mode != kOutHalf || d.out_t || d.debug) return 0;
   if (a.N % d.gn_groups != 0 || a.N % 8 != 0) return 0;
   const int cpg = a.N / d.gn_groups;
   if (cpg > 64) return 0;                       // a group may span two 64-column n-tiles, not three
@@ -2163,6 +2183,33 @@ int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
   IgemmArgs a = make_args(d);
   Plan p = choose_plan(d, a);
   const bool halo = p.tile == 7;
+  const bool twins = d.n_twins > 0;
+  SD_REQUIRE(!twins || (d.out_mode == kOutHalf && !d.ln_colsum && !d.out_t && !d.debug && reduce_twin_ok(a.HoWo, a.N, d.n_twins, d.twin)),
+             kInvalidArgument, "GroupNorm twins need a plain fp16 output and whole (sample, group) slices (HoWo=%d N=%d)", a.HoWo, a.N);
+  if (p.tile == 9) {
+    // weight-streaming kernel: slabs, then the group-organised combine (with the consumer's GroupNorm twins) or the plain one
+    const int nw = p.staging == 4 ? 4 : 8;
+    const int S = wstream_splits(d, nw);
+    const size_t need = (size_t)S * a.M * a.N * sizeof(float);
+    SD_REQUIRE(ws.partial && ws.partial_bytes >= need, kInternal, "wstream workspace too small (%zu < %zu)", ws.partial_bytes, need);
+    static const bool log_ws = tune_env_set("SD_LOG_CONVS");
+    if (log_ws)
+      fprintf(stderr, "[sd conv] k%d up%d C0=%d C1=%d M=%d N=%d K=%d tile=9 nw=%d slabs=%d twins=%d\n", a.ksize, a.up, a.C0, a.C1, a.M, a.N,
+              a.K, nw, S, d.n_twins);
+    launch_wstream(d, ws.partial, nw, s);
+    a.partial = ws.partial;
+    a.splitk = S;
+    a.slab = 1;
+    if (twins) {
+      launch_reduce_twin(a.partial, S, a.M, a.N, a.HoWo, a.bias, a.temb, a.temb_stride, a.res, a.out, d.n_twins, d.twin, s);
+    } else {
+      size_t total4 = (size_t)a.M * a.N / 4;
+      int blocks = (int)std::min<size_t>((total4 + 255) / 256, 2048);
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a);
+    }
+    SD_HIP(hipGetLastError());
+    return 0;
+  }
   if (halo) {
     const int nch = a.Ctot / BK;
     a.nk_per_split = cdiv(nch, p.splitk);
@@ -2172,7 +2219,8 @@ int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
     a.nk_per_split = cdiv(a.nk_total, p.splitk);
     a.splitk = cdiv(a.nk_total, a.nk_per_split);   // no empty splits
   }
-  if (a.splitk > 1) {
+  a.slab = (a.splitk > 1 || twins) ? 1 : 0;
+  if (a.slab) {
     size_t need = (size_t)a.splitk * a.M * a.N * sizeof(float);
     SD_REQUIRE(ws.partial && ws.partial_bytes >= need, kInternal, "split-K workspace too small (%zu < %zu)",
                ws.partial_bytes, need);
@@ -2194,11 +2242,11 @@ int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
     const double l2 = 3.5e6;   // what one 4-MB L2 keeps of an operand next to the other one's stream
     const double m_fast_cost = w_bytes + a_bytes * (a_bytes <= l2 ? std::min(8.0, nbn) : nbn);
     const double n_fast_cost = a_bytes + w_bytes * (w_bytes <= l2 ? std::min(8.0, nbm) : nbm);
-    static const int forced = getenv("SD_TILE_ORDER") ? atoi(getenv("SD_TILE_ORDER")) : -1;   // A/B switch: 0 / 1 / 2
+    static const int forced = tune_env_int("SD_TILE_ORDER", -1);   // A/B switch: 0 / 1 / 2
     if (forced == 2) a.n_fast = nbn > 1 && a_bytes * (nbn - 1) > 7.0 * w_bytes;
     else a.n_fast = forced >= 0 ? (forced != 0) : (nbn > 1 && n_fast_cost < m_fast_cost);
   }
-  static const bool log_plans = getenv("SD_LOG_CONVS") != nullptr;
+  static const bool log_plans = tune_env_set("SD_LOG_CONVS");
   if (log_plans)
     fprintf(stderr, "[sd conv] k%d s%d up%d C0=%d C1=%d M=%d N=%d K=%d mode=%d tile=%d splitk=%d\n", a.ksize, a.stride, a.up,
             a.C0, a.C1, a.M, a.N, a.K, d.out_mode, p.tile, a.splitk);
@@ -2223,7 +2271,9 @@ int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
       default: launch_tile<64, 128, 2, 2>(a, trans, st, s); break;
     }
   }
-  if (a.splitk > 1) {
+  if (twins) {
+    launch_reduce_twin(a.partial, a.splitk, a.M, a.N, a.HoWo, a.bias, a.temb, a.temb_stride, a.res, a.out, d.n_twins, d.twin, s);
+  } else if (a.slab) {
     size_t total4 = (size_t)a.M * a.N / 4;
     int blocks = (int)std::min<size_t>((total4 + 255) / 256, 2048);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a);

@@ -16,6 +16,19 @@ enum OutMode : int {
   kOutGeglu = 2,       // half out[M][N/2] = (v+bv) * gelu_erf(g+bg); W rows interleaved 32/32
 };
 
+// GroupNorm (+ SiLU) of a conv's OUTPUT written by the conv's own slab-combine pass (wstream.hip reduce_twin_kernel): the
+// consumer is torch.nn.GroupNorm over this tensor (unet.py:430-451, :528-531) or over a channel concat in which this tensor
+// occupies the group-aligned column range [c_off, c_off + N) (torch.cat of unet.py:213-216 followed by norm1).
+struct GnTwin {
+  half_t* y = nullptr;           // [M][ld]: the normalised copy goes to columns [c_off, c_off + N)
+  int ld = 0, c_off = 0;
+  int cpg = 0;                   // channels per group of the consuming GroupNorm
+  const float* gamma = nullptr;  // the consumer's affine, indexed by ITS channel (c_off + n)
+  const float* beta = nullptr;
+  float eps = 1e-5f;
+  int silu = 0;
+};
+
 struct ConvDesc {
   const half_t* x0 = nullptr;   // [B][Hi][Wi][C0]
   const half_t* x1 = nullptr;   // optional second source (channel concat), [B][Hi][Wi][C1]
@@ -54,6 +67,12 @@ struct ConvDesc {
   // then runs its own statistics pass.
   float* gn_partial = nullptr;
   int gn_groups = 0;
+  // weights in the fragment-major layout of wstream.hip (launch_wstream_retile), or null: plan tile 9 needs them
+  const half_t* w_tiled = nullptr;
+  // n_twins > 0: the output leaves through fp32 slabs and reduce_twin_kernel, which also writes the GroupNorm twins
+  // (needs Ho * Wo <= 256 and reduce_twin_ok; launch_conv forces the slab path whatever the plan's split-K)
+  GnTwin twin[2];
+  int n_twins = 0;
 };
 
 constexpr int kGnMaxSlabs = 256;   // entries per (sample, group) of a GroupNorm partial buffer
@@ -71,6 +90,20 @@ bool conv_fast_path_ok(const ConvDesc& d);
 // tuning hook: plan (tile 1-6, staging 0-5, splitk) forced on every conv that admits it; tile 0 = off
 void conv_tune_set_candidate(int tile, int staging, int splitk);
 int conv_plan_table_set(const char* text);   // rows of tuned_convs.inc format; returns the number of plans read
+
+// wstream.hip: the small-M weight-streaming kernel (plan tile 9) and the group-organised slab combine
+bool wstream_shape_ok(const ConvDesc& d);                 // shape admits plan tile 9 (d.w_tiled not looked at)
+int wstream_splits(const ConvDesc& d, int nw);            // slabs launch_wstream writes with nw waves per workgroup
+size_t wstream_tiled_halves(int N, int Ctot, int ksize);
+void launch_wstream_retile(const half_t* w, half_t* wt, int N, int Ctot, int ksize, hipStream_t s);
+int launch_wstream(const ConvDesc& d, float* partial, int nw, hipStream_t s);
+bool reduce_twin_ok(int HW, int N, int n_twins, const GnTwin* tw);
+void launch_reduce_twin(const float* partial, int S, int M, int N, int HW, const float* bias, const float* temb, int temb_stride,
+                        const half_t* res, half_t* out, int n_twins, const GnTwin* tw, hipStream_t s);
+
+// calib.hip: box calibration for bench.py - out[0..3] = copy GB/s, dense MFMA TFLOP/s, us per launch of a 323-launch empty
+// graph, us per launch of a 323-launch chain of short kernels on cold operands
+void run_calibration(int device, float* out);
 
 // direct conv for tiny / odd shapes (any Cin, any N): fp32 accumulate, one thread per output
 int launch_conv_generic(const ConvDesc& d, int act_silu_out, hipStream_t s);   // returns like launch_conv

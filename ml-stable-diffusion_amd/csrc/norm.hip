@@ -458,13 +458,13 @@ namespace {
 long gn_fused_max_hw() {
   // measured crossover (tools/gn_sweep.py): the single launch wins for HW <= 256 (3.5-11 us vs 10-23 us), the
   // slab pair wins at 32x32 and above (8-16 us vs 13-208 us).  SD_GN_FUSED_MAX_HW overrides for tuning.
-  static const long v = getenv("SD_GN_FUSED_MAX_HW") ? atol(getenv("SD_GN_FUSED_MAX_HW")) : 256;
+  static const long v = tune_env_int("SD_GN_FUSED_MAX_HW", 256);
   return v;
 }
 }  // namespace
 
 bool groupnorm_wants_producer_stats(int HW, int C, int G) {
-  static const bool off = getenv("SD_NO_GN_PRODUCER_STATS") != nullptr;   // A/B switch
+  static const bool off = tune_env_set("SD_NO_GN_PRODUCER_STATS");   // A/B switch
   if (off || G < 1 || C % G != 0) return false;
   const int cpg = C / G;
   const bool single_launch = HW <= gn_fused_max_hw() && cpg <= 128 && cpg % 2 == 0;
@@ -505,7 +505,7 @@ void launch_groupnorm(const half_t* x0, int C0, const half_t* x1, int C1, float*
   }
   // 32x32 level: one 1024-thread workgroup per (group, sample) instead of the slab pair (in sequence a dependent launch costs
   // more than the second pass over a slice that is still in L2); SD_GN_WIDE=0 switches it off (A/B)
-  static const bool wide = !(getenv("SD_GN_WIDE") && atoi(getenv("SD_GN_WIDE")) == 0);
+  static const bool wide = tune_env_int("SD_GN_WIDE", 1) != 0;
   if (wide && HW <= 1024 && cpg >= 16 && cpg <= 48 && cpg % 4 == 0) {   // (60-channel groups measured slower: 20.8 vs 16.0 us)
     dim3 grid(G, B);
     if (cpg % 8 == 0)

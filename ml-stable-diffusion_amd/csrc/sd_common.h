@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -74,6 +75,19 @@ struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
 };
+
+// A/B switches of the measurement tools: read from the environment ONLY when SD_TUNE is set, so a production process cannot be
+// steered by a stray variable.  (cached per call site by the callers' function-local statics)
+inline int tune_env_int(const char* name, int dflt) {
+  static const bool on = getenv("SD_TUNE") != nullptr;
+  if (!on) return dflt;
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+inline bool tune_env_set(const char* name) {
+  static const bool on = getenv("SD_TUNE") != nullptr;
+  return on && getenv(name) != nullptr;
+}
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -37,12 +37,12 @@ UNet::UNet(const sd_unet_config& cfg, const WeightStore& ws, int device) : cfg_(
   SD_REQUIRE(device >= 0 && device < ndev, kInvalidArgument, "device %d out of range (%d visible)", device, ndev);
   SD_HIP(hipSetDevice(device));
   SD_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-  if (getenv("SD_SIDE_TIME") && atoi(getenv("SD_SIDE_TIME")) != 0) {
+  if (tune_env_int("SD_SIDE_TIME", 0) != 0) {
     SD_HIP(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
     SD_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
     SD_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
   }
-  if (cfg_.support_controlnet && !cfg_.is_controlnet && !(getenv("SD_CN_CONCURRENT") && atoi(getenv("SD_CN_CONCURRENT")) == 0)) {
+  if (cfg_.support_controlnet && !cfg_.is_controlnet && tune_env_int("SD_CN_CONCURRENT", 1) != 0) {
     SD_HIP(hipStreamCreateWithFlags(&cn_stream_, hipStreamNonBlocking));
     SD_HIP(hipEventCreateWithFlags(&ev_cn_fork_, hipEventDisableTiming));
     SD_HIP(hipEventCreateWithFlags(&ev_cn_join_, hipEventDisableTiming));
@@ -232,7 +232,7 @@ bool UNet::can_fold_ln(const Tensor& x, int cout, bool geglu) const {
   d.N = cout;
   d.ksize = 1;
   d.out_mode = geglu ? kOutGeglu : kOutHalf;
-  static const bool off = getenv("SD_NO_LN_FOLD") != nullptr;   // A/B switch for measurements
+  static const bool off = tune_env_set("SD_NO_LN_FOLD");   // A/B switch for measurements
   return !off && conv_fast_path_ok(d);
 }
 
@@ -313,16 +313,33 @@ Tensor UNet::conv_w(std::vector<Op>& ops, const std::string& name, const half_t*
   if (out_mode == kOutHalf && !(ex && ex->n_trans > 0)) {
     hook = std::make_shared<GnHook>();
     out.gn = hook;
+    hook->ops_pos = (int)ops.size();
+    hook->ops_list = &ops;
   }
   auto with_hook = [hook](const ConvDesc& d0) {
     ConvDesc dd = d0;
     if (hook) {
       dd.gn_partial = hook->partial;
       dd.gn_groups = hook->groups;
+      dd.n_twins = hook->n_twins;
+      for (int k = 0; k < hook->n_twins; ++k) dd.twin[k] = hook->twin[k];
     }
     return dd;
   };
   if (conv_fast_path_ok(d) && !silu_out) {
+    // small-M layers: the weight-streaming kernel (plan tile 9) needs the fragment-major copy of the weights
+    static const int ws_mode = tune_env_int("SD_WSTREAM", 1);
+    const int Mrows = x.B * d.Ho * d.Wo;
+    if (ws_mode != 0 && !ex && wstream_shape_ok(d) && ((k == 3 && Mrows <= 512) || (k == 1 && Mrows <= 128))) {
+      const int cin_t = x.C + (x2 ? x2->C : 0);
+      half_t* wt = arena_.alloc_n<half_t>(wstream_tiled_halves(cout, cin_t, k));
+      launch_wstream_retile(w, wt, cout, cin_t, k, stream_);
+      d.w_tiled = wt;
+    }
+    if (hook) {
+      hook->twin_capable = !ex && d.Ho * d.Wo <= 256;
+      hook->desc = d;
+    }
     ws_need_ = std::max(ws_need_, conv_workspace_bytes(d));
     ops.push_back([this, d, hook, with_hook](hipStream_t s) {
       const int n = launch_conv(with_hook(d), ws_conv_, s);
@@ -367,17 +384,64 @@ Tensor UNet::group_norm(std::vector<Op>& ops, const std::string& name, const Ten
     ops.back().label = "groupnorm fp32 C=" + std::to_string(C) + " @" + std::to_string(x.H) + "x" + std::to_string(x.W) + " " + name;
     return y;
   }
-  float* partial = arena_.alloc_n<float>(groupnorm_scratch_floats(x.B, x.H * x.W, G));
   const float* gamma = upload_vec(name + ".weight", C);
   const float* beta = upload_vec(name + ".bias", C);
   Tensor y = new_tensor(x.B, x.H, x.W, C);
+  // 8x8 / 16x16 levels: every source is the output of a conv that can leave through the group-organised slab combine, and the
+  // group boundaries fall on the source boundaries -> the producers write this GroupNorm themselves (GnHook twins), no launch.
+  // SD_GN_TWIN=0 (with SD_TUNE) keeps the launch: A/B.
+  {
+    static const int twin_mode = tune_env_int("SD_GN_TWIN", 1);
+    const int cpg = C / G;
+    const Tensor* srcs[2] = {&x, x2};
+    bool ok = twin_mode != 0 && x.H * x.W <= 256 && cpg % 4 == 0 && (!x2 || x.C % cpg == 0);
+    for (int i = 0; i < 2 && ok; ++i) {
+      const Tensor* t = srcs[i];
+      if (!t) continue;
+      const GnHook* hk = t->gn.get();
+      ok = hk && hk->twin_capable && hk->ops_list == &ops && hk->n_twins < 2 && hk->desc.N == t->C && t->C % cpg == 0;
+      if (ok) {
+        GnTwin tw[2];
+        int n = hk->n_twins;
+        for (int k = 0; k < n; ++k) tw[k] = hk->twin[k];
+        tw[n].cpg = cpg;
+        tw[n].c_off = i == 0 ? 0 : x.C;
+        tw[n].ld = C;
+        ok = reduce_twin_ok(t->H * t->W, t->C, n + 1, tw);
+      }
+    }
+    if (ok) {
+      for (int i = 0; i < 2; ++i) {
+        const Tensor* t = srcs[i];
+        if (!t) continue;
+        GnHook* hk = t->gn.get();
+        GnTwin& tw = hk->twin[hk->n_twins++];
+        tw.y = y.p;
+        tw.ld = C;
+        tw.c_off = i == 0 ? 0 : x.C;
+        tw.cpg = cpg;
+        tw.gamma = gamma;
+        tw.beta = beta;
+        tw.eps = eps;
+        tw.silu = silu ? 1 : 0;
+        ConvDesc dd = hk->desc;
+        dd.n_twins = hk->n_twins;
+        ws_need_ = std::max(ws_need_, conv_workspace_bytes(dd));
+      }
+      return y;
+    }
+  }
+  float* partial = arena_.alloc_n<float>(groupnorm_scratch_floats(x.B, x.H * x.W, G));
   const half_t* p0 = x.p;
   const half_t* p1 = x2 ? x2->p : nullptr;
   const int C0 = x.C, C1 = x2 ? x2->C : 0, B = x.B, HW = x.H * x.W, si = silu ? 1 : 0;
   half_t* yp = y.p;
   // single-source GroupNorm that would need its own statistics launch: ask the op that produced x for them
   std::shared_ptr<GnHook> hook;
-  if (!x2 && x.gn && !x.gn->partial && groupnorm_wants_producer_stats(HW, C, G)) {
+  if (!x2 && x.gn && !x.gn->partial && x.gn->n_twins == 0 && groupnorm_wants_producer_stats(HW, C, G)) {
+    // (`entries` is handed over at launch time - the producer must run first, in the same launch list)
+    SD_REQUIRE(x.gn->ops_list == &ops && x.gn->ops_pos >= 0 && x.gn->ops_pos < (int)ops.size(), kInternal,
+               "%s: GroupNorm producer statistics need the producing op earlier in the same launch list", name.c_str());
     hook = x.gn;
     hook->partial = partial;
     hook->groups = G;
@@ -1450,7 +1514,7 @@ void UNet::denoise_loop(const sd_unet_io& io, float* latents, int n_images, int 
   // pass (rows = steps x batch through the same GEMV kernels) and each step copies its rows inside loop_prep - four
   // dependent launches (~65 us) less per step for ~0.5 ms once per call.  Recomputed on every call: nothing is cached
   // across generations.  SDXL's text_time conditioning enters the same MLP: it keeps the in-step path.
-  static const bool hoist_off = getenv("SD_NO_TEMB_TABLE") != nullptr;   // A/B switch
+  static const bool hoist_off = tune_env_set("SD_NO_TEMB_TABLE");   // A/B switch
   const bool hoist = !hoist_off && tpath_.ok && temb_w_all_ && temb_used_ > 0 && temb_used_ % 4 == 0;
   if (hoist) {
     const int Bt = cfg_.batch, rows = n_steps * Bt;

@@ -12,10 +12,24 @@ namespace sd {
 // Link between a conv / GEMM op and the GroupNorm that consumes its output: the GroupNorm (built later) asks the
 // producer to leave per-tile (sum, sumsq) partials of the tensor in `partial`; at launch time the producer reports how
 // many entries per (sample, group) its plan wrote (0: none - split-K, ragged tiles - the GroupNorm runs its own pass).
+// `entries` is written by the producer's launch closure and read by the GroupNorm's: the GroupNorm op MUST sit behind its
+// producer in the launch list (UNet::group_norm asserts the positions at build time: ops_pos of the producer < its own).
+//
+// Twins (round 5): at the 8x8 / 16x16 levels (Ho * Wo <= 256) the producer can leave through fp32 slabs and the group-organised
+// combine of wstream.hip, which holds whole (sample, group) slices and writes the GroupNorm(+SiLU) the consumer asks for next to
+// the raw tensor - the GroupNorm launch disappears.  A GroupNorm built later registers up to two twins here (a tensor can be
+// normalised on its own by the next resnet AND as the second source of an up-block concat); the producer's closure reads them
+// at launch time.
 struct GnHook {
   float* partial = nullptr;
   int groups = 0;
   int entries = 0;
+  int ops_pos = -1;              // index of the producing op in its launch list
+  const void* ops_list = nullptr;
+  bool twin_capable = false;     // the producer can run the slab + reduce_twin path
+  ConvDesc desc;                 // the producer's conv (workspace sizing when a twin is attached)
+  GnTwin twin[2];
+  int n_twins = 0;
 };
 
 struct Tensor {

@@ -316,7 +316,7 @@ void launch_nst(const XAttnArgs& a, hipStream_t s) {
 }  // namespace
 
 bool xattn_fused_ok(int C, int heads, int S, int L) {
-  static const bool off = getenv("SD_NO_XATTN_FUSED") != nullptr;   // A/B switch
+  static const bool off = tune_env_set("SD_NO_XATTN_FUSED");   // A/B switch
   return !off && heads >= 1 && C == heads * XD && C % BK == 0 && S >= 1 && L >= 1 && L <= XKEYS;
 }
 
@@ -331,7 +331,7 @@ void launch_xattn_fused(const XAttnDesc& d, hipStream_t s) {
               1.4426950408889634f / sqrtf((float)XD)};
   // ring depth: 2 stages keep two workgroups on a CU (75 KB each), 3 / 4 stages keep more of the weight panel in flight for
   // the deep-K levels; SD_XATTN_NST overrides (tuning)
-  static const int forced = getenv("SD_XATTN_NST") ? atoi(getenv("SD_XATTN_NST")) : 0;
+  static const int forced = tune_env_int("SD_XATTN_NST", 0);
   const int nst = forced ? forced : (d.nst ? d.nst : (d.C <= 640 ? 2 : 3));
   if (nst >= 5) launch_nst<5>(a, s);
   else if (nst == 4) launch_nst<4>(a, s);

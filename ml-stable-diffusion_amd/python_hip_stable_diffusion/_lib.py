@@ -99,6 +99,7 @@ SYMBOLS = [
     ("sd_numpy_randn", _I, [C.c_uint32, C.POINTER(C.c_double), C.c_size_t]),
     ("sd_torch_randn", _I, [C.c_uint32, C.POINTER(C.c_double), C.c_size_t]),
     ("sd_philox_randn", _I, [C.c_uint64, C.c_uint32, C.POINTER(C.c_double), C.c_size_t]),
+    ("sd_calibrate", _I, [_I, _FP]),
     ("sd_selftest_mfma", _I, []),
 ]
 
@@ -281,3 +282,11 @@ def philox_randn(seed, n, offset=0):
     out = np.empty(n, np.float64)
     check(lib().sd_philox_randn(seed, offset, out.ctypes.data_as(C.POINTER(C.c_double)), n))
     return out
+
+
+def calibrate(device=0):
+    """Four fixed micro-measurements of the box (calib.hip): what bench.py prints as `calibration` and normalises by."""
+    out = (C.c_float * 4)()
+    check(lib().sd_calibrate(device, out))
+    return {"copy_gbs": round(out[0], 1), "mfma_tflops": round(out[1], 1), "empty_launch_us": round(out[2], 3),
+            "chain_us": round(out[3], 3)}

@@ -1,0 +1,132 @@
+"""Round-5 kernels through the C ABI against fp32 torch:
+  * the small-M weight-streaming conv kernel (wstream.hip, plan tile 9): 3x3 stride-1 convs of the 8x8 / 16x16 levels incl. the
+    nearest-x2 upsample gather, 1x1 GEMMs, dead K-slice waves, odd batch (unet.py:435-468, :496-500);
+  * GroupNorm(+SiLU) written by the conv's own slab combine ("twin", reduce_twin_kernel) instead of a GroupNorm launch
+    (unet.py:430-451, :472-481, :528-531).
+Tolerances as tests/test_ops_gpu.py: PSNR >= 60 dB, max |err| <= 4e-3 * max|ref| + 1e-3 (fp16 I/O, fp32 accumulate)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import psnr
+from python_hip_stable_diffusion import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def h16(a):
+    return np.asarray(a, np.float32).astype(np.float16)
+
+
+def close(got, ref, what, min_psnr=60.0, rel=4e-3):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert np.isfinite(got).all(), what
+    p = psnr.compute_psnr(got, ref)
+    err = np.abs(got - ref).max()
+    bound = rel * np.abs(ref).max() + 1e-3
+    assert p >= min_psnr and err <= bound, f"{what}: PSNR {p:.1f} dB, max|err| {err:.3e} (bound {bound:.3e})"
+
+
+def conv_ref(x, w, bias, res, upsample):
+    xt = torch.from_numpy(x.astype(np.float32))
+    if upsample:
+        xt = F.interpolate(xt, scale_factor=2.0, mode="nearest")
+    y = F.conv2d(xt, torch.from_numpy(w.astype(np.float32)), None if bias is None else torch.from_numpy(bias), padding=w.shape[2] // 2)
+    if res is not None:
+        y = y + torch.from_numpy(res.astype(np.float32))
+    return y
+
+
+WS_CASES = [  # (B, Cin, H, W, Cout, k, upsample)
+    (2, 256, 8, 8, 128, 3, False),      # the 8x8 level: two images per 128-pixel block
+    (2, 1280, 8, 8, 1280, 3, False),    # SD2.1-base mid-block resnet conv at full size (5 slabs at 8 waves)
+    (1, 96, 8, 8, 32, 3, False),        # odd batch (second sub-tile masked), 3 input slices: dead waves
+    (3, 64, 8, 8, 64, 3, False),        # two blocks, the second half empty
+    (2, 128, 16, 16, 96, 3, False),     # the 16x16 level: 8-row blocks, four of them
+    (2, 64, 8, 8, 64, 3, True),         # Upsample2D (unet.py:492-500): 8x8 source, 16x16 output
+    (1, 320, 16, 16, 64, 3, False),     # 10 slices: two K splits at 8 waves with a ragged tail
+    (2, 128, 8, 8, 96, 1, False),       # 1x1
+    (2, 1280, 8, 8, 1280, 1, False),    # proj_in / to_out of the mid block
+    (5, 64, 4, 4, 32, 1, False),        # 1x1: M = 80 < 128 (masked rows)
+]
+
+
+@pytest.mark.parametrize("case", WS_CASES, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("tile", [9, 49], ids=["8waves", "4waves"])
+def test_weight_streaming_conv_matches_torch(case, tile):
+    b, cin, h, w_, cout, k, up = case
+    rs = np.random.RandomState(cin + cout + h + k)
+    x = h16(rs.randn(b, cin, h, w_))
+    w = h16(rs.randn(cout, cin, k, k) / np.sqrt(cin * k * k))
+    bias = (0.1 * rs.randn(cout)).astype(np.float32)
+    ho = h * (2 if up else 1)
+    res = h16(rs.randn(b, cout, ho, ho * w_ // h))
+    ref = conv_ref(x, w, bias, res, up).numpy()
+    out, _ = _lib.conv2d(x, w, bias, res, upsample=up, tile=tile)
+    close(out, ref, f"wstream conv {case} tile {tile}")
+    again, _ = _lib.conv2d(x, w, bias, res, upsample=up, tile=tile, iters=3)
+    assert np.array_equal(out, again), "replays must be bit-identical (fixed-order slab sums)"
+    # the same conv on the tiled kernels of igemm.hip: two kernels, one answer
+    base, _ = _lib.conv2d(x, w, bias, res, upsample=up)
+    close(out, base.astype(np.float32), f"wstream vs tiled kernel {case}", min_psnr=65.0)
+
+
+def test_weight_streaming_rejects_ineligible_shapes():
+    rs = np.random.RandomState(0)
+    x = h16(rs.randn(1, 64, 32, 32))
+    w = h16(rs.randn(64, 64, 3, 3) * 0.05)
+    with pytest.raises(ValueError):
+        _lib.conv2d(x, w, tile=9)               # 32-pixel-wide image: not the 8x8 / 16x16 form
+    x = h16(rs.randn(1, 64, 8, 8))
+    with pytest.raises(ValueError):
+        _lib.conv2d(x, w, stride=2, tile=9)     # stride 2
+
+
+TWIN_CASES = [  # (B, Cin, HW, Cout, k, silu, tile)
+    (2, 128, 8, 1280, 3, True, 0),      # 40-channel groups, default plan forced onto the slab path
+    (2, 128, 8, 1280, 3, True, 9),      # ... behind the weight-streaming kernel
+    (2, 1280, 8, 1280, 3, True, 9),     # full-size resnet conv of the 8x8 level
+    (2, 64, 16, 640, 3, True, 0),       # 20-channel groups at 16x16
+    (2, 64, 16, 1280, 3, False, 9),     # SpatialTransformer norm (no SiLU) at 16x16: 10 items per thread
+    (1, 64, 16, 2560, 1, True, 0),      # 80-channel groups: 20 items per thread
+    (2, 256, 8, 1280, 1, False, 0),     # proj_out-like 1x1 GEMM forced onto the slab path
+    (2, 64, 4, 256, 3, True, 0),        # 8-channel groups, 4x4 image
+]
+
+
+@pytest.mark.parametrize("case", TWIN_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_groupnorm_twin_of_the_slab_combine(case):
+    b, cin, hw, cout, k, silu, tile = case
+    rs = np.random.RandomState(cin + cout + hw)
+    x = h16(rs.randn(b, cin, hw, hw))
+    w = h16(rs.randn(cout, cin, k, k) / np.sqrt(cin * k * k))
+    bias = (0.1 * rs.randn(cout)).astype(np.float32) + 0.3
+    res = h16(rs.randn(b, cout, hw, hw) * 0.5 + 0.2)
+    gw = (1.0 + 0.2 * rs.randn(cout)).astype(np.float32)
+    gb = (0.2 * rs.randn(cout)).astype(np.float32)
+    eps = 1e-5
+    conv_t, out_t, _, _ = _lib.conv2d_groupnorm(x, w, gw, gb, bias, res, 32, eps, silu, tile=tile, producer_stats=2)
+    conv_b, out_b, _, _ = _lib.conv2d_groupnorm(x, w, gw, gb, bias, res, 32, eps, silu, tile=0, producer_stats=0)
+    ref_conv = conv_ref(x, w, bias, res, False)
+    close(conv_t, ref_conv.numpy(), f"conv {case}")
+    # against the GroupNorm of OUR conv output (isolates the twin from the conv's rounding) and against the launch it replaces
+    z = F.group_norm(torch.from_numpy(conv_t.astype(np.float32)), 32, torch.from_numpy(gw), torch.from_numpy(gb), eps)
+    z = (F.silu(z) if silu else z).numpy()
+    close(out_t, z, f"GroupNorm twin {case}")
+    close(out_t, out_b.astype(np.float32), f"twin vs GroupNorm launch {case}", min_psnr=58.0, rel=1e-2)
+    zr = F.group_norm(ref_conv.half().float(), 32, torch.from_numpy(gw), torch.from_numpy(gb), eps)
+    zr = (F.silu(zr) if silu else zr).numpy()
+    close(out_t, zr, f"conv -> GroupNorm {case}", min_psnr=55.0, rel=1e-2)
+    _, again, _, _ = _lib.conv2d_groupnorm(x, w, gw, gb, bias, res, 32, eps, silu, tile=tile, producer_stats=2, iters=3)
+    assert np.array_equal(out_t, again)
+
+
+def test_groupnorm_twin_rejects_what_it_cannot_hold():
+    rs = np.random.RandomState(1)
+    x = h16(rs.randn(1, 64, 32, 32))
+    w = h16(rs.randn(64, 64, 3, 3) * 0.05)
+    g = np.ones(64, np.float32)
+    with pytest.raises(ValueError):   # 32x32 = 1024 pixels per (sample, group) slice: more than a workgroup keeps in registers
+        _lib.conv2d_groupnorm(x, w, g, g, groups=32, producer_stats=2)
