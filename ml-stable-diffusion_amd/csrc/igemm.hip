@@ -378,9 +378,16 @@ __device__ __forceinline__ void tile_epilogue(const IgemmArgs& a, floatx16 (&acc
 // The DMA writes lane-linear 1-KiB pieces (8 rows x 128 B), so the bank swizzle lives on the
 // per-lane SOURCE address: physical 16-B chunk p of row r holds logical chunk p ^ ((r >> 1) & 7),
 // and fragment reads apply the same XOR (conflict-free ds_read_b128, cdna guide rule 21).
-template <int BM, int BN, int WGM, int WGN, bool TRANS_OUT, bool GLDS, int NST, int DBG = 0, bool LNF = false>
-__global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
+// KG = 2 (round 5): IN-WORKGROUP split-K.  The small-M GEMMs of the 16x16 / 8x8 levels (1280 -> 1280 at M = 512: 160 tiles of
+// 64 x 64, 20 K steps each) expose their serial K loop - 0.45 us per barrier-separated step - on 160 of 256 CUs; a split-K over
+// workgroups costs a dependent reduce launch (measured: it loses).  Here a workgroup is TWO groups of four waves, each with its
+// own LDS ring, walking one half of the K range in lockstep (the s_barrier is workgroup-wide; the shorter half pads with one
+// barrier-only step); group 1 hands its accumulators over through LDS and retires (s_barrier only waits for surviving
+// waves), group 0 adds them and runs the epilogue.  Same loop body, half as many steps, no HBM slabs, no extra launch.
+template <int BM, int BN, int WGM, int WGN, bool TRANS_OUT, bool GLDS, int NST, int DBG = 0, bool LNF = false, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void igemm_kernel(IgemmArgs a) {
   static_assert(WGM * WGN == 4, "4 waves");
+  static_assert(KG == 1 || (KG == 2 && GLDS && NST >= 3 && !LNF && !TRANS_OUT && DBG == 0), "in-workgroup split-K: ring variants of the plain epilogue");
   static_assert(!(LNF && TRANS_OUT), "LayerNorm fold uses the in-lane row layout of the non-transposed tile");
   constexpr int TM = BM / WGM / 32;   // 32x32 MFMA tiles per wave along m
   constexpr int TN = BN / WGN / 32;
@@ -395,15 +402,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   long long prof_w0 = 0;
   if (prof) { prof_t[0] = clock64(); prof_w0 = wall_clock64(); }
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  half_t* Xs = reinterpret_cast<half_t*>(smem);                 // [NST][BM][ROW]
+  const int kg = KG > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;   // K group of this wave
+  half_t* Xs = reinterpret_cast<half_t*>(smem) + (size_t)kg * NST * (BM + BN) * ROW;   // [NST][BM][ROW] of this K group
   half_t* Ws = Xs + NST * BM * ROW;                             // [NST][BN][ROW]
   // behind the ring: per-column epilogue constants [BN] bias (+ timestep-embedding row when the tile lies in
   // one sample) | [BN] LayerNorm colsum.  Loaded once per workgroup next to the first tile's DMA, so the
   // epilogue reads them from LDS instead of issuing dependent global loads per accumulator fragment
   // (those cost the 128x128 tile ~9k cycles, profiles/r01_prof_conv_phases.log).
-  float* sconst = reinterpret_cast<float*>(smem + (size_t)NST * (BM + BN) * ROW * sizeof(half_t));
+  float* sconst = reinterpret_cast<float*>(smem + (size_t)KG * NST * (BM + BN) * ROW * sizeof(half_t));
 
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x & 255;   // thread inside its K group
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (LDS-DMA base -> M0)
   const int wm = wave / WGN, wn = wave % WGN;
@@ -423,9 +431,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   const int m_blk = bm_idx * BM, n_blk = bn_idx * BN;
 
   const int split = blockIdx.y;
-  const int kt_begin = split * a.nk_per_split;
+  int kt_begin = split * a.nk_per_split;
   int kt_end = kt_begin + a.nk_per_split;
   if (kt_end > a.nk_total) kt_end = a.nk_total;
+  int kg_steps = kt_end - kt_begin;   // barrier-separated steps every K group goes through (KG == 2: the longer half)
+  if constexpr (KG == 2) {
+    const int half0 = (kt_end - kt_begin + 1) >> 1;
+    kg_steps = half0;
+    if (kg == 0) kt_end = kt_begin + half0;
+    else kt_begin += half0;
+  }
 
   // ---- per-thread staging coordinates (loop invariant) ----
   const int pchunk = tid & 7;       // physical 16-B slot of the 128-B K row this thread fills
@@ -646,7 +661,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   constexpr int RIT = BM * BN / 8 / 256;
   constexpr bool RES_PRE = !TRANS_OUT && GLDS && RIT <= 4 && DBG == 0;
   half8 resv[RES_PRE ? RIT : 1];
-  const bool use_resv = RES_PRE && a.res_pre && a.res != nullptr && !a.slab && a.out_mode == kOutHalf && n_blk < a.n_trans;
+  const bool use_resv = RES_PRE && a.res_pre && a.res != nullptr && !a.slab && a.out_mode == kOutHalf && n_blk < a.n_trans && kg == 0;
   if constexpr (RES_PRE) {
     if (use_resv) {
 #pragma unroll
@@ -673,8 +688,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
 #pragma unroll
     for (int p = 0; p < NST - 1; ++p)
       if (kt_begin + p < kt_end) load_tile(p);
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      const int rel = kt - kt_begin;
+    for (int rel = 0; rel < kg_steps; ++rel) {
+      const int kt = kt_begin + rel;
+      if (KG == 2 && kt >= kt_end) {       // the shorter K half: keep the workgroup-wide barrier count (wave-uniform branch)
+        asm volatile("s_barrier" ::: "memory");
+        continue;
+      }
       const int ahead = kt_end - 1 - kt;   // tiles after this one that are already issued (capped below)
       // wait until at most min(ahead, DEPTH) newer tiles are outstanding == tile kt has landed (loads of one
       // wave return in order); the immediate must be a literal, hence the ladder
@@ -719,6 +738,34 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   }
 
   if (prof) prof_t[2] = clock64();
+  if constexpr (KG == 2) {
+    // K group 1 hands its accumulators to group 0 through LDS (its own ring: every read of it is behind the barrier) and retires
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    floatx4* hx = reinterpret_cast<floatx4*>(smem + (size_t)NST * (BM + BN) * ROW * sizeof(half_t));   // group 1's ring
+    static_assert((size_t)TM * TN * 4 * 256 * sizeof(floatx4) <= (size_t)NST * (BM + BN) * ROW * sizeof(half_t), "hand-over fits one ring");
+    if (kg == 1) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            hx[((i * TN + j) * 4 + q) * 256 + tid] = floatx4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+    }
+    __syncthreads();
+    if (kg == 1) return;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const floatx4 v = hx[((i * TN + j) * 4 + q) * 256 + tid];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += v[e];
+        }
+  }
   // ---------------------------------- epilogue ----------------------------------
   const int hi = lane >> 5;
   // LNF: y = rstd*(x.W') - rstd*mean*colsum + bias'  ->  out = acc*ln_a + ln_b*colsum[n] + bias[n]
@@ -1242,11 +1289,13 @@ __global__ __launch_bounds__(256, halo_lds_bytes(64, D) <= 80 * 1024 ? 2 : 1) vo
 // Accumulator layout, swizzle and epilogue are igemm_kernel's (tile_epilogue: bias / timestep embedding / LayerNorm fold /
 // GEGLU / residual / fused q|k|v / GroupNorm statistics / split-K slabs).
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WGM, int WGN, int D, bool LNF>
+// DBG (ablation builds, tools/r5_gemm_ablation.py; results are garbage): bit 0 = no weight DMA, bit 1 = no activation DMA
+template <int BM, int BN, int WGM, int WGN, int D, bool LNF, int DBG = 0>
 __global__ __launch_bounds__(256, D == 2 ? 2 : 1) void gemm_pipe_kernel(IgemmArgs a) {   // D = 2: 64 KB of LDS on the 128 x 128 tile, two workgroups per CU
   static_assert(WGM * WGN == 4, "4 waves");
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
-  constexpr int XR = BM / 32, WR = BN / 32, PER = XR + WR, ROWB = BK * 2, KK = BK / 16;
+  constexpr int XR = BM / 32, WR = BN / 32, PER = ((DBG & 2) ? 0 : XR) + ((DBG & 1) ? 0 : WR), ROWB = BK * 2, KK = BK / 16;
+  static_assert(DBG != 3, "one operand must still arrive");
   static_assert((D - 1) * PER <= 63, "vmcnt range");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const Xs = smem;                                   // [D][BM][BK] halves
@@ -1303,10 +1352,14 @@ __global__ __launch_bounds__(256, D == 2 ? 2 : 1) void gemm_pipe_kernel(IgemmArg
     const int xs_off = (second ? k - a.C0 : k) * 2;
     char* xs = Xs + iw_stage * (BM * ROWB) + wave * 1024;
     char* ws = Ws + iw_stage * (BN * ROWB) + wave * 1024;
+    if constexpr ((DBG & 2) == 0) {
 #pragma unroll
-    for (int i = 0; i < XR; ++i) dma16_to_lds(rs_x, xs + i * 4096, second ? xoff1[i] : xoff0[i], xs_off);
+      for (int i = 0; i < XR; ++i) dma16_to_lds(rs_x, xs + i * 4096, second ? xoff1[i] : xoff0[i], xs_off);
+    }
+    if constexpr ((DBG & 1) == 0) {
 #pragma unroll
-    for (int i = 0; i < WR; ++i) dma16_to_lds(rs_w, ws + i * 4096, woff[i], k * 2);
+      for (int i = 0; i < WR; ++i) dma16_to_lds(rs_w, ws + i * 4096, woff[i], k * 2);
+    }
     ++iw_kt;
     iw_stage = (iw_stage + 1 == D) ? 0 : iw_stage + 1;
   };
@@ -1490,6 +1543,59 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmArgs a) {
     }
     half4 o = {(half_t)s[0], (half_t)s[1], (half_t)s[2], (half_t)s[3]};
     *reinterpret_cast<half4*>(a.out + e0) = o;
+  }
+}
+
+// The same combine for a tensor whose consumer is a GroupNorm (8x8 / 16x16 levels: every conv there is split-K or the
+// weight-streaming kernel, so its GroupNorm statistics cannot come out of a tile epilogue): one workgroup per (PPB pixels of a
+// sample) x all channels, per-(pixel, 4-channel quad) sums of the fp16-rounded outputs through LDS, then one thread per group adds
+// its quads in a fixed order and writes entry blockIdx.x of gn_partial [B][G][kGnMaxSlabs][2] - the format the tile epilogues
+// write, so the GroupNorm runs its fully parallel apply pass instead of the 64-workgroup two-pass kernel.
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(IgemmArgs a, int ppb) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* qs = reinterpret_cast<float*>(smem);            // [ppb][N / 4] (sum, sumsq) pairs
+  const int NQ = a.N >> 2, t = threadIdx.x, b = blockIdx.y;
+  const int p0 = blockIdx.x * ppb;
+  const int items = ppb * NQ;
+  for (int id = t; id < items; id += 256) {
+    const int pl = id / NQ, qd = id - pl * NQ;
+    const int p = p0 + pl;
+    float fs = 0.f, fq = 0.f;
+    if (p < a.HoWo) {
+      const int m = b * a.HoWo + p, n = 4 * qd;
+      const size_t e0 = (size_t)m * a.N + n;
+      floatx4 s = {0.f, 0.f, 0.f, 0.f};
+      for (int z = 0; z < a.splitk; ++z) s += *reinterpret_cast<const floatx4*>(a.partial + (size_t)z * a.M * a.N + e0);
+      if (a.bias) s += *reinterpret_cast<const floatx4*>(a.bias + n);
+      if (a.temb) s += *reinterpret_cast<const floatx4*>(a.temb + (size_t)b * a.temb_stride + n);
+      if (a.res) {
+        const half4 rr = *reinterpret_cast<const half4*>(a.res + e0);
+        s[0] += (float)rr[0];
+        s[1] += (float)rr[1];
+        s[2] += (float)rr[2];
+        s[3] += (float)rr[3];
+      }
+      const half4 o = {(half_t)s[0], (half_t)s[1], (half_t)s[2], (half_t)s[3]};
+      *reinterpret_cast<half4*>(a.out + e0) = o;
+      const float f0 = (float)o[0], f1 = (float)o[1], f2 = (float)o[2], f3 = (float)o[3];
+      fs = (f0 + f1) + (f2 + f3);
+      fq = fmaf(f0, f0, fmaf(f1, f1, fmaf(f2, f2, f3 * f3)));
+    }
+    qs[2 * id] = fs;
+    qs[2 * id + 1] = fq;
+  }
+  __syncthreads();
+  if (t < a.gn_G) {
+    const int q0 = t * (a.gn_cpg >> 2), q1 = q0 + (a.gn_cpg >> 2);
+    float s = 0.f, q = 0.f;
+    for (int pl = 0; pl < ppb; ++pl)
+      for (int qd = q0; qd < q1; ++qd) {
+        s += qs[2 * (pl * NQ + qd)];
+        q += qs[2 * (pl * NQ + qd) + 1];
+      }
+    float* dst = a.gn_partial + (((size_t)b * a.gn_G + t) * kGnMaxSlabs + blockIdx.x) * 2;
+    dst[0] = s;
+    dst[1] = q;
   }
 }
 
@@ -1991,18 +2097,19 @@ void launch_halo_ks(IgemmArgs a, int splitk, int staging, hipStream_t s) {
   launch_halo_ks_d<2>(a, s);
 }
 
-template <int BM, int BN, int WGM, int WGN, bool TRANS, bool GLDS, int NST, bool LNF = false>
+template <int BM, int BN, int WGM, int WGN, bool TRANS, bool GLDS, int NST, bool LNF = false, int KG = 1>
 void launch_variant(const IgemmArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)NST * (BM + BN) * (GLDS ? BK : LDS_ROW) * sizeof(half_t) + 2 * BN * sizeof(float);
+  const size_t lds = (size_t)KG * NST * (BM + BN) * (GLDS ? BK : LDS_ROW) * sizeof(half_t) + 2 * BN * sizeof(float);
+  static_assert((size_t)KG * NST * (BM + BN) * BK * sizeof(half_t) + 2 * BN * sizeof(float) <= 160 * 1024, "LDS");
   static_assert((size_t)BN * (BM + 8) <= (size_t)NST * (BM + BN) * (GLDS ? BK : LDS_ROW), "transposed staging fits");
   static_assert((size_t)BM * (BN + 8) * 2 + 16 + (kGnScratchFloats + 2 * BN) * sizeof(float) <=
                     (size_t)NST * (BM + BN) * (GLDS ? BK : LDS_ROW) * sizeof(half_t),
                 "GroupNorm statistics scratch fits behind the staged tile");
   dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), a.splitk);
-  auto k = igemm_kernel<BM, BN, WGM, WGN, TRANS, GLDS, NST, 0, LNF>;
+  auto k = igemm_kernel<BM, BN, WGM, WGN, TRANS, GLDS, NST, 0, LNF, KG>;
   static DynLdsOnce once;   // per instantiation, per device
   once.set(k, lds);
-  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL(k, grid, dim3(256 * KG), lds, s, a);
 }
 
 template <int BM, int BN, int DBG>
@@ -2030,11 +2137,30 @@ bool launch_debug_mode(const IgemmArgs& a, int dbg, hipStream_t s) {
 // 3 / 4 / 6 / 8 stages (a ring that would not fit the 160 KB of LDS falls back to the deepest one that does),
 constexpr size_t kLdsBudget = 160 * 1024;
 template <int BM, int BN>
+constexpr size_t ring_bytes(int nst) {
+  return (size_t)nst * (BM + BN) * BK * sizeof(half_t);
+}
+template <int BM, int BN>
 constexpr bool ring_fits(int nst) {
   return (size_t)nst * (BM + BN) * BK * sizeof(half_t) + 2 * BN * sizeof(float) <= kLdsBudget;
 }
 // staging 6 / 7 / 8: the software-pipelined 1x1 GEMM kernel with a ring of 3 / 4 / 2 stages (1x1, stride 1, non-transposed
 // output; 32-bit buffer offsets); anything else that asks for them runs the 4-stage ring of igemm_kernel
+template <int BM, int BN, int WGM, int WGN, int D, bool LNF>
+void launch_pipe_dbg(const IgemmArgs& a, hipStream_t s) {   // ablation builds (a.debug = 64 + bits)
+  constexpr size_t lds = (size_t)D * (BM + BN) * BK * sizeof(half_t) + 2 * BN * sizeof(float);
+  dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), a.splitk);
+  if (a.debug == 65) {
+    auto k = gemm_pipe_kernel<BM, BN, WGM, WGN, D, LNF, 1>;
+    SD_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+  } else {
+    auto k = gemm_pipe_kernel<BM, BN, WGM, WGN, D, LNF, 2>;
+    SD_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+  }
+}
+
 template <int BM, int BN, int WGM, int WGN, int D, bool LNF>
 void launch_pipe(const IgemmArgs& a, hipStream_t s) {
   constexpr size_t lds = (size_t)D * (BM + BN) * BK * sizeof(half_t) + 2 * BN * sizeof(float);
@@ -2043,6 +2169,12 @@ void launch_pipe(const IgemmArgs& a, hipStream_t s) {
                 "staged tile + GroupNorm statistics scratch fit the K-loop buffers");
   static_assert((size_t)BN * (BM + 8) <= (size_t)D * (BM + BN) * BK, "transposed staging fits");
   dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), a.splitk);
+  if constexpr (D == 2 && !LNF) {   // the ablation builds exist for the 2-stage ring of the plain epilogue only
+    if (a.debug == 65 || a.debug == 66) {
+      launch_pipe_dbg<BM, BN, WGM, WGN, D, LNF>(a, s);
+      return;
+    }
+  }
   auto k = gemm_pipe_kernel<BM, BN, WGM, WGN, D, LNF>;
   static DynLdsOnce once;
   once.set(k, lds);
@@ -2050,6 +2182,19 @@ void launch_pipe(const IgemmArgs& a, hipStream_t s) {
 }
 template <int BM, int BN, int WGM, int WGN, bool LNF>
 void launch_ring(const IgemmArgs& a, int staging, hipStream_t s) {
+  // staging 12 / 13: igemm_kernel's 3- / 4-stage ring with the in-workgroup split-K (two K groups of four waves, KG = 2) where two
+  // rings fit the LDS and the epilogue is the plain one; anything else that names them gets the same ring without it
+  if (staging == 12 || staging == 13) {
+    if constexpr (!LNF) {
+      if (a.nk_per_split >= 4) {
+        if (staging == 13) {
+          if constexpr (2 * ring_bytes<BM, BN>(4) + 2 * BN * sizeof(float) <= kLdsBudget) { launch_variant<BM, BN, WGM, WGN, false, true, 4, false, 2>(a, s); return; }
+        }
+        if constexpr (2 * ring_bytes<BM, BN>(3) + 2 * BN * sizeof(float) <= kLdsBudget) { launch_variant<BM, BN, WGM, WGN, false, true, 3, false, 2>(a, s); return; }
+      }
+    }
+    staging -= 10;
+  }
   if (staging == 8 && gemm_pipe_ok(a)) {   // 2-stage ring, two workgroups per CU (three on 128 x 64): profiles/r03_exp_pipe_d2.txt
     launch_pipe<BM, BN, WGM, WGN, 2, LNF>(a, s);
     return;
@@ -2171,6 +2316,33 @@ int setup_gn_stats(const ConvDesc& d, IgemmArgs& a, int bm) {
 }
 }  // namespace
 
+namespace {
+// slab combine of a split-K / weight-streaming launch: plain, or - when the consumer is a GroupNorm over <= 256 pixels per sample -
+// with the GroupNorm statistics of the result (returns the entries per (sample, group) it wrote, else 0)
+int launch_slab_combine(const ConvDesc& d, IgemmArgs& a, hipStream_t s) {
+  static const int stats_mode = tune_env_int("SD_REDUCE_STATS", 0);   // measured: the step loses 0.25 ms with it (LAB_NOTES.md r5) - off unless asked for
+  a.gn_partial = nullptr;
+  if (stats_mode != 0 && d.gn_partial && d.gn_groups >= 1 && d.gn_groups <= 256 && a.N % d.gn_groups == 0 && (a.N / d.gn_groups) % 4 == 0 &&
+      a.HoWo <= 256 && d.out_mode == kOutHalf && !d.out_t) {
+    int ppb = std::max(1, a.B * a.HoWo / 512);
+    const int slabs = cdiv(a.HoWo, ppb);
+    const size_t lds = (size_t)ppb * (a.N / 4) * 2 * sizeof(float);
+    if (slabs <= kGnMaxSlabs && lds <= 64 * 1024) {
+      a.gn_partial = d.gn_partial;
+      a.gn_G = d.gn_groups;
+      a.gn_cpg = a.N / d.gn_groups;
+      a.gn_T = slabs;
+      hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3(slabs, a.B), dim3(256), lds, s, a, ppb);
+      return slabs;
+    }
+  }
+  const size_t total4 = (size_t)a.M * a.N / 4;
+  const int blocks = (int)std::min<size_t>((total4 + 255) / 256, 2048);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a);
+  return 0;
+}
+}  // namespace
+
 int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
   SD_REQUIRE(conv_fast_path_ok(d), kInvalidArgument, "launch_conv: shape not MFMA-tileable (C0=%d C1=%d N=%d k=%d)",
              d.C0, d.C1, d.N, d.ksize);
@@ -2200,15 +2372,11 @@ int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
     a.partial = ws.partial;
     a.splitk = S;
     a.slab = 1;
-    if (twins) {
-      launch_reduce_twin(a.partial, S, a.M, a.N, a.HoWo, a.bias, a.temb, a.temb_stride, a.res, a.out, d.n_twins, d.twin, s);
-    } else {
-      size_t total4 = (size_t)a.M * a.N / 4;
-      int blocks = (int)std::min<size_t>((total4 + 255) / 256, 2048);
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a);
-    }
+    int entries = 0;
+    if (twins) launch_reduce_twin(a.partial, S, a.M, a.N, a.HoWo, a.bias, a.temb, a.temb_stride, a.res, a.out, d.n_twins, d.twin, s);
+    else entries = launch_slab_combine(d, a, s);
     SD_HIP(hipGetLastError());
-    return 0;
+    return entries;
   }
   if (halo) {
     const int nch = a.Ctot / BK;
@@ -2254,7 +2422,7 @@ int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
   if (halo) {
     gn_entries = setup_gn_stats(d, a, 0);
     launch_halo_ks(a, a.splitk, st, s);
-  } else if (d.debug) {   // ablation builds exist for two tiles only (tools/prof_conv.py)
+  } else if (d.debug && d.debug < 64) {   // ablation builds exist for two tiles only (tools/prof_conv.py)
     const bool ok = p.tile == 1 ? launch_debug_mode<128, 128>(a, d.debug, s) : launch_debug_mode<64, 64>(a, d.debug, s);
     SD_REQUIRE(ok && !trans, kInvalidArgument, "no ablation kernel for debug mode %d", d.debug);
     return 0;
@@ -2274,9 +2442,7 @@ int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
   if (twins) {
     launch_reduce_twin(a.partial, a.splitk, a.M, a.N, a.HoWo, a.bias, a.temb, a.temb_stride, a.res, a.out, d.n_twins, d.twin, s);
   } else if (a.slab) {
-    size_t total4 = (size_t)a.M * a.N / 4;
-    int blocks = (int)std::min<size_t>((total4 + 255) / 256, 2048);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a);
+    gn_entries = launch_slab_combine(d, a, s);
   }
   SD_HIP(hipGetLastError());
   return gn_entries;

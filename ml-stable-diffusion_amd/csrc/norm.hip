@@ -467,8 +467,11 @@ bool groupnorm_wants_producer_stats(int HW, int C, int G) {
   static const bool off = tune_env_set("SD_NO_GN_PRODUCER_STATS");   // A/B switch
   if (off || G < 1 || C % G != 0) return false;
   const int cpg = C / G;
+  // (round 5: also where the GroupNorm itself would be ONE launch, HW <= 256: its 64-workgroup two-pass kernel takes 7-13 us in
+  // sequence, the fully parallel apply pass behind producer statistics ~5; SD_GN_STATS_SMALL=0 restores round 4's rule)
+  static const bool small_too = tune_env_int("SD_GN_STATS_SMALL", 0) != 0;   // measured: no gain (LAB_NOTES.md r5)
   const bool single_launch = HW <= gn_fused_max_hw() && cpg <= 128 && cpg % 2 == 0;
-  return !single_launch && cpg <= 64 && G <= 64;
+  return (!single_launch || small_too) && cpg <= 64 && G <= 64;
 }
 
 size_t groupnorm_scratch_floats(int B, int HW, int G) { return (size_t)B * G * kGnMaxSlabs * 2; }

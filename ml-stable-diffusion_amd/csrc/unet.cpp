@@ -391,7 +391,7 @@ Tensor UNet::group_norm(std::vector<Op>& ops, const std::string& name, const Ten
   // group boundaries fall on the source boundaries -> the producers write this GroupNorm themselves (GnHook twins), no launch.
   // SD_GN_TWIN=0 (with SD_TUNE) keeps the launch: A/B.
   {
-    static const int twin_mode = tune_env_int("SD_GN_TWIN", 1);
+    static const int twin_mode = tune_env_int("SD_GN_TWIN", 0);   // measured and rejected: off unless asked for
     const int cpg = C / G;
     const Tensor* srcs[2] = {&x, x2};
     bool ok = twin_mode != 0 && x.H * x.W <= 256 && cpg % 4 == 0 && (!x2 || x.C % cpg == 0);

@@ -130,3 +130,65 @@ def test_groupnorm_twin_rejects_what_it_cannot_hold():
     g = np.ones(64, np.float32)
     with pytest.raises(ValueError):   # 32x32 = 1024 pixels per (sample, group) slice: more than a workgroup keeps in registers
         _lib.conv2d_groupnorm(x, w, g, g, groups=32, producer_stats=2)
+
+
+STATS_CASES = [  # (B, Cin, HW, Cout, k, tile, entries expected)
+    (2, 256, 8, 1280, 3, 9, 64),     # weight-streaming conv: one entry per pixel at 8x8
+    (2, 64, 16, 640, 3, 9, 256),     # 16x16: 256 entries, the fold's limit
+    (1, 64, 8, 1280, 1, 9, 64),      # 1x1 through the streaming kernel
+    (4, 64, 16, 640, 3, 9, 128),     # batch 4: two pixels per workgroup
+]
+
+
+@pytest.mark.parametrize("case", STATS_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_groupnorm_statistics_from_the_slab_combine(case):
+    """Split-K / weight-streaming producers (every conv of the 8x8 / 16x16 levels): the GroupNorm statistics come out of the slab
+    combine (splitk_reduce_stats_kernel) and the GroupNorm runs its parallel apply pass (unet.py:470-489)."""
+    b, cin, hw, cout, k, tile, want = case
+    rs = np.random.RandomState(cin + cout + hw + b)
+    x = h16(rs.randn(b, cin, hw, hw))
+    w = h16(rs.randn(cout, cin, k, k) / np.sqrt(cin * k * k))
+    bias = (0.1 * rs.randn(cout)).astype(np.float32) + 0.2
+    res = h16(rs.randn(b, cout, hw, hw) * 0.5)
+    gw = (1.0 + 0.2 * rs.randn(cout)).astype(np.float32)
+    gb = (0.2 * rs.randn(cout)).astype(np.float32)
+    conv_a, out_a, entries, _ = _lib.conv2d_groupnorm(x, w, gw, gb, bias, res, 32, 1e-5, True, tile=tile, producer_stats=1)
+    conv_b, out_b, none, _ = _lib.conv2d_groupnorm(x, w, gw, gb, bias, res, 32, 1e-5, True, tile=tile, producer_stats=0)
+    assert entries == want and none == 0, (entries, none)
+    assert np.array_equal(conv_a, conv_b), "the statistics pass must not change the conv output"
+    z = F.silu(F.group_norm(torch.from_numpy(conv_a.astype(np.float32)), 32, torch.from_numpy(gw), torch.from_numpy(gb), 1e-5)).numpy()
+    close(out_a, z, f"GroupNorm from the slab combine's statistics {case}")
+    close(out_b, z, f"GroupNorm with its own statistics {case}")
+    _, again, _, _ = _lib.conv2d_groupnorm(x, w, gw, gb, bias, res, 32, 1e-5, True, tile=tile, producer_stats=1, iters=3)
+    assert np.array_equal(out_a, again)
+
+
+KG2_CASES = [  # (B, Cin, H, Cout, k, stride)
+    (2, 1280, 16, 1280, 1, 1),    # to_out / proj_in / proj_out of the 16x16 level: 20 K steps -> 10 + 10
+    (2, 1344, 16, 192, 1, 1),     # 21 steps: 11 + 10 (the shorter half pads with a barrier-only step)
+    (2, 320, 32, 320, 1, 1),      # 5 steps: 3 + 2
+    (1, 256, 8, 64, 1, 1),        # 4 steps, M = 64
+    (2, 128, 32, 128, 3, 2),      # Downsample2D through the im2col kernel, 18 steps
+    (2, 64, 8, 64, 1, 1),         # 1 step: below the threshold, the plain ring runs
+]
+
+
+@pytest.mark.parametrize("case", KG2_CASES, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("tile", [123, 133, 122, 124], ids=["64x64ring3", "64x64ring4", "128x64ring3", "64x128ring3"])
+@pytest.mark.parametrize("splitk", [1, 2])
+def test_in_workgroup_split_k_matches_torch(case, tile, splitk):
+    """igemm_kernel KG = 2: two K groups of four waves per workgroup, accumulators handed over through LDS (unet.py:62-118 1x1
+    projections, :503-510 stride-2 conv)."""
+    b, cin, h, cout, k, stride = case
+    rs = np.random.RandomState(cin + cout + h + tile)
+    x = h16(rs.randn(b, cin, h, h))
+    w = h16(rs.randn(cout, cin, k, k) / np.sqrt(cin * k * k))
+    bias = (0.1 * rs.randn(cout)).astype(np.float32)
+    ho = (h + 2 * (k // 2) - k) // stride + 1
+    res = h16(rs.randn(b, cout, ho, ho))
+    y = F.conv2d(torch.from_numpy(x.astype(np.float32)), torch.from_numpy(w.astype(np.float32)), torch.from_numpy(bias), stride=stride,
+                 padding=k // 2) + torch.from_numpy(res.astype(np.float32))
+    out, _ = _lib.conv2d(x, w, bias, res, stride=stride, tile=tile, splitk=splitk)
+    close(out, y.numpy(), f"KG2 conv {case} tile {tile} splitk {splitk}")
+    again, _ = _lib.conv2d(x, w, bias, res, stride=stride, tile=tile, splitk=splitk, iters=3)
+    assert np.array_equal(out, again)
