@@ -267,6 +267,16 @@ int sd_op_conv2d(const void* x, const void* w, const float* bias, const void* re
 int sd_op_conv2d_groupnorm(const void* x, const void* w, const float* bias, const void* res, const float* gn_weight,
                            const float* gn_bias, void* conv_out, void* out, int B, int Cin, int H, int W, int Cout, int ksize,
                            int groups, float eps, int silu, int tile, int producer_stats, int* entries, int iters, float* ms);
+/* conv -> torch.nn.GroupNorm (no SiLU) -> 1x1 projection: a resnet's last conv followed by SpatialTransformer.norm + proj_in
+ * (unet.py:528-531 eps 1e-6, :553-556).  fold = 1: the GroupNorm is applied inside the projection GEMM (statistics from the
+ * conv's epilogue, per-channel mean / scale / shift applied to the GEMM's activation fragments: no GroupNorm launch);
+ * fold = 0: GroupNorm launch + plain GEMM.  *entries (may be NULL) returns the number of statistics entries the fold consumed
+ * (0: it fell back to the GroupNorm launch because the conv's plan wrote none).  proj_w (Nproj, Cout) f16, proj_bias (Nproj)
+ * f32 or NULL; conv_out (may be NULL) (B, Cout, H, W), out (B, Nproj, H, W) f16 NCHW. */
+int sd_op_conv2d_groupnorm_proj(const void* x, const void* w, const float* bias, const void* res, const float* gn_weight,
+                                const float* gn_bias, const void* proj_w, const float* proj_bias, void* conv_out, void* out, int B,
+                                int Cin, int H, int W, int Cout, int ksize, int Nproj, int groups, float eps, int fold, int tile,
+                                int* entries, int iters, float* ms);
 /* Cross-attention front half as one launch (unet.py:87-118 inside :586-591): out = softmax(to_q(LayerNormANE(x)) k^T / 8) v
  * per head, head dim 64, Sk <= 96 (the prompt), any Sq >= 1 (ragged last token tile).  V^T columns [Sk, round_up(Sk, 8)) must be
  * zero (this entry point zero-fills them; the masked probabilities there are 0 but 0 * inf would be NaN).  x (B, heads*64, 1, Sq), k / v (B, heads*64, 1, Sk) f16 BC1S,

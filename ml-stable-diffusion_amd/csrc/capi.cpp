@@ -531,6 +531,93 @@ int sd_op_conv2d_groupnorm(const void* x, const void* w, const float* bias, cons
   });
 }
 
+int sd_op_conv2d_groupnorm_proj(const void* x, const void* w, const float* bias, const void* res, const float* gn_weight,
+                                const float* gn_bias, const void* proj_w, const float* proj_bias, void* conv_out, void* out, int B,
+                                int Cin, int H, int W, int Cout, int ksize, int Nproj, int groups, float eps, int fold, int tile,
+                                int* entries, int iters, float* ms) {
+  return guarded([&] {
+    SD_REQUIRE(x && w && gn_weight && gn_bias && proj_w && out, kInvalidArgument, "NULL argument");
+    SD_REQUIRE(ksize == 1 || ksize == 3, kInvalidArgument, "conv2d_groupnorm_proj: ksize %d", ksize);
+    Scratch sc;
+    std::vector<half_t> xt = nchw_to_nhwc(reinterpret_cast<const half_t*>(x), B, Cin, H, W);
+    const half_t* wh = reinterpret_cast<const half_t*>(w);
+    const int kk = ksize * ksize;
+    std::vector<half_t> wt((size_t)Cout * Cin * kk);
+    for (int o = 0; o < Cout; ++o)
+      for (int c = 0; c < Cin; ++c)
+        for (int t = 0; t < kk; ++t) wt[((size_t)o * kk + t) * Cin + c] = wh[((size_t)o * Cin + c) * kk + t];
+    ConvDesc d;
+    d.x0 = sc.dev<half_t>(xt.size(), xt.data());
+    d.C0 = Cin;
+    d.w = sc.dev<half_t>(wt.size(), wt.data());
+    d.bias = bias ? sc.dev<float>(Cout, bias) : nullptr;
+    std::vector<half_t> rt;
+    if (res) {
+      rt = nchw_to_nhwc(reinterpret_cast<const half_t*>(res), B, Cout, H, W);
+      d.res = sc.dev<half_t>(rt.size(), rt.data());
+    }
+    const size_t on = (size_t)B * H * W * Cout, pn = (size_t)B * H * W * Nproj;
+    half_t* dconv = sc.dev<half_t>(on);
+    half_t* dnorm = sc.dev<half_t>(on);
+    half_t* dy = sc.dev<half_t>(pn);
+    d.out = dconv;
+    d.B = B; d.Hi = H; d.Wi = W; d.Ho = H; d.Wo = W;
+    d.ksize = ksize; d.stride = 1; d.up = 1; d.N = Cout;
+    d.tile = tile % 10;
+    d.staging = tile / 10;
+    d.splitk = 1;
+    SD_REQUIRE(conv_fast_path_ok(d), kInvalidArgument, "conv2d_groupnorm_proj: the producer must run on the MFMA path");
+    const size_t pf = groupnorm_scratch_floats(B, H * W, groups);
+    float* partial = sc.dev<float>(pf);
+    {   // poison: the fold must only read what the producer wrote
+      std::vector<float> poison(pf, 1.0e30f);
+      SD_HIP(hipMemcpy(partial, poison.data(), pf * sizeof(float), hipMemcpyHostToDevice));
+    }
+    d.gn_partial = partial;
+    d.gn_groups = groups;
+    float* dgw = sc.dev<float>(Cout, gn_weight);
+    float* dgb = sc.dev<float>(Cout, gn_bias);
+    ConvDesc pd;   // the 1x1 projection over the conv's output
+    pd.C0 = Cout;
+    pd.w = sc.dev<half_t>((size_t)Nproj * Cout, reinterpret_cast<const half_t*>(proj_w));
+    pd.bias = proj_bias ? sc.dev<float>(Nproj, proj_bias) : nullptr;
+    pd.out = dy;
+    pd.B = B; pd.Hi = H; pd.Wi = W; pd.Ho = H; pd.Wo = W;
+    pd.N = Nproj;
+    SD_REQUIRE(conv_fast_path_ok(pd), kInvalidArgument, "conv2d_groupnorm_proj: the projection must run on the MFMA path");
+    ConvWorkspace ws;
+    ws.partial_bytes = std::max(conv_workspace_bytes(d), conv_workspace_bytes(pd));
+    if (ws.partial_bytes) ws.partial = reinterpret_cast<float*>(sc.dev<char>(ws.partial_bytes));
+    int n_entries = 0;
+    sc.timed(iters, ms, [&] {
+      n_entries = launch_conv(d, ws, sc.stream);
+      ConvDesc pp = pd;
+      if (fold && n_entries >= 1 && n_entries <= 128) {
+        pp.x0 = dconv;
+        pp.gnf_partial = partial;
+        pp.gnf_gamma = dgw;
+        pp.gnf_beta = dgb;
+        pp.gnf_eps = eps;
+        pp.gnf_groups = groups;
+        pp.gnf_entries = n_entries;
+      } else {
+        launch_groupnorm(dconv, Cout, nullptr, 0, partial, dgw, dgb, dnorm, B, H * W, groups, eps, 0, sc.stream, n_entries);
+        pp.x0 = dnorm;
+      }
+      launch_conv(pp, ws, sc.stream);
+    });
+    if (entries) *entries = (fold && n_entries >= 1 && n_entries <= 128) ? n_entries : 0;
+    if (conv_out) {
+      std::vector<half_t> ot(on);
+      SD_HIP(hipMemcpy(ot.data(), dconv, on * 2, hipMemcpyDeviceToHost));
+      nhwc_to_nchw(ot.data(), reinterpret_cast<half_t*>(conv_out), B, Cout, H, W);
+    }
+    std::vector<half_t> ot(pn);
+    SD_HIP(hipMemcpy(ot.data(), dy, pn * 2, hipMemcpyDeviceToHost));
+    nhwc_to_nchw(ot.data(), reinterpret_cast<half_t*>(out), B, Nproj, H, W);
+  });
+}
+
 int sd_op_cross_attention_fused(const void* x, const float* ln_weight, const float* ln_bias, const void* wq, const void* k,
                                 const void* v, void* out, int B, int heads, int Sq, int Sk, float eps, int nst, int iters,
                                 float* ms) {

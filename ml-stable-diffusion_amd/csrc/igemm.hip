@@ -72,6 +72,12 @@ struct IgemmArgs {
   // (round 2 measured 27 MB of fabric reads for a 320->320 GEMM at M = 8192 with 10.6 MB of operands: every n-tile of a row
   // block ran on a different XCD).  Chosen per launch from the operand sizes (launch_conv).
   int n_fast;
+  // GroupNorm folded into a 1x1 GEMM (gemm_pipe_kernel GNF): partial (sum, sumsq) entries of the input's producer, affine, eps
+  const float* gnf_partial;
+  const float* gnf_gamma;
+  const float* gnf_beta;
+  float gnf_eps;
+  int gnf_G, gnf_entries;
 };
 
 constexpr int kGnScratchFloats = 256 * 17;   // per-thread (sum[8], sumsq[8]) of the epilogue's store loop, +1 pad
@@ -1290,8 +1296,15 @@ __global__ __launch_bounds__(256, halo_lds_bytes(64, D) <= 80 * 1024 ? 2 : 1) vo
 // GEGLU / residual / fused q|k|v / GroupNorm statistics / split-K slabs).
 // ---------------------------------------------------------------------------------------------
 // DBG (ablation builds, tools/r5_gemm_ablation.py; results are garbage): bit 0 = no weight DMA, bit 1 = no activation DMA
-template <int BM, int BN, int WGM, int WGN, int D, bool LNF, int DBG = 0>
-__global__ __launch_bounds__(256, D == 2 ? 2 : 1) void gemm_pipe_kernel(IgemmArgs a) {   // D = 2: 64 KB of LDS on the 128 x 128 tile, two workgroups per CU
+// GNF (round 5): GroupNorm of the input folded in (SpatialTransformer.norm -> proj_in, unet.py:528-531 + :553-556: eps 1e-6, no
+// SiLU).  The producer of x left (sum, sumsq) partials per (sample, group); every workgroup folds the ones of its sample (its M
+// tile lies inside one sample) into a per-channel scale / shift table in LDS - requested as the oldest VMEM ops of the wave, in
+// flight beside the first tiles' DMA - and each wave applies it to its activation fragments with v_pk_fma_f16 between the LDS
+// read and the MFMA: what the GroupNorm kernel would have stored as fp16 is formed in registers instead, the launch and the
+// activation round trip are gone.
+template <int BM, int BN, int WGM, int WGN, int D, bool LNF, int DBG = 0, bool GNF = false>
+__global__ __launch_bounds__(256, D == 2 ? 2 : 1) void gemm_pipe_kernel(IgemmArgs a) {
+  static_assert(!(GNF && LNF), "one fold at a time");   // D = 2: 64 KB of LDS on the 128 x 128 tile, two workgroups per CU
   static_assert(WGM * WGN == 4, "4 waves");
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
   constexpr int XR = BM / 32, WR = BN / 32, PER = ((DBG & 2) ? 0 : XR) + ((DBG & 1) ? 0 : WR), ROWB = BK * 2, KK = BK / 16;
@@ -1301,6 +1314,9 @@ __global__ __launch_bounds__(256, D == 2 ? 2 : 1) void gemm_pipe_kernel(IgemmArg
   char* const Xs = smem;                                   // [D][BM][BK] halves
   char* const Ws = smem + D * BM * ROWB;                   // [D][BN][BK]
   float* sconst = reinterpret_cast<float*>(smem + (size_t)D * (BM + BN) * ROWB);
+  // GNF: [64] mean | [64] rstd floats, then [K] mean | [K] scale | [K] shift halves, behind the epilogue constants
+  float* gn_stat = sconst + 2 * BN;
+  half_t* gn_tab = reinterpret_cast<half_t*>(gn_stat + 128);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1411,7 +1427,9 @@ __global__ __launch_bounds__(256, D == 2 ? 2 : 1) void gemm_pipe_kernel(IgemmArg
   struct Frags {
     half8 x[KK][TM];
     half8 w[KK][TN];
+    half8 gm[GNF ? KK : 1], gs[GNF ? KK : 1], gh[GNF ? KK : 1];   // GNF: mean / scale / shift of this lane's 8 channels of every k sub-step
   };
+  int rd_kt = kt_begin;                         // K step whose fragments the next read_step fetches (GNF table offset)
   auto read_step = [&](Frags& f, int stage) {
     const char* xs = Xs + stage * (BM * ROWB) + xrow;
     const char* ws = Ws + stage * (BN * ROWB) + wrow;
@@ -1421,15 +1439,27 @@ __global__ __launch_bounds__(256, D == 2 ? 2 : 1) void gemm_pipe_kernel(IgemmArg
       for (int i = 0; i < TM; ++i) f.x[kk][i] = *reinterpret_cast<const half8*>(xs + i * 32 * ROWB + foff[kk]);
 #pragma unroll
       for (int j = 0; j < TN; ++j) f.w[kk][j] = *reinterpret_cast<const half8*>(ws + j * 32 * ROWB + foff[kk]);
+      if constexpr (GNF) {
+        const int k0 = rd_kt * BK + (kk * 2 + hi) * 8;
+        f.gm[kk] = *reinterpret_cast<const half8*>(gn_tab + k0);
+        f.gs[kk] = *reinterpret_cast<const half8*>(gn_tab + a.K + k0);
+        f.gh[kk] = *reinterpret_cast<const half8*>(gn_tab + 2 * a.K + k0);
+      }
     }
+    ++rd_kt;
   };
   auto mfma_step = [&](const Frags& f) {
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i) {
+        half8 xv = f.x[kk][i];
+        // (x - fp16(mean)) * (rstd * gamma) + (beta - (mean - fp16(mean)) * rstd * gamma): the subtraction comes first so that every
+        // rounding is relative to |x - mean|, not to |mean| (a group far from zero would otherwise lose digits in the shift)
+        if constexpr (GNF) xv = __builtin_elementwise_fma(xv - f.gm[kk], f.gs[kk], f.gh[kk]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.w[kk][j], f.x[kk][i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.w[kk][j], xv, acc[i][j], 0, 0, 0);
+      }
       if constexpr (LNF) {   // row statistics of the A tile for the LayerNorm fold: VALU work in the MFMAs' issue shadow
         const half2v one2 = {(half_t)1.f, (half_t)1.f};
 #pragma unroll
@@ -1444,13 +1474,74 @@ __global__ __launch_bounds__(256, D == 2 ? 2 : 1) void gemm_pipe_kernel(IgemmArg
     }
   };
 
+  // GNF prologue, part 1 (before the first DMA: oldest VMEM ops of the wave): this sample's partial statistics - eight lanes
+  // per group, 16 entries (8 float4) each, entries <= 128 - and gamma / beta of the channels whose table rows this thread writes
+  floatx4 gnf_v[GNF ? 8 : 1];
+  float gnf_g[GNF ? 8 : 1], gnf_b[GNF ? 8 : 1];
+  if constexpr (GNF) {
+    const int b = m_blk / a.HoWo;
+    const int g = tid >> 3, j = tid & 7;
+    const floatx4* src = reinterpret_cast<const floatx4*>(a.gnf_partial + (((size_t)b * a.gnf_G + (g < a.gnf_G ? g : 0)) * kGnMaxSlabs + j * 16) * 2);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int e0 = j * 16 + 2 * k;
+      floatx4 v = {0.f, 0.f, 0.f, 0.f};
+      if (e0 < a.gnf_entries) v = src[k];
+      if (e0 + 1 >= a.gnf_entries) {
+        v[2] = 0.f;
+        v[3] = 0.f;
+      }
+      gnf_v[k] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = tid + 256 * i;
+      gnf_g[i] = k < a.K ? a.gnf_gamma[k] : 0.f;
+      gnf_b[i] = k < a.K ? a.gnf_beta[k] : 0.f;
+    }
+  }
   Frags fA, fB;
 #pragma unroll
   for (int p = 0; p < D; ++p) {
     asm volatile("" ::: "memory");                          // keep the DMA issue order: the counted waits rely on it
     issue_tile();
   }
-  wait_vmcnt_barrier<(D - 1) * PER>();                      // tile 0 has landed for every wave
+  if constexpr (GNF) {
+    // part 2: fold (fixed order), statistics -> LDS, per-channel scale / shift table -> LDS; the barrier below publishes it
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      s += gnf_v[k][0] + gnf_v[k][2];
+      q += gnf_v[k][1] + gnf_v[k][3];
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      s += __shfl_xor(s, o);
+      q += __shfl_xor(q, o);
+    }
+    const int cpg = a.K / a.gnf_G;
+    if ((tid & 7) == 0 && (tid >> 3) < a.gnf_G) {
+      const float inv_n = 1.0f / ((float)cpg * (float)a.HoWo);
+      const float mean = s * inv_n;
+      gn_stat[tid >> 3] = mean;
+      gn_stat[64 + (tid >> 3)] = rsqrtf(fmaxf(q * inv_n - mean * mean, 0.f) + a.gnf_eps);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = tid + 256 * i;
+      if (k < a.K) {
+        const int g = k / cpg;
+        const float sc = gnf_g[i] * gn_stat[64 + g];
+        const half_t mh = (half_t)gn_stat[g];
+        gn_tab[k] = mh;
+        gn_tab[a.K + k] = (half_t)sc;
+        gn_tab[2 * a.K + k] = (half_t)(gnf_b[i] - (gn_stat[g] - (float)mh) * sc);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  wait_vmcnt_barrier<(D - 1) * PER>();                      // tile 0 has landed for every wave (GNF: and the table is visible)
   read_step(fA, 0);
   int rd_stage = 0;                                         // ring stage of the step being multiplied
   auto body = [&](Frags& cur, Frags& nxt, auto last) {
@@ -1466,7 +1557,7 @@ __global__ __launch_bounds__(256, D == 2 ? 2 : 1) void gemm_pipe_kernel(IgemmArg
       issue_tile();                                         // tile (step + D) -> the stage just freed
       mfma_step(cur);
       rd_stage = nstage;
-      if constexpr (!LNF) {
+      if constexpr (!LNF && !GNF) {
         constexpr int NM = KK * TM * TN, NR = KK * (TM + TN);
         constexpr int RPM = (NR + NM / 2 - 1) / (NM / 2);   // reads behind each MFMA of the first half
 #pragma unroll
@@ -1872,6 +1963,12 @@ IgemmArgs make_args(const ConvDesc& d) {
   a.res_pre = res_pre;
   a.gn_partial = nullptr;
   a.gn_G = a.gn_cpg = a.gn_T = 0;
+  a.gnf_partial = d.gnf_partial;
+  a.gnf_gamma = d.gnf_gamma;
+  a.gnf_beta = d.gnf_beta;
+  a.gnf_eps = d.gnf_eps;
+  a.gnf_G = d.gnf_groups;
+  a.gnf_entries = d.gnf_entries;
   return a;
 }
 
@@ -2175,6 +2272,16 @@ void launch_pipe(const IgemmArgs& a, hipStream_t s) {
       return;
     }
   }
+  if constexpr (BM == 64 && BN == 64 && !LNF) {   // GroupNorm-folded proj_in: 64 x 64 tile only (launch_conv routes it here)
+    if (a.gnf_partial) {
+      const size_t lds_g = lds + 128 * sizeof(float) + (size_t)3 * a.K * sizeof(half_t);
+      auto kg = gemm_pipe_kernel<BM, BN, WGM, WGN, D, false, 0, true>;
+      static DynLdsOnce once_g;
+      once_g.set(kg, lds + 128 * sizeof(float) + (size_t)3 * 2048 * sizeof(half_t));   // K <= 2048 (launch_conv)
+      hipLaunchKernelGGL(kg, grid, dim3(256), lds_g, s, a);
+      return;
+    }
+  }
   auto k = gemm_pipe_kernel<BM, BN, WGM, WGN, D, LNF>;
   static DynLdsOnce once;
   once.set(k, lds);
@@ -2358,6 +2465,15 @@ int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
   const bool twins = d.n_twins > 0;
   SD_REQUIRE(!twins || (d.out_mode == kOutHalf && !d.ln_colsum && !d.out_t && !d.debug && reduce_twin_ok(a.HoWo, a.N, d.n_twins, d.twin)),
              kInvalidArgument, "GroupNorm twins need a plain fp16 output and whole (sample, group) slices (HoWo=%d N=%d)", a.HoWo, a.N);
+  if (d.gnf_partial) {   // GroupNorm folded into this 1x1 GEMM: gemm_pipe_kernel's 64 x 64 tile (the only GNF instantiation)
+    SD_REQUIRE(d.ksize == 1 && d.stride == 1 && !d.x1 && d.out_mode == kOutHalf && !d.ln_colsum && !d.out_t && !twins && gemm_pipe_ok(a) &&
+                   d.gnf_gamma && d.gnf_beta && d.gnf_groups >= 1 && d.gnf_groups <= 32 && a.K % d.gnf_groups == 0 && a.K <= 2048 &&
+                   d.gnf_entries >= 1 && d.gnf_entries <= 128 && a.HoWo % 64 == 0,
+               kInvalidArgument, "GroupNorm fold: K=%d groups=%d entries=%d HoWo=%d", a.K, d.gnf_groups, d.gnf_entries, a.HoWo);
+    p.tile = 3;
+    if (p.staging != 6 && p.staging != 7 && p.staging != 8) p.staging = 6;
+    p.splitk = 1;
+  }
   if (p.tile == 9) {
     // weight-streaming kernel: slabs, then the group-organised combine (with the consumer's GroupNorm twins) or the plain one
     const int nw = p.staging == 4 ? 4 : 8;

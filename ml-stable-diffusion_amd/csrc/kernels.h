@@ -67,6 +67,15 @@ struct ConvDesc {
   // then runs its own statistics pass.
   float* gn_partial = nullptr;
   int gn_groups = 0;
+  // GroupNorm folded into this 1x1 GEMM (SpatialTransformer.norm -> proj_in, unet.py:528-531, :553-556): x0 is the UN-normalised
+  // tensor, gnf_partial holds gnf_entries (sum, sumsq) partials per (sample, group) written by x0's producer
+  // ([B][gnf_groups][kGnMaxSlabs][2]); the kernel turns them into per-channel scale / shift and applies them to its A fragments
+  // (v_pk_fma_f16 between the LDS read and the MFMA).  Needs a single source, Ho * Wo a multiple of the M tile, C0 <= 2048.
+  const float* gnf_partial = nullptr;
+  const float* gnf_gamma = nullptr;
+  const float* gnf_beta = nullptr;
+  float gnf_eps = 1e-6f;
+  int gnf_groups = 0, gnf_entries = 0;
   // weights in the fragment-major layout of wstream.hip (launch_wstream_retile), or null: plan tile 9 needs them
   const half_t* w_tiled = nullptr;
   // n_twins > 0: the output leaves through fp32 slabs and reduce_twin_kernel, which also writes the GroupNorm twins

@@ -9,6 +9,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <atomic>
 #include <vector>
 
 namespace sd {
@@ -95,15 +96,17 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per (kernel, device): remember it per device so a
 // process that drives several GPUs (one handle per device) raises the limit on each of them.
+// Handles may be driven from different host threads: the flags are atomics; two threads racing on the
+// first launch both set the (idempotent) attribute.
 struct DynLdsOnce {
-  bool done[32] = {};
+  std::atomic<bool> done[32] = {};
   template <class K>
   void set(K kernel, size_t bytes) {
     int dev = 0;
     SD_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 32 || !done[dev]) {
+    if (dev < 0 || dev >= 32 || !done[dev].load(std::memory_order_acquire)) {
       SD_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-      if (dev >= 0 && dev < 32) done[dev] = true;
+      if (dev >= 0 && dev < 32) done[dev].store(true, std::memory_order_release);
     }
   }
 };

@@ -614,8 +614,62 @@ Tensor UNet::transformer_block(std::vector<Op>& ops, const std::string& b, const
 
 // unet.py:553-563; GroupNorm eps hard-coded 1e-6 (unet.py:528-531)
 Tensor UNet::transformer(std::vector<Op>& ops, const std::string& p, const Tensor& x, int heads, int depth) {
-  Tensor t0 = group_norm(ops, p + ".norm", x, nullptr, 1e-6f, false);
-  Tensor h = conv(ops, p + ".proj_in", t0, nullptr, x.C, 1, 1, 1, true, nullptr, nullptr);
+  // norm -> proj_in as ONE launch where x's producer can leave the GroupNorm statistics (GnHook): the 1x1 GEMM folds them into a
+  // per-channel scale / shift of its activation fragments (gemm_pipe_kernel GNF).  When the producer's plan wrote none (split-K)
+  // the op falls back, at launch time, to the GroupNorm launch + the plain GEMM.  SD_GN_FOLD=0 (with SD_TUNE): always the pair (A/B).
+  static const int fold_mode = tune_env_int("SD_GN_FOLD", 1);
+  const int G = cfg_.norm_num_groups, C = x.C, HW = x.H * x.W;
+  ConvDesc d;
+  d.x0 = x.p;
+  d.C0 = C;
+  d.B = x.B;
+  d.Hi = d.Ho = x.H;
+  d.Wi = d.Wo = x.W;
+  d.N = C;
+  const bool fold = fold_mode != 0 && !f32_ && x.gn && !x.gn->partial && x.gn->n_twins == 0 && x.gn->ops_list == &ops && C % G == 0 && G <= 32 &&
+                    C <= 2048 && HW % 64 == 0 && conv_fast_path_ok(d) && (size_t)x.M() * C * 2 < ((size_t)1 << 31);
+  Tensor h;
+  if (fold) {
+    float* partial = arena_.alloc_n<float>(groupnorm_scratch_floats(x.B, HW, G));
+    const float* gamma = upload_vec(p + ".norm.weight", C);
+    const float* beta = upload_vec(p + ".norm.bias", C);
+    std::shared_ptr<GnHook> hook = x.gn;
+    hook->partial = partial;
+    hook->groups = G;
+    Tensor t0 = new_tensor(x.B, x.H, x.W, C);   // the normalised tensor of the fallback path
+    h = new_tensor(x.B, x.H, x.W, C);
+    d.w = upload_conv_weight(p + ".proj_in", C, C, 1, false);
+    d.bias = upload_vec(p + ".proj_in.bias", C);
+    d.out = h.p;
+    ws_need_ = std::max(ws_need_, conv_workspace_bytes(d));
+    const int B = x.B;
+    const half_t* xp = x.p;
+    ops.push_back([this, d, hook, partial, gamma, beta, t0, xp, B, HW, G, C](hipStream_t s) {
+      const int n = hook->entries;
+      if (n >= 1 && n <= 128) {
+        ConvDesc dd = d;
+        dd.gnf_partial = partial;
+        dd.gnf_gamma = gamma;
+        dd.gnf_beta = beta;
+        dd.gnf_eps = 1e-6f;
+        dd.gnf_groups = G;
+        dd.gnf_entries = n;
+        launch_conv(dd, ws_conv_, s);
+      } else {
+        launch_groupnorm(xp, C, nullptr, 0, partial, gamma, beta, t0.p, B, HW, G, 1e-6f, 0, s, n);
+        ConvDesc dd = d;
+        dd.x0 = t0.p;
+        launch_conv(dd, ws_conv_, s);
+      }
+    });
+    char buf[256];
+    snprintf(buf, sizeof(buf), "gemm1x1+gn %d->%d @%dx%d M=%d K=%d %s.proj_in #0,1,1,1,%d,%d,%d", C, C, x.H, x.W, x.M(), C, p.c_str(), C, C, x.M());
+    ops.back().label = buf;
+    ops.back().flop = 2.0 * x.M() * (double)C * C;
+  } else {
+    Tensor t0 = group_norm(ops, p + ".norm", x, nullptr, 1e-6f, false);
+    h = conv(ops, p + ".proj_in", t0, nullptr, x.C, 1, 1, 1, true, nullptr, nullptr);
+  }
   for (int d = 0; d < depth; ++d) h = transformer_block(ops, p + ".transformer_blocks." + std::to_string(d), h, heads);
   return conv(ops, p + ".proj_out", h, nullptr, x.C, 1, 1, 1, true, nullptr, x.p);
 }

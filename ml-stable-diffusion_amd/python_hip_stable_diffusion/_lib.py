@@ -93,6 +93,7 @@ SYMBOLS = [
     ("sd_op_groupnorm", _I, [_P, _FP, _FP, _P, _I, _I, _I, _I, _I, _F, _I, _I, _FP]),
     ("sd_op_conv2d", _I, [_P, _P, _FP, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _FP]),
     ("sd_op_conv2d_groupnorm", _I, [_P, _P, _FP, _P, _FP, _FP, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, C.POINTER(_I), _I, _FP]),
+    ("sd_op_conv2d_groupnorm_proj", _I, [_P, _P, _FP, _P, _FP, _FP, _P, _FP, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, C.POINTER(_I), _I, _FP]),
     ("sd_op_cross_attention_fused", _I, [_P, _FP, _FP, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _FP]),
     ("sd_op_geglu", _I, [_P, _P, _FP, _P, _I, _I, _I, _I, _FP]),
     ("sd_op_timestep_embedding", _I, [_FP, _FP, _I, _I, _I, _F]),
@@ -228,6 +229,30 @@ def conv2d_groupnorm(x, w, gn_weight, gn_bias, bias=None, res=None, groups=32, e
     check(lib().sd_op_conv2d_groupnorm(ptr(x), ptr(w), fptr(bias), ptr(res), fptr(gn_weight), fptr(gn_bias), ptr(conv_out),
                                        ptr(out), B, Cin, H, W, Cout, k, groups, eps, int(silu), tile, int(producer_stats),
                                        C.byref(entries), iters, C.byref(ms)))
+    return conv_out, out, entries.value, ms.value
+
+
+def conv2d_groupnorm_proj(x, w, gn_weight, gn_bias, proj_w, proj_bias=None, bias=None, res=None, groups=32, eps=1e-6, fold=True,
+                          tile=0, iters=1):
+    """proj(GroupNorm(conv(x))) - a resnet's last conv followed by SpatialTransformer.norm + proj_in; fold=True applies the
+    GroupNorm inside the projection GEMM.  Returns (conv_out, out, entries consumed by the fold, ms)."""
+    x, w, proj_w = f16(x), f16(w), f16(proj_w)
+    B, Cin, H, W = x.shape
+    Cout, k = w.shape[0], w.shape[2]
+    Np = proj_w.shape[0]
+    if w.shape[1] != Cin or proj_w.reshape(Np, -1).shape[1] != Cout:
+        raise ValueError("conv2d_groupnorm_proj: inconsistent shapes")
+    proj_w = np.ascontiguousarray(proj_w.reshape(Np, Cout))
+    gn_weight, gn_bias = f32(gn_weight), f32(gn_bias)
+    bias = None if bias is None else f32(bias)
+    proj_bias = None if proj_bias is None else f32(proj_bias)
+    res = None if res is None else f16(res)
+    conv_out = np.empty((B, Cout, H, W), np.float16)
+    out = np.empty((B, Np, H, W), np.float16)
+    ms, entries = C.c_float(0), C.c_int(0)
+    check(lib().sd_op_conv2d_groupnorm_proj(ptr(x), ptr(w), fptr(bias), ptr(res), fptr(gn_weight), fptr(gn_bias), ptr(proj_w),
+                                            fptr(proj_bias), ptr(conv_out), ptr(out), B, Cin, H, W, Cout, k, Np, groups, eps,
+                                            int(fold), tile, C.byref(entries), iters, C.byref(ms)))
     return conv_out, out, entries.value, ms.value
 
 

@@ -192,3 +192,41 @@ def test_in_workgroup_split_k_matches_torch(case, tile, splitk):
     close(out, y.numpy(), f"KG2 conv {case} tile {tile} splitk {splitk}")
     again, _ = _lib.conv2d(x, w, bias, res, stride=stride, tile=tile, splitk=splitk, iters=3)
     assert np.array_equal(out, again)
+
+
+GNF_CASES = [  # (B, Cin, H, C, k, tile of the producer, group mean offset)
+    (2, 320, 64, 320, 3, 0, 0.0),     # SD2.1-base level 0: resnet conv2 -> SpatialTransformer.norm -> proj_in at full size
+    (2, 640, 32, 640, 3, 0, 0.0),     # level 1
+    (2, 128, 16, 256, 1, 3, 0.0),     # 1x1 producer on the 64 x 64 tile, 8 channels per group
+    (1, 64, 8, 64, 1, 3, 0.0),        # one sample, HW = 64: a single M tile, 2 channels per group
+    (3, 192, 16, 192, 3, 0, 0.0),     # odd batch, 6 channels per group (groups straddle the fragments' 8-channel runs)
+    (2, 128, 32, 128, 3, 0, 6.0),     # groups far from zero (|mean| ~ 6 sigma): the subtraction-first form keeps its digits
+]
+
+
+@pytest.mark.parametrize("case", GNF_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_groupnorm_folded_into_proj_in(case):
+    """SpatialTransformer.norm -> proj_in as ONE launch (unet.py:528-531 eps 1e-6 no SiLU, :553-556): the GroupNorm statistics
+    come from the producing conv's epilogue, the 1x1 GEMM applies mean / scale / shift to its activation fragments
+    (gemm_pipe_kernel GNF).  Checked against fp32 torch on the conv output the kernel itself produced, and against the
+    GroupNorm launch + plain GEMM pair."""
+    b, cin, hw, c, k, tile, off = case
+    rs = np.random.RandomState(cin + c + hw + b)
+    x = h16(rs.randn(b, cin, hw, hw))
+    w = h16(rs.randn(c, cin, k, k) / np.sqrt(cin * k * k))
+    bias = (0.1 * rs.randn(c)).astype(np.float32) + off * np.repeat(rs.randn(32), c // 32).astype(np.float32)
+    res = h16(rs.randn(b, c, hw, hw) * 0.5)
+    gw = (1.0 + 0.2 * rs.randn(c)).astype(np.float32)
+    gb = (0.2 * rs.randn(c)).astype(np.float32)
+    pw = h16(rs.randn(c, c) / np.sqrt(c))
+    pb = (0.1 * rs.randn(c)).astype(np.float32)
+    conv_a, out_a, entries, _ = _lib.conv2d_groupnorm_proj(x, w, gw, gb, pw, pb, bias, res, 32, 1e-6, fold=True, tile=tile)
+    conv_b, out_b, none, _ = _lib.conv2d_groupnorm_proj(x, w, gw, gb, pw, pb, bias, res, 32, 1e-6, fold=False, tile=tile)
+    assert entries >= 1 and none == 0, (entries, none)
+    assert np.array_equal(conv_a, conv_b)
+    z = F.group_norm(torch.from_numpy(conv_a.astype(np.float32)), 32, torch.from_numpy(gw), torch.from_numpy(gb), 1e-6)
+    y = F.conv2d(z, torch.from_numpy(pw.astype(np.float32)).reshape(c, c, 1, 1), torch.from_numpy(pb)).numpy()
+    close(out_b, y, f"GroupNorm launch + GEMM {case}")
+    close(out_a, y, f"GroupNorm folded into the GEMM {case}")
+    _, again, _, _ = _lib.conv2d_groupnorm_proj(x, w, gw, gb, pw, pb, bias, res, 32, 1e-6, fold=True, tile=tile, iters=3)
+    assert np.array_equal(out_a, again)
