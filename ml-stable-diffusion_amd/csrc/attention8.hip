@@ -39,8 +39,9 @@ struct Attn8Args {
   half_t* out;
   int heads, Sq, Sk;
   int ldq, ldk, ldv, ldo;
-  float scale_log2;   // d^-0.5 * log2(e)
+  float scale_log2;   // d^-0.5 * log2(e); 1 when q arrives pre-scaled (AttnDesc::q_prescaled)
   int q_tiles;        // query tiles (WAVES * 32 queries) per (sample, head)
+  int prescaled;
 };
 
 __device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t& rs, char* lds, unsigned voffset, int soffset) {
@@ -107,8 +108,9 @@ __global__ __launch_bounds__(WAVES * 64) void attn8_kernel(Attn8Args a) {
   const half_t* kbase = a.k + (size_t)b * a.Sk * a.ldk + (size_t)h * 64;
   const half_t* vbase = a.vt + ((size_t)b * a.heads + h) * 64 * (size_t)a.ldv;
 
-  // ---- Q fragments (B operand of K.Q^T): lane (query l31, k half hi) holds 8 consecutive channels per 16-deep step,
-  //      pre-multiplied by d^-0.5 * log2(e) (one fp16 rounding per element, of the size q already carries) ----
+  // ---- Q fragments (B operand of K.Q^T): lane (query l31, k half hi) holds 8 consecutive channels per 16-deep step, carrying
+  //      d^-0.5 * log2(e): in the UNet the producing q|k|v GEMM multiplied it into its fp32 accumulator (prescaled: nothing
+  //      to do here, q was rounded once); a caller's plain q is multiplied here (one more fp16 rounding per element) ----
   half8 qf[4];
   {
     const int q = q0 + l31;
@@ -116,8 +118,10 @@ __global__ __launch_bounds__(WAVES * 64) void attn8_kernel(Attn8Args a) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       qf[kk] = (q < a.Sq) ? *reinterpret_cast<const half8*>(qbase + (size_t)q * a.ldq + kk * 16 + hi * 8) : z;
+      if (!a.prescaled) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) qf[kk][e] = (half_t)((float)qf[kk][e] * a.scale_log2);
+        for (int e = 0; e < 8; ++e) qf[kk][e] = (half_t)((float)qf[kk][e] * a.scale_log2);
+      }
     }
   }
 
@@ -250,7 +254,16 @@ __global__ __launch_bounds__(WAVES * 64) void attn8_kernel(Attn8Args a) {
     half8 kf[2][4];
     read_k(kf, aoff);
     qk(sA, kf);                                              // negm == 0: plain scaled scores
-    move_max(sA, xor32_max(raw_max(sA)));                    // oacc / ls are still zero: this only seeds m and shifts the scores
+    // seed the running max: oacc / ls are still zero, so nothing is rescaled - move_max would multiply them by
+    // exp2(-up), which is +inf for a first tile far below zero (0 * inf = NaN unless the compiler happens to fold it)
+    const float up = xor32_max(raw_max(sA));
+    mrun = up;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sA[0][r] -= up;
+      sA[1][r] -= up;
+      negm[r] = -up;
+    }
   }
 
   int st_cur = 0;                                            // ring stage of tile j
@@ -393,7 +406,7 @@ bool attention8_ok(const AttnDesc& d) {
 }
 
 void launch_attention8(const AttnDesc& d, hipStream_t s) {
-  Attn8Args a{d.q, d.k, d.vt, d.out, d.heads, d.Sq, d.Sk, d.ldq, d.ldk, d.ldv, d.ldo, 1.4426950408889634f / 8.0f, 0};
+  Attn8Args a{d.q, d.k, d.vt, d.out, d.heads, d.Sq, d.Sk, d.ldq, d.ldk, d.ldv, d.ldo, 1.4426950408889634f / 8.0f, 0, d.q_prescaled};
   static const bool exact = tune_env_int("SD_ATTN8_EXACT", 0) != 0;
   // 256-query workgroups when they give at least half the CUs one, else 128-query ones: more, smaller workgroups
   const long wg8 = (long)d.B * d.heads * cdiv(d.Sq, 256);

@@ -330,6 +330,10 @@ int sd_op_attention(int impl, const void* q, const void* k, const void* v, void*
     a.impl = impl;
     a.variant = variant;
     a.vt_perm = perm ? 1 : 0;
+    if (variant == 2) {   // the caller multiplied d^-0.5 * log2(e) into q before rounding it to fp16 (what the UNet's q|k|v GEMM does)
+      SD_REQUIRE(perm, kInvalidArgument, "attention variant 2 (pre-scaled q) needs attention8's shape (d %d Sq %d Sk %d)", d, Sq, Sk);
+      a.q_prescaled = 1;
+    }
     sc.timed(iters, ms, [&] { launch_attention(a, sc.stream); });
     std::vector<half_t> ot((size_t)B * Sq * C);
     SD_HIP(hipMemcpy(ot.data(), o, ot.size() * 2, hipMemcpyDeviceToHost));
@@ -425,9 +429,13 @@ int sd_op_conv2d(const void* x, const void* w, const float* bias, const void* re
       ws.partial_bytes = conv_workspace_bytes(d);
       if (ws.partial_bytes) ws.partial = reinterpret_cast<float*>(sc.dev<char>(ws.partial_bytes));
     }
+    // N <= 8 (conv_out of the UNet / the VAE): the small-N kernels the handles use, unless the direct kernel was asked for
+    const bool small_n = !fast && force_generic == 0 && Cout <= 8 && Cin % 8 == 0 && ksize == 3 && stride == 1 && !res;
     sc.timed(iters, ms, [&] {
       if (fast)
         launch_conv(d, ws, sc.stream);
+      else if (small_n)
+        launch_conv_small_n(d, nullptr, sc.stream);
       else
         launch_conv_generic(d, 0, sc.stream);
     });

@@ -78,6 +78,9 @@ struct IgemmArgs {
   const float* gnf_beta;
   float gnf_eps;
   int gnf_G, gnf_entries;
+  // fused q|k|v: columns [0, q_cols) leave multiplied by q_scale in fp32 (ConvDesc::q_scale); q_cols = 0: off
+  float q_scale;
+  int q_cols;
 };
 
 constexpr int kGnScratchFloats = 256 * 17;   // per-thread (sum[8], sumsq[8]) of the epilogue's store loop, +1 pad
@@ -267,6 +270,10 @@ __device__ __forceinline__ void tile_epilogue(const IgemmArgs& a, floatx16 (&acc
             } else {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] += bb[e];
+            }
+            if (n < a.q_cols) {   // queries for attention8: softmax scale and log2(e) before the rounding to fp16
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] *= a.q_scale;
             }
             if (a.temb && !temb_uniform && n < a.N) {   // tile straddles samples (HoWo < BM): per-row sample index
               floatx4 tt = *reinterpret_cast<const floatx4*>(a.temb + (size_t)b * a.temb_stride + n);
@@ -1905,6 +1912,87 @@ __global__ __launch_bounds__(256) void conv_small_n_kernel(IgemmArgs a, float* o
   }
 }
 
+// ---- N <= 4 output channels, 3x3 / stride 1 (the UNet's conv_out 320 -> 4, the VAE decoder's 128 -> 3): FOUR pixels of a row per
+// lane group (round 5).  The one-wave-per-pixel kernel above walks its nine taps as nine dependent load -> FMA rounds (32 us for
+// 8192 pixels: pure latency); here a group of LPC lanes (one per 8-channel chunk) requests the 3 x 6 input patch of four
+// neighbouring pixels and the 9 x N weight chunks up front - 18 + 9 N independent 16-byte loads in flight per lane -, multiplies
+// with v_dot2_f32_f16 and folds the LPC partial sums by butterfly.  64 / LPC groups per wave (C = 128: four groups of 16 lanes).
+template <int LPC>
+__global__ __launch_bounds__(256) void conv3x3_small_n_rows_kernel(IgemmArgs a, float* out_nchw) {
+  constexpr int PG = 64 / LPC, PX = 4, NMAX = 4;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / LPC, cl = lane % LPC;
+  const int gpr = a.Wo / PX;                                   // pixel groups per row
+  const int total = a.B * a.Ho * gpr;
+  const int g = (blockIdx.x * 4 + (threadIdx.x >> 6)) * PG + sub;
+  const bool live = g < total && cl < (a.Ctot >> 3);
+  const int gg = g < total ? g : total - 1;
+  const int row = gg / gpr, gx = gg - row * gpr;
+  const int b = row / a.Ho, oy = row - b * a.Ho, ox0 = gx * PX;
+  const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  half8 xv[3][PX + 2];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int iy = oy - 1 + r;
+#pragma unroll
+    for (int c = 0; c < PX + 2; ++c) {
+      const int ix = ox0 - 1 + c;
+      const bool ok = live && iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi;
+      xv[r][c] = ok ? *reinterpret_cast<const half8*>(a.x0 + (((size_t)b * a.Hi + iy) * a.Wi + ix) * a.C0 + cl * 8) : z;
+    }
+  }
+  half8 wv[NMAX][9];
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+      wv[n][t] = (live && n < a.N) ? *reinterpret_cast<const half8*>(a.w + (size_t)n * a.K + (size_t)t * a.Ctot + cl * 8) : z;
+  float acc[NMAX][PX];
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n)
+#pragma unroll
+    for (int px = 0; px < PX; ++px) acc[n][px] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int px = 0; px < PX; ++px)
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const half2v x2 = {xv[r][px + kx][2 * e], xv[r][px + kx][2 * e + 1]};
+            const half2v w2 = {wv[n][r * 3 + kx][2 * e], wv[n][r * 3 + kx][2 * e + 1]};
+            acc[n][px] = __builtin_amdgcn_fdot2(x2, w2, acc[n][px], false);
+          }
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n)
+#pragma unroll
+    for (int px = 0; px < PX; ++px) {
+      float v = acc[n][px];
+#pragma unroll
+      for (int o = LPC / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      acc[n][px] = v;
+    }
+  // lanes 0-15 of the group store one (channel, pixel) each
+  const int sel = cl & 15;
+  float v = 0.f;
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n)
+#pragma unroll
+    for (int px = 0; px < PX; ++px) v = (sel == n * PX + px) ? acc[n][px] : v;
+  const int n = sel >> 2, px = sel & 3;
+  if (g < total && cl < 16 && n < a.N) {
+    v += a.bias ? a.bias[n] : 0.f;
+    const int rem = oy * a.Wo + ox0 + px;
+    if (out_nchw)
+      out_nchw[((size_t)b * a.N + n) * a.HoWo + rem] = v;
+    else
+      a.out[((size_t)b * a.HoWo + rem) * a.N + n] = (half_t)v;
+  }
+}
+
 const half_t* device_zero_chunk() {   // allocated on first use (always outside graph capture: eager warm-up run)
   static half_t* p = nullptr;
   if (!p) {
@@ -1969,6 +2057,8 @@ IgemmArgs make_args(const ConvDesc& d) {
   a.gnf_eps = d.gnf_eps;
   a.gnf_G = d.gnf_groups;
   a.gnf_entries = d.gnf_entries;
+  a.q_scale = d.q_scale;
+  a.q_cols = d.out_t ? d.q_cols : 0;
   return a;
 }
 
@@ -2459,6 +2549,7 @@ int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
                           d.ldT % 8 == 0 && !d.res && !d.temb),
              kInvalidArgument, "fused q|k|v: n_trans %d N %d HoWo %d ldT %d", d.n_trans, d.N, d.Ho * d.Wo, d.ldT);
   SD_REQUIRE(!d.vt_perm || (d.out_t && (d.Ho * d.Wo) % 16 == 0), kInvalidArgument, "permuted V^T needs the fused q|k|v epilogue and HoWo %% 16 == 0");
+  SD_REQUIRE(d.q_cols == 0 || (d.out_t && d.q_cols % 4 == 0 && d.q_cols <= d.n_trans), kInvalidArgument, "pre-scaled queries need the fused q|k|v epilogue (q_cols %d)", d.q_cols);
   IgemmArgs a = make_args(d);
   Plan p = choose_plan(d, a);
   const bool halo = p.tile == 7;
@@ -2594,6 +2685,22 @@ void launch_conv_small_n(const ConvDesc& d, float* out_nchw_f32, hipStream_t s) 
   IgemmArgs a = make_args(d);
   SD_REQUIRE(a.N <= 8 && a.Ctot % 8 == 0 && a.C0 % 8 == 0, kInvalidArgument, "conv_small_n: N=%d Ctot=%d", a.N,
              a.Ctot);
+  // 3x3 / stride 1 / N <= 4: four pixels of a row per lane group, every load in flight at once (conv3x3_small_n_rows_kernel);
+  // SD_CONV_OUT_ROWS=0 (with SD_TUNE) keeps the one-wave-per-pixel kernel: A/B
+  static const int rows_mode = tune_env_int("SD_CONV_OUT_ROWS", 1);
+  const int chunks = a.Ctot / 8;
+  const int lpc = chunks <= 16 ? 16 : (chunks <= 32 ? 32 : 64);
+  if (rows_mode != 0 && a.ksize == 3 && a.stride == 1 && a.up == 1 && a.pad == 1 && !d.x1 && a.N <= 4 && chunks <= 64 &&
+      a.Wo % 4 == 0 && a.Hi == a.Ho && a.Wi == a.Wo) {
+    const int pg = 64 / lpc;
+    const int groups = a.B * a.Ho * (a.Wo / 4);
+    const dim3 grid(cdiv(cdiv(groups, pg), 4));
+    if (lpc == 16) hipLaunchKernelGGL(conv3x3_small_n_rows_kernel<16>, grid, dim3(256), 0, s, a, out_nchw_f32);
+    else if (lpc == 32) hipLaunchKernelGGL(conv3x3_small_n_rows_kernel<32>, grid, dim3(256), 0, s, a, out_nchw_f32);
+    else hipLaunchKernelGGL(conv3x3_small_n_rows_kernel<64>, grid, dim3(256), 0, s, a, out_nchw_f32);
+    SD_HIP(hipGetLastError());
+    return;
+  }
   hipLaunchKernelGGL(conv_small_n_kernel<8>, dim3(cdiv(a.M, 4)), dim3(256), 0, s, a, out_nchw_f32);
   SD_HIP(hipGetLastError());
 }

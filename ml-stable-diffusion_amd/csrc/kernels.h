@@ -61,6 +61,10 @@ struct ConvDesc {
   half_t* out_t = nullptr;
   int n_trans = 0;
   int vt_perm = 0;              // out_t in the key order of AttnDesc::vt_perm (needs Ho*Wo % 16 == 0)
+  // fused q|k|v for attention8: output columns [0, q_cols) - the queries - leave multiplied by q_scale (d^-0.5 * log2 e), applied
+  // to the fp32 accumulator BEFORE the one rounding to fp16 (AttnDesc::q_prescaled).  0 columns = off.
+  float q_scale = 1.f;
+  int q_cols = 0;
   // GroupNorm statistics of the output from the conv's own epilogue (the consumer is a GroupNorm over exactly this
   // tensor, gn_groups groups): partial sums go to gn_partial [B][gn_groups][kGnMaxSlabs][2].  launch_conv returns how
   // many entries per (sample, group) it wrote - 0 when the chosen plan cannot (split-K, ragged tiles): the GroupNorm
@@ -140,7 +144,12 @@ struct AttnDesc {
   // P.V MFMA consumes keys, so its V^T fragment is ONE 16-byte LDS read (attention8.hip; written so by the fused q|k|v GEMM,
   // ConvDesc::vt_perm).  Only attention8 reads this layout; the general kernels need 0.
   int vt_perm = 0;
+  // 1: q already carries d^-0.5 * log2(e) (multiplied into the fp32 accumulator of the producing GEMM, ConvDesc::q_scale): attention8
+  // does not re-scale (and re-round) it.  Only with vt_perm.
+  int q_prescaled = 0;
 };
+// the factor a producer of pre-scaled queries multiplies in (head dim d)
+inline float attention_q_prescale(int d) { return 1.4426950408889634f / sqrtf((float)d); }
 void launch_attention(const AttnDesc& d, hipStream_t s);
 bool attention_supported(int d);
 // attention8.hip: head dim 64, S_k a multiple of 64 (the UNet's self-attention): LDS-DMA ring, two waves per SIMD, software-

@@ -275,6 +275,10 @@ Tensor UNet::conv_w(std::vector<Op>& ops, const std::string& name, const half_t*
   Tensor out;
   if (ex) d.ln_colsum = ex->ln_colsum;
   if (ex) d.vt_perm = ex->vt_perm ? 1 : 0;
+  if (ex) {
+    d.q_scale = ex->q_scale;
+    d.q_cols = ex->q_cols;
+  }
   if (ex && ex->n_trans > 0) {   // fused q|k|v: [M][n_trans] row-major + V^T [B][cout - n_trans][ldT]
     out = new_tensor(x.B, d.Ho, d.Wo, ex->n_trans);
     ex->vt = arena_.alloc_n<half_t>((size_t)x.B * (cout - ex->n_trans) * ldT);
@@ -495,7 +499,7 @@ Tensor UNet::resnet(std::vector<Op>& ops, const std::string& p, const Tensor& x,
 }
 
 Tensor UNet::attention(std::vector<Op>& ops, const Tensor& q, const half_t* k, const half_t* vt, int heads, int Sq,
-                       int Sk, int ldk, int ldv, int ldq, bool vt_perm) {
+                       int Sk, int ldk, int ldv, int ldq, bool vt_perm, bool q_prescaled) {
   Tensor o = new_tensor(q.B, q.H, q.W, q.C);
   AttnDesc d;
   d.q = q.p;
@@ -512,6 +516,7 @@ Tensor UNet::attention(std::vector<Op>& ops, const Tensor& q, const half_t* k, c
   d.ldv = ldv;
   d.ldo = q.C;
   d.vt_perm = vt_perm ? 1 : 0;
+  d.q_prescaled = (vt_perm && q_prescaled) ? 1 : 0;
   SD_REQUIRE(attention_supported(d.d), kUnsupported, "head dim %d (C=%d, heads=%d) unsupported", d.d, q.C, heads);
   ops.push_back([this, d](hipStream_t s) {
     AttnDesc dd = d;
@@ -532,6 +537,7 @@ Tensor UNet::transformer_block(std::vector<Op>& ops, const std::string& b, const
   const int ldv = round_up(S, 8);
   Tensor qk;
   bool vt_perm = false;   // attention8.hip will run this self-attention: the fused q|k|v GEMM writes V^T in its key order
+  bool q_pre = false;     // ... and the queries pre-scaled
   half_t* vtp;
   if (can_fold_ln(h, 3 * C, false) && S % 8 == 0 && (2 * C) % 64 == 0) {
     LnFold f = fold_layernorm(b + ".norm1", {b + ".attn1.to_q", b + ".attn1.to_k", b + ".attn1.to_v"}, C, C, false);
@@ -540,6 +546,11 @@ Tensor UNet::transformer_block(std::vector<Op>& ops, const std::string& b, const
     ex.n_trans = 2 * C;
     vt_perm = attention8_shape_ok(C / heads, S, S) && S % 16 == 0;
     ex.vt_perm = vt_perm;
+    if (vt_perm) {   // attention8 takes the queries with d^-0.5 * log2(e) already in them: multiplied into the fp32 accumulator here
+      ex.q_scale = attention_q_prescale(C / heads);
+      ex.q_cols = C;
+      q_pre = true;
+    }
     qk = conv_w(ops, b + ".attn1.to_qkv", f.w, f.bias, h, nullptr, 3 * C, 1, 1, 1, nullptr, nullptr, kOutHalf, ldv,
                 false, &ex);
     vtp = ex.vt;
@@ -550,7 +561,7 @@ Tensor UNet::transformer_block(std::vector<Op>& ops, const std::string& b, const
   }
   Tensor q = qk;
   q.C = C;   // logical width of q; rows are 2C apart
-  Tensor a1 = attention(ops, q, qk.p + C, vtp, heads, S, S, 2 * C, ldv, 2 * C, vt_perm);
+  Tensor a1 = attention(ops, q, qk.p + C, vtp, heads, S, S, 2 * C, ldv, 2 * C, vt_perm, q_pre);
   Tensor h1 = conv(ops, b + ".attn1.to_out.0", a1, nullptr, C, 1, 1, 1, true, nullptr, h.p);
   // --- cross attention: K / V^T of the prompt are computed by ctx_ops_ when the prompt changes
   const int ldvc = round_up(L, 8);

@@ -101,6 +101,8 @@ class UNet {
     int n_trans = 0;
     half_t* vt = nullptr;   // out
     bool vt_perm = false;   // V^T in attention8's key order (AttnDesc::vt_perm)
+    float q_scale = 1.f;    // fused q|k|v: the first q_cols columns leave pre-scaled for attention8 (ConvDesc::q_scale)
+    int q_cols = 0;
   };
   Tensor conv_w(std::vector<Op>& ops, const std::string& name, const half_t* w, const float* bias, const Tensor& x,
                 const Tensor* x2, int cout, int k, int stride, int up, const float* temb, const half_t* res,
@@ -125,7 +127,7 @@ class UNet {
   Tensor transformer_block(std::vector<Op>& ops, const std::string& b, const Tensor& h, int heads);
   Tensor vae_attention(std::vector<Op>& ops, const std::string& p, const Tensor& h);
   Tensor attention(std::vector<Op>& ops, const Tensor& q, const half_t* k, const half_t* vt, int heads, int Sq,
-                   int Sk, int ldk, int ldv, int ldq, bool vt_perm = false);
+                   int Sk, int ldk, int ldv, int ldq, bool vt_perm = false, bool q_prescaled = false);
   void down_and_mid(std::vector<Op>& ops, Tensor& h, std::vector<Tensor>& skips);
   const float* register_temb(const std::string& name, int cout);
   void finalize_temb();

@@ -230,3 +230,93 @@ def test_groupnorm_folded_into_proj_in(case):
     close(out_a, y, f"GroupNorm folded into the GEMM {case}")
     _, again, _, _ = _lib.conv2d_groupnorm_proj(x, w, gw, gb, pw, pb, bias, res, 32, 1e-6, fold=True, tile=tile, iters=3)
     assert np.array_equal(out_a, again)
+
+
+# ---------------------------------------------------------------- attention8 at real-checkpoint logit magnitudes
+def _attn_truth(q32, k, v, h):
+    from oracle import attention_ref
+    return attention_ref.original(q32.astype(np.float32), k.astype(np.float32), v.astype(np.float32), h, 64)
+
+
+def test_attention8_first_key_tile_far_below_zero():
+    """a query whose first 64 keys all score below -128 in log2 units made the seed of the running max multiply
+    the (zero) accumulators by exp2(+big) = inf; the seed now only sets the max.  First tile anti-aligned with the queries."""
+    b, h, sq, sk = 1, 2, 128, 256
+    rs = np.random.RandomState(11)
+    q = rs.randn(b, h * 64, 1, sq).astype(np.float32) * 3.0
+    k = rs.randn(b, h * 64, 1, sk).astype(np.float32)
+    v = rs.randn(b, h * 64, 1, sk).astype(np.float32)
+    qm = q.reshape(b, h, 64, sq).mean(axis=3, keepdims=True)            # a direction every query of the head shares
+    q = (q.reshape(b, h, 64, sq) + 6.0 * np.sign(qm)).reshape(b, h * 64, 1, sq)
+    kk = k.reshape(b, h, 64, sk)
+    kk[:, :, :, :64] = -8.0 * np.sign(qm) + 0.1 * kk[:, :, :, :64]     # first key tile: q.k / 8 * log2(e) far below -128
+    k = kk.reshape(b, h * 64, 1, sk)
+    q, k, v = h16(q), h16(k), h16(v)
+    s0 = np.einsum("bhcq,bhck->bhqk", q.astype(np.float32).reshape(b, h, 64, sq), k.astype(np.float32).reshape(b, h, 64, sk)[:, :, :, :64])
+    assert (s0.max(axis=3) / 8 * 1.4427 < -128).any(), "the case must reach the overflow range"
+    ref = _attn_truth(q, k, v, h)
+    for impl in ("ORIGINAL", "SPLIT_EINSUM"):
+        out, _ = _lib.attention(impl, q, k, v, h, 64)
+        close(out, ref, f"attention8 {impl}, first tile below -128")
+
+
+def test_attention8_query_scale_rounding_at_large_logits():
+    """Logits of real-checkpoint magnitude (|q.k| / 8 up to ~60, competing keys, per-head outliers).  The reference rounds q to
+    fp16 and scales the scores in fp32 (attention.py:49); the general kernel does the same; attention8 takes q with the scale in
+    it.  Measured against the fp32 result on UNROUNDED queries: q scaled in fp32 and rounded once (variant 2: the UNet's path)
+    must be as good as the reference's order; scaling the rounded q again in fp16 (variant 0: a caller's plain q) may cost at
+    most 3 dB."""
+    from oracle import psnr
+    b, h, sq, sk = 1, 4, 256, 512
+    rs = np.random.RandomState(5)
+    q32 = rs.randn(b, h * 64, 1, sq).astype(np.float32)
+    k32 = rs.randn(b, h * 64, 1, sk).astype(np.float32)
+    v = h16(rs.randn(b, h * 64, 1, sk))
+    gain = np.repeat(np.array([2.0, 4.0, 6.0, 7.5], np.float32), 64).reshape(1, h * 64, 1, 1)   # per-head logit scale
+    q32 = q32 * gain
+    k32[:, :, :, 17] *= 3.0                                                                        # an outlier key
+    k = h16(k32)
+    c = np.float32(1.4426950408889634 / 8.0)
+    truth = _attn_truth(q32, k, v, h)
+    s = np.einsum("bhcq,bhck->bhqk", q32.reshape(b, h, 64, sq), k.astype(np.float32).reshape(b, h, 64, sk)) / 8
+    assert 40 < np.abs(s).max() < 400, np.abs(s).max()
+    got = {
+        "general (fp16 q, fp32 scale)": _lib.attention("ORIGINAL", h16(q32), k, v, h, 64, variant=1)[0],
+        "attention8, plain q": _lib.attention("ORIGINAL", h16(q32), k, v, h, 64, variant=0)[0],
+        "attention8, pre-scaled q": _lib.attention("ORIGINAL", h16(q32 * c), k, v, h, 64, variant=2)[0],
+    }
+    db = {n: psnr.compute_psnr(np.asarray(o, np.float64), truth.astype(np.float64)) for n, o in got.items()}
+    print("PSNR vs fp32 attention on unrounded q:", {n: round(x, 2) for n, x in db.items()})
+    base = db["general (fp16 q, fp32 scale)"]
+    assert base > 35, db
+    assert db["attention8, pre-scaled q"] >= base - 1.0, db
+    assert db["attention8, plain q"] >= base - 3.0, db
+
+
+SMALL_N_CASES = [  # (B, Cin, H, W, Cout, upsample)
+    (2, 320, 64, 64, 4, False),     # the UNet's conv_out at full size: 64 lanes, one 4-pixel group per wave
+    (1, 128, 64, 96, 3, False),     # the VAE decoder's conv_out shape class: 16 lanes per group, four groups per wave, N = 3
+    (1, 256, 8, 12, 4, False),      # 32 lanes per group, rows shorter than a wave's pixels, ragged last wave
+    (1, 64, 5, 4, 2, False),        # 8 chunks on a 16-lane group (dead lanes), odd height
+    (1, 640, 8, 8, 4, False),       # 80 chunks: above the row kernel's range -> the one-wave-per-pixel kernel
+    (1, 64, 6, 6, 4, False),        # W % 4 != 0 -> the one-wave-per-pixel kernel
+    (2, 64, 8, 8, 8, False),        # N = 8 (VAE encoder conv_out): the one-wave-per-pixel kernel
+]
+
+
+@pytest.mark.parametrize("case", SMALL_N_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_small_n_conv_matches_torch(case):
+    """conv_out (unet.py:1046: 320 -> 4, 3x3) and the VAE decoder's / encoder's last conv on the small-N kernels: every border
+    pixel, dead lanes, both kernels' shape ranges."""
+    b, cin, h, w_, cout, up = case
+    rs = np.random.RandomState(cin + cout + h + w_)
+    x = h16(rs.randn(b, cin, h, w_))
+    w = h16(rs.randn(cout, cin, 3, 3) / np.sqrt(cin * 9))
+    bias = (0.1 * rs.randn(cout)).astype(np.float32)
+    y = conv_ref(x, w, bias, None, up).numpy()
+    out, _ = _lib.conv2d(x, w, bias)
+    close(out, y, f"small-N conv {case}")
+    ref_kernel, _ = _lib.conv2d(x, w, bias, force_generic=True)
+    close(ref_kernel, y, f"direct conv {case}")
+    again, _ = _lib.conv2d(x, w, bias, iters=3)
+    assert np.array_equal(out, again)
