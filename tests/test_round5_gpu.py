@@ -4,6 +4,8 @@
   * GroupNorm(+SiLU) written by the conv's own slab combine ("twin", reduce_twin_kernel) instead of a GroupNorm launch
     (unet.py:430-451, :472-481, :528-531).
 Tolerances as tests/test_ops_gpu.py: PSNR >= 60 dB, max |err| <= 4e-3 * max|ref| + 1e-3 (fp16 I/O, fp32 accumulate)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -140,6 +142,9 @@ STATS_CASES = [  # (B, Cin, HW, Cout, k, tile, entries expected)
 ]
 
 
+@pytest.mark.skipif(os.environ.get("SD_TUNE") is None or os.environ.get("SD_REDUCE_STATS") != "1",
+                    reason="the statistics pass of the slab combine is off by default (measured: the step loses 0.25 ms); "
+                           "run with SD_TUNE=1 SD_REDUCE_STATS=1")
 @pytest.mark.parametrize("case", STATS_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_groupnorm_statistics_from_the_slab_combine(case):
     """Split-K / weight-streaming producers (every conv of the 8x8 / 16x16 levels): the GroupNorm statistics come out of the slab
