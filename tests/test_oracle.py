@@ -259,3 +259,37 @@ def test_vae_decoder_oracle_equals_the_golden_of_the_reference_blocks(name):
     got = vae_ref.vae_decode(sd, cfg, torch.from_numpy(z)).numpy()
     assert got.shape == g["image"].shape
     assert np.abs(got - g["image"]).max() <= 1e-5 * max(1.0, np.abs(g["image"]).max())
+
+
+@pytest.mark.parametrize("name", ["mini", "sd"])
+def test_vae_encoder_oracle_equals_the_golden_of_the_reference_blocks(name):
+    """oracle/vae_ref.vae_encode against tests/golden/vae_encoder_*_golden.npz, written by oracle/pin_round5.py from the reference's
+    OWN ResnetBlock2D(temb_channels=None, eps=1e-6) / attention.original(heads=1) plus the two plain torch calls of the asymmetric
+    down-sampler (F.pad (0,1,0,1) + F.conv2d stride 2) wired in the encoder's topology (torch2coreml.py:739-749): the encoder's
+    arithmetic is pinned, its topology restated (diffusers absent)."""
+    import torch
+    from oracle import vae_ref, weights
+    from oracle.pin_round5 import encoder_image
+    g = load_golden(f"vae_encoder_{name}_golden.npz")
+    cfg = vae_ref.VAE_CONFIGS[name]
+    hw = int(g["hw"])
+    sd16 = weights.make_state_dict(vae_ref.vae_encoder_param_shapes(cfg), seed=int(g["seed"]), dtype=np.float16, gain=float(g["gain"]))
+    sd = weights.to_torch({k: v.astype(np.float32) for k, v in sd16.items()})
+    got = vae_ref.vae_encode(sd, cfg, torch.from_numpy(encoder_image(hw, int(g["x_seed"])).astype(np.float32))).numpy()
+    assert got.shape == g["moments"].shape == (1, 8, hw // 8, hw // 8)
+    assert np.abs(got - g["moments"]).max() <= 1e-5 * max(1.0, np.abs(g["moments"]).max())
+
+
+def test_vae_decoder_oracle_equals_the_reference_block_golden_at_the_benchmarked_size():
+    """the 64x64-latent decode bench.py times (oracle/pin_round5.py --vae64; golden stored as fp16)"""
+    import torch
+    from oracle import vae_ref, weights
+    g = load_golden("vae_decoder_sd64_golden.npz")
+    cfg = vae_ref.VAE_CONFIGS["sd"]
+    hw = int(g["hw"])
+    sd = weights.to_torch(weights.round_to_fp16(weights.make_state_dict(vae_ref.vae_decoder_param_shapes(cfg), seed=int(g["seed"]))))
+    z = weights.seeded_normal((1, cfg["latent_channels"], hw, hw), int(g["z_seed"])).astype(np.float16).astype(np.float32)
+    got = vae_ref.vae_decode(sd, cfg, torch.from_numpy(z)).numpy()
+    ref = g["image"].astype(np.float32)
+    assert got.shape == ref.shape == (1, 3, 512, 512)
+    assert np.abs(got - ref).max() <= 2.0 ** -11 * np.abs(ref).max() + 1e-6   # the golden's own fp16 storage rounding

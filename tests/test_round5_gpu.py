@@ -325,3 +325,42 @@ def test_small_n_conv_matches_torch(case):
     close(ref_kernel, y, f"direct conv {case}")
     again, _ = _lib.conv2d(x, w, bias, iters=3)
     assert np.array_equal(out, again)
+
+
+# ---------------------------------------------------------------- VAE encoder / 64x64 decoder against the reference's own blocks
+@pytest.mark.parametrize("name", ["mini", "sd"])
+def test_vae_encoder_matches_the_golden_of_the_reference_blocks(name):
+    """tests/golden/vae_encoder_*_golden.npz: quant_conv(encoder(x)) (torch2coreml.py:739-749) wired from the reference's
+    ResnetBlock2D(temb_channels=None, eps=1e-6) and single-head attention.original plus F.pad((0,1,0,1)) / F.conv2d(stride=2)
+    (oracle/pin_round5.py): arithmetic pinned by the reference's blocks, topology restated."""
+    from conftest import load_golden
+    from oracle import vae_ref, weights
+    from oracle.pin_round5 import encoder_image
+    from python_hip_stable_diffusion import HipVaeEncoder
+    g = load_golden(f"vae_encoder_{name}_golden.npz")
+    cfg = vae_ref.VAE_CONFIGS[name]
+    hw = int(g["hw"])
+    sd16 = weights.make_state_dict(vae_ref.vae_encoder_param_shapes(cfg), seed=int(g["seed"]), dtype=np.float16, gain=float(g["gain"]))
+    enc = HipVaeEncoder(cfg, sd16, batch=1, height=hw, width=hw)
+    out = enc(x=encoder_image(hw, int(g["x_seed"])))["latent"]
+    p = psnr.compute_psnr(out, g["moments"])
+    assert out.shape == g["moments"].shape and p >= 67.0, f"VAE encoder {name}: PSNR {p:.1f} dB vs the reference-block golden"
+    enc.close()
+
+
+def test_vae_decoder_matches_the_reference_block_golden_at_the_benchmarked_size():
+    """the decode bench.py times: SD-sized decoder, 64x64 latents -> 512x512 image (oracle/pin_round5.py --vae64)"""
+    from conftest import load_golden
+    from oracle import vae_ref, weights
+    from python_hip_stable_diffusion import HipVaeDecoder
+    g = load_golden("vae_decoder_sd64_golden.npz")
+    cfg = vae_ref.VAE_CONFIGS["sd"]
+    hw = int(g["hw"])
+    sd16 = weights.make_state_dict(vae_ref.vae_decoder_param_shapes(cfg), seed=int(g["seed"]), dtype=np.float16)
+    vae = HipVaeDecoder(cfg, sd16, batch=1, latent_height=hw, latent_width=hw)
+    z = weights.seeded_normal((1, cfg["latent_channels"], hw, hw), int(g["z_seed"])).astype(np.float16)
+    out = vae(z=z)["image"]
+    ref = g["image"].astype(np.float32)
+    p = psnr.compute_psnr(out, ref)
+    assert out.shape == ref.shape == (1, 3, 512, 512) and p >= 60.0, f"VAE decoder @64x64: PSNR {p:.1f} dB vs the reference-block golden"
+    vae.close()

@@ -1,8 +1,7 @@
 #!/usr/bin/env python
 """Where do the main loops top out?  The 1x1 GEMM kernels of this library (best plan code per shape out of igemm_kernel's
 tiles, gemm_pipe_kernel's rings / tiles) and the K-split halo 3x3 conv against the vendor libraries
-(hipBLASLt through torch F.linear, MIOpen through F.conv2d channels_last fp16 - yardsticks, never linked) at M = 8 192 ...
-131 072 rows, back-to-back launches (operands L2 / Infinity-Cache warm: the ceiling, not the in-sequence time).
+(hipBLASLt through torch F.linear, MIOpen through F.conv2d channels_last fp16 - yardsticks, never linked) at M = 128 ... 131 072 rows (round 5: the small-M shapes of the 8x8 / 16x16 / 32x32 levels too), back-to-back launches (operands L2 / Infinity-Cache warm: the ceiling, not the in-sequence time).
 usage: gemm_ceiling.py [out.txt]"""
 import os
 import sys
@@ -41,7 +40,9 @@ def torch_us(fn, iters=30):
 say("1x1 GEMM (bias + residual epilogue), fp16: best plan code of libsdmi355 vs hipBLASLt (F.linear, no epilogue), us and TFLOP/s; peak 2500")
 rs = np.random.RandomState(0)
 for cin, cout in ((320, 320), (640, 640), (1280, 1280), (1280, 320), (2560, 640), (5120, 1280), (320, 2560), (1280, 10240)):
-    for m in (8192, 32768, 131072):
+    for m in (128, 512, 2048, 8192, 32768, 131072):
+        if m < 8192 and not ((m <= 512 and cin >= 1280) or (m == 2048 and cin in (640, 2560)) ):
+            continue   # small M: only the shapes the 8x8 / 16x16 / 32x32 levels of the SD2.1 step have
         hw = int(round((m // 2) ** 0.5))
         if 2 * hw * hw != m:
             continue
@@ -50,7 +51,7 @@ for cin, cout in ((320, 320), (640, 640), (1280, 1280), (1280, 320), (2560, 640)
         res = rs.randn(2, cout, hw, hw).astype(np.float16)
         flop = 2.0 * m * cin * cout
         best = None
-        for code in CODES:
+        for code in (CODES + [3, 23, 33, 43, 63, 73, 83, 24, 34] if m < 8192 else CODES):
             _, ms = _lib.conv2d(x, w, np.zeros(cout, np.float32), res, tile=code, iters=20)
             if best is None or ms < best[1]:
                 best = (code, ms)
