@@ -254,6 +254,14 @@ int sd_op_layernorm(const void* x, const float* weight, const float* bias, void*
 /* torch.nn.GroupNorm (+ optional SiLU) as used by unet.py:430-451,:472-481,:528-531.  NCHW f16 */
 int sd_op_groupnorm(const void* x, const float* weight, const float* bias, void* out, int B, int C, int H, int W,
                     int groups, float eps, int silu, int iters, float* ms);
+/* The two independent first steps of a ResnetBlock2D with a channel change (unet.py:470-489): norm1 (+ SiLU) over the channel concat
+ * (x0 | x1) (x1 may be NULL; the up blocks' torch.cat of unet.py:213-216) and conv_shortcut, a 1x1 conv over the same concat.
+ * side = 1: both in ONE launch (the GroupNorm's blocks and the GEMM's tiles share a grid); side = 0: two launches.  The results are
+ * bit-identical.  x0 (B,C0,H,W), x1 (B,C1,H,W) f16 NCHW, gn_weight / gn_bias (C0+C1) f32, w (N, C0+C1) f16, bias (N) f32 or NULL
+ * -> out_gn (B, C0+C1, H, W), out_sc (B, N, H, W) f16 NCHW. */
+int sd_op_groupnorm_shortcut(const void* x0, const void* x1, const float* gn_weight, const float* gn_bias, const void* w, const float* bias,
+                             void* out_gn, void* out_sc, int B, int C0, int C1, int H, int W, int N, int groups, float eps, int silu,
+                             int side, int iters, float* ms);
 /* nn.Conv2d as used by unet.py (k in {1,3}, stride in {1,2}, padding k/2), optional nearest x2
  * upsample before the conv (unet.py:498-500), optional residual add.  x (B,Cin,H,W) f16 NCHW,
  * w (Cout,Cin,k,k) f16, bias (Cout) f32 or NULL, res (B,Cout,Ho,Wo) f16 or NULL -> out f16 NCHW.

@@ -380,6 +380,59 @@ int sd_op_groupnorm(const void* x, const float* weight, const float* bias, void*
   });
 }
 
+int sd_op_groupnorm_shortcut(const void* x0, const void* x1, const float* gn_weight, const float* gn_bias, const void* w, const float* bias,
+                             void* out_gn, void* out_sc, int B, int C0, int C1, int H, int W, int N, int groups, float eps, int silu,
+                             int side, int iters, float* ms) {
+  return guarded([&] {
+    SD_REQUIRE(x0 && gn_weight && gn_bias && w && out_gn && out_sc, kInvalidArgument, "NULL argument");
+    if (!x1) C1 = 0;
+    const int C = C0 + C1;
+    Scratch sc;
+    std::vector<half_t> x0t = nchw_to_nhwc(reinterpret_cast<const half_t*>(x0), B, C0, H, W);
+    half_t* d0 = sc.dev<half_t>(x0t.size(), x0t.data());
+    half_t* d1 = nullptr;
+    if (x1) {
+      std::vector<half_t> x1t = nchw_to_nhwc(reinterpret_cast<const half_t*>(x1), B, C1, H, W);
+      d1 = sc.dev<half_t>(x1t.size(), x1t.data());
+    }
+    const size_t gn_n = (size_t)B * H * W * C, sc_n = (size_t)B * H * W * N;
+    half_t* dy = sc.dev<half_t>(gn_n);
+    half_t* ds = sc.dev<half_t>(sc_n);
+    float* dgw = sc.dev<float>(C, gn_weight);
+    float* dgb = sc.dev<float>(C, gn_bias);
+    float* partial = sc.dev<float>(groupnorm_scratch_floats(B, H * W, groups));
+    ConvDesc d;   // conv_shortcut: a 1x1 conv over the channel concat (x0 | x1), weights [N][C] as they are
+    d.x0 = d0;
+    d.C0 = C0;
+    d.x1 = d1;
+    d.C1 = C1;
+    d.w = sc.dev<half_t>((size_t)N * C, reinterpret_cast<const half_t*>(w));
+    d.bias = bias ? sc.dev<float>(N, bias) : nullptr;
+    d.out = ds;
+    d.B = B; d.Hi = H; d.Wi = W; d.Ho = H; d.Wo = W;
+    d.N = N;
+    SD_REQUIRE(conv_fast_path_ok(d), kInvalidArgument, "groupnorm_shortcut: C0=%d C1=%d N=%d not MFMA-tileable", C0, C1, N);
+    SD_REQUIRE(!side || gn_side_gemm_ok(d), kUnsupported, "groupnorm_shortcut: the GEMM cannot ride in the GroupNorm launch (M=%d)", B * H * W);
+    ConvWorkspace ws;
+    ws.partial_bytes = conv_workspace_bytes(d);
+    if (ws.partial_bytes) ws.partial = reinterpret_cast<float*>(sc.dev<char>(ws.partial_bytes));
+    sc.timed(iters, ms, [&] {
+      if (side) {
+        launch_groupnorm(d0, C0, d1, C1, partial, dgw, dgb, dy, B, H * W, groups, eps, silu, sc.stream, 0, &d);
+      } else {
+        launch_groupnorm(d0, C0, d1, C1, partial, dgw, dgb, dy, B, H * W, groups, eps, silu, sc.stream);
+        launch_conv(d, ws, sc.stream);
+      }
+    });
+    std::vector<half_t> ot(gn_n);
+    SD_HIP(hipMemcpy(ot.data(), dy, gn_n * 2, hipMemcpyDeviceToHost));
+    nhwc_to_nchw(ot.data(), reinterpret_cast<half_t*>(out_gn), B, C, H, W);
+    ot.resize(sc_n);
+    SD_HIP(hipMemcpy(ot.data(), ds, sc_n * 2, hipMemcpyDeviceToHost));
+    nhwc_to_nchw(ot.data(), reinterpret_cast<half_t*>(out_sc), B, N, H, W);
+  });
+}
+
 int sd_op_conv2d(const void* x, const void* w, const float* bias, const void* res, void* out, int B, int Cin, int H,
                  int W, int Cout, int ksize, int stride, int upsample, int tile, int splitk, int force_generic,
                  int iters, float* ms) {

@@ -162,6 +162,13 @@ __device__ __forceinline__ float xor32_sum(float v) {
   return __uint_as_float(r0) + __uint_as_float(r1);
 }
 
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+#include "gn_body.inc"   // groupnorm_apply_body / groupnorm_fused_body (the stand-alone launches are in norm.hip)
+
 // buffer_load_dwordx4 ... lds (16 bytes per lane straight into LDS; M0 carries the wave-uniform LDS base).  hipcc's HOST pass
 // checks the 16-byte form against a target without the gfx950 feature and then silently drops the enclosing kernel's stub,
 // so the builtin is only visible to the device pass.
@@ -1309,8 +1316,10 @@ __global__ __launch_bounds__(256, halo_lds_bytes(64, D) <= 80 * 1024 ? 2 : 1) vo
 // flight beside the first tiles' DMA - and each wave applies it to its activation fragments with v_pk_fma_f16 between the LDS
 // read and the MFMA: what the GroupNorm kernel would have stored as fp16 is formed in registers instead, the launch and the
 // activation round trip are gone.
+// (the body is a device function so that gn_*_side_kernel can run it beside a GroupNorm in one launch: bid_in / split are what the
+// stand-alone kernel takes from blockIdx.x / .y)
 template <int BM, int BN, int WGM, int WGN, int D, bool LNF, int DBG = 0, bool GNF = false>
-__global__ __launch_bounds__(256, D == 2 ? 2 : 1) void gemm_pipe_kernel(IgemmArgs a) {
+__device__ __forceinline__ void gemm_pipe_body(const IgemmArgs& a, int bid_in, int split) {
   static_assert(!(GNF && LNF), "one fold at a time");   // D = 2: 64 KB of LDS on the 128 x 128 tile, two workgroups per CU
   static_assert(WGM * WGN == 4, "4 waves");
   constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
@@ -1330,7 +1339,7 @@ __global__ __launch_bounds__(256, D == 2 ? 2 : 1) void gemm_pipe_kernel(IgemmArg
   const int wm = wave / WGN, wn = wave % WGN;
   const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
   const int nwg = nbm * nbn;
-  int bid = blockIdx.x;
+  int bid = bid_in;
   {   // XCD-aware order (see igemm_kernel): each XCD walks a contiguous run of tiles sharing a weight panel
     int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
@@ -1338,7 +1347,6 @@ __global__ __launch_bounds__(256, D == 2 ? 2 : 1) void gemm_pipe_kernel(IgemmArg
   }
   const int bn_idx = a.n_fast ? bid % nbn : bid / nbm, bm_idx = a.n_fast ? bid / nbn : bid % nbm;
   const int m_blk = bm_idx * BM, n_blk = bn_idx * BN;
-  const int split = blockIdx.y;
   const int kt_begin = split * a.nk_per_split;
   int kt_end = kt_begin + a.nk_per_split;
   if (kt_end > a.nk_total) kt_end = a.nk_total;
@@ -1612,6 +1620,58 @@ __global__ __launch_bounds__(256, D == 2 ? 2 : 1) void gemm_pipe_kernel(IgemmArg
   }
   tile_epilogue<BM, BN, WGM, WGN, TM, TN, LNF, (RES_PRE ? RIT : 0)>(a, acc, ln_a, ln_b, smem, sconst, const_b, const_t, const_c, m_blk,
                                                                     n_blk, wave, split, temb_uniform, resv, use_resv);
+}
+
+template <int BM, int BN, int WGM, int WGN, int D, bool LNF, int DBG = 0, bool GNF = false>
+__global__ __launch_bounds__(256, D == 2 ? 2 : 1) void gemm_pipe_kernel(IgemmArgs a) {
+  gemm_pipe_body<BM, BN, WGM, WGN, D, LNF, DBG, GNF>(a, blockIdx.x, blockIdx.y);
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm and an INDEPENDENT 1x1 GEMM side by side in one launch (round 5).  A resnet with a channel change (unet.py:470-489)
+// runs norm1 -> conv1 -> norm2 -> conv2 on one chain and conv_shortcut(x) on another that meets it in conv2's residual add; as
+// separate launches the 14 shortcut GEMMs of the SD2.1 step cost 10-20 us each and the norm1 launches beside them 8-23 us, each
+// on a fraction of the chip (the single-launch GroupNorm runs on 64 workgroups, the shortcut GEMM at M = 512 on 160).  A side
+// stream inside the captured graph costs more than it hides (round 4: fork / join pairs, +3.8 %).  Here ONE grid holds both:
+// blocks [0, n_gn) run the GroupNorm body (gn_body.inc, the code of the stand-alone launch), blocks [n_gn_pad, ...) the pipelined
+// GEMM body on the same input tensors (second reader: L2 / Infinity Cache hits).  No dependence between the two halves, no extra
+// synchronisation; the consumer of both (conv1 / conv2) is a later launch as before.
+// ---------------------------------------------------------------------------------------------
+struct GnSideArgs {
+  const half_t* x0;
+  const half_t* x1;
+  int C0, C1;
+  const float* partial;
+  int slabs;            // apply: entries to fold
+  const float* gamma;
+  const float* beta;
+  half_t* y;
+  int HW, G;
+  float eps;
+  int silu, pix_per_block;
+  int gx, gy;           // the GroupNorm's own grid
+  int n_gn_pad;         // first block of the GEMM half (n_gn rounded up to a multiple of 8: keeps the GEMM's XCD mapping)
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void gn_apply_side_kernel(GnSideArgs g, IgemmArgs a) {
+  const int v = blockIdx.x;
+  if (v < g.gx * g.gy) {
+    groupnorm_apply_body(g.x0, g.C0, g.x1, g.C1, g.partial, g.slabs, g.gamma, g.beta, g.y, g.HW, g.G, g.eps, g.silu, g.pix_per_block,
+                         v % g.gx, v / g.gx);
+  } else if (v >= g.n_gn_pad) {
+    gemm_pipe_body<64, 64, 2, 2, D, false>(a, v - g.n_gn_pad, 0);
+  }
+}
+
+template <int VW, int D>
+__global__ __launch_bounds__(256) void gn_fused_side_kernel(GnSideArgs g, IgemmArgs a) {
+  const int v = blockIdx.x;
+  if (v < g.gx * g.gy) {
+    groupnorm_fused_body<VW, 256>(g.x0, g.C0, g.x1, g.C1, g.gamma, g.beta, g.y, g.HW, g.G, g.eps, g.silu, v % g.gx, v / g.gx);
+  } else if (v >= g.n_gn_pad) {
+    gemm_pipe_body<64, 64, 2, 2, D, false>(a, v - g.n_gn_pad, 0);
+  }
 }
 
 // split-K combine + the same epilogue (bias, temb broadcast, residual) -> fp16
@@ -2540,6 +2600,28 @@ int launch_slab_combine(const ConvDesc& d, IgemmArgs& a, hipStream_t s) {
 }
 }  // namespace
 
+namespace {
+// tile order (IgemmArgs::n_fast) from an estimate of the bytes each order pulls through the fabric into the 8 XCD L2s:
+//   m fastest: every weight panel once; the activations once per XCD when they fit an L2, else once per n-tile
+//   n fastest: the activations once; the weights once per XCD when they fit an L2, else once per m-tile
+// (SD_TILE_ORDER=2: round 3's first rule, activations x (n-tiles - 1) > 7 x weights - same step time at batch 2, but it
+// sent the 1280 -> 1280 GEMMs of the 16x16 level n-fast: 27 MB of fabric reads per launch for 4.6 MB of operands)
+void choose_tile_order(IgemmArgs& a, int tile) {
+  int bm, bn;
+  tile_dims(tile, bm, bn);
+  const bool halo_tile = tile == 7;
+  const double nbn = (double)cdiv(a.N, bn);
+  const double nbm = halo_tile ? (double)a.B * a.tiles_x * a.tiles_y : (double)cdiv(a.M, bm);
+  const double a_bytes = 2.0 * a.B * a.Hi * a.Wi * a.Ctot, w_bytes = 2.0 * a.N * a.K;
+  const double l2 = 3.5e6;   // what one 4-MB L2 keeps of an operand next to the other one's stream
+  const double m_fast_cost = w_bytes + a_bytes * (a_bytes <= l2 ? std::min(8.0, nbn) : nbn);
+  const double n_fast_cost = a_bytes + w_bytes * (w_bytes <= l2 ? std::min(8.0, nbm) : nbm);
+  static const int forced = tune_env_int("SD_TILE_ORDER", -1);   // A/B switch: 0 / 1 / 2
+  if (forced == 2) a.n_fast = nbn > 1 && a_bytes * (nbn - 1) > 7.0 * w_bytes;
+  else a.n_fast = forced >= 0 ? (forced != 0) : (nbn > 1 && n_fast_cost < m_fast_cost);
+}
+}  // namespace
+
 int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
   SD_REQUIRE(conv_fast_path_ok(d), kInvalidArgument, "launch_conv: shape not MFMA-tileable (C0=%d C1=%d N=%d k=%d)",
              d.C0, d.C1, d.N, d.ksize);
@@ -2603,24 +2685,7 @@ int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
   }
   const bool trans = d.out_mode == kOutHalfT;
   const int st = p.staging;
-  {   // tile order (IgemmArgs::n_fast) from an estimate of the bytes each order pulls through the fabric into the 8 XCD L2s:
-      //   m fastest: every weight panel once; the activations once per XCD when they fit an L2, else once per n-tile
-      //   n fastest: the activations once; the weights once per XCD when they fit an L2, else once per m-tile
-      // (SD_TILE_ORDER=2: round 3's first rule, activations x (n-tiles - 1) > 7 x weights - same step time at batch 2, but it
-      // sent the 1280 -> 1280 GEMMs of the 16x16 level n-fast: 27 MB of fabric reads per launch for 4.6 MB of operands)
-    int bm, bn;
-    tile_dims(p.tile, bm, bn);
-    const bool halo_tile = p.tile == 7;
-    const double nbn = (double)cdiv(a.N, bn);
-    const double nbm = halo_tile ? (double)a.B * a.tiles_x * a.tiles_y : (double)cdiv(a.M, bm);
-    const double a_bytes = 2.0 * a.B * a.Hi * a.Wi * a.Ctot, w_bytes = 2.0 * a.N * a.K;
-    const double l2 = 3.5e6;   // what one 4-MB L2 keeps of an operand next to the other one's stream
-    const double m_fast_cost = w_bytes + a_bytes * (a_bytes <= l2 ? std::min(8.0, nbn) : nbn);
-    const double n_fast_cost = a_bytes + w_bytes * (w_bytes <= l2 ? std::min(8.0, nbm) : nbm);
-    static const int forced = tune_env_int("SD_TILE_ORDER", -1);   // A/B switch: 0 / 1 / 2
-    if (forced == 2) a.n_fast = nbn > 1 && a_bytes * (nbn - 1) > 7.0 * w_bytes;
-    else a.n_fast = forced >= 0 ? (forced != 0) : (nbn > 1 && n_fast_cost < m_fast_cost);
-  }
+  choose_tile_order(a, p.tile);
   static const bool log_plans = tune_env_set("SD_LOG_CONVS");
   if (log_plans)
     fprintf(stderr, "[sd conv] k%d s%d up%d C0=%d C1=%d M=%d N=%d K=%d mode=%d tile=%d splitk=%d\n", a.ksize, a.stride, a.up,
@@ -2653,6 +2718,64 @@ int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
   }
   SD_HIP(hipGetLastError());
   return gn_entries;
+}
+
+// ---- GroupNorm + independent 1x1 GEMM in one launch (gn_*_side_kernel) ----
+bool gn_side_gemm_ok(const ConvDesc& d) {
+  if (!(d.ksize == 1 && d.stride == 1 && d.up == 1 && d.out_mode == kOutHalf && !d.ln_colsum && !d.out_t && d.n_twins == 0 && !d.gnf_partial &&
+        !d.gn_partial && !d.temb && !d.debug && conv_fast_path_ok(d)))
+    return false;
+  const IgemmArgs a = make_args(d);
+  return gemm_pipe_ok(a) && a.M >= 256;   // (M = 128: the 8x8 level's shortcut GEMMs are split-K weight streams, a 40-workgroup side GEMM loses)
+}
+
+namespace {
+constexpr int kSideD = 4;   // ring depth of the side GEMM: 64 KB + constants, the plan most shortcut shapes have stand-alone
+IgemmArgs side_args(const ConvDesc& d) {
+  SD_REQUIRE(gn_side_gemm_ok(d), kInvalidArgument, "side GEMM: not a plain 1x1 GEMM of the pipelined kernel (C0=%d C1=%d N=%d)", d.C0, d.C1, d.N);
+  IgemmArgs a = make_args(d);
+  a.splitk = 1;
+  a.slab = 0;
+  choose_tile_order(a, 3);
+  return a;
+}
+constexpr size_t kSideLds = (size_t)kSideD * (64 + 64) * BK * sizeof(half_t) + 2 * 64 * sizeof(float);
+}  // namespace
+
+void launch_gn_apply_side(const half_t* x0, int C0, const half_t* x1, int C1, const float* partial, int entries, const float* gamma,
+                          const float* beta, half_t* y, int B, int HW, int G, float eps, int silu, int slabs, int ppb, const ConvDesc& side,
+                          hipStream_t s) {
+  IgemmArgs a = side_args(side);
+  GnSideArgs g{x0, x1, C0, x1 ? C1 : 0, partial, entries, gamma, beta, y, HW, G, eps, silu, ppb, slabs, B, 0};
+  g.n_gn_pad = (slabs * B + 7) / 8 * 8;
+  auto k = gn_apply_side_kernel<kSideD>;
+  static DynLdsOnce once;
+  once.set(k, kSideLds);
+  hipLaunchKernelGGL(k, dim3(g.n_gn_pad + cdiv(a.M, 64) * cdiv(a.N, 64)), dim3(256), kSideLds, s, g, a);
+  SD_HIP(hipGetLastError());
+}
+
+void launch_gn_fused_side(int vw, const half_t* x0, int C0, const half_t* x1, int C1, const float* gamma, const float* beta, half_t* y, int B,
+                          int HW, int G, float eps, int silu, const ConvDesc& side, hipStream_t s) {
+  IgemmArgs a = side_args(side);
+  GnSideArgs g{x0, x1, C0, x1 ? C1 : 0, nullptr, 0, gamma, beta, y, HW, G, eps, silu, 0, G, B, 0};
+  g.n_gn_pad = (G * B + 7) / 8 * 8;
+  const dim3 grid(g.n_gn_pad + cdiv(a.M, 64) * cdiv(a.N, 64));
+  static DynLdsOnce o8, o4, o2;
+  if (vw == 8) {
+    auto k = gn_fused_side_kernel<8, kSideD>;
+    o8.set(k, kSideLds);
+    hipLaunchKernelGGL(k, grid, dim3(256), kSideLds, s, g, a);
+  } else if (vw == 4) {
+    auto k = gn_fused_side_kernel<4, kSideD>;
+    o4.set(k, kSideLds);
+    hipLaunchKernelGGL(k, grid, dim3(256), kSideLds, s, g, a);
+  } else {
+    auto k = gn_fused_side_kernel<2, kSideD>;
+    o2.set(k, kSideLds);
+    hipLaunchKernelGGL(k, grid, dim3(256), kSideLds, s, g, a);
+  }
+  SD_HIP(hipGetLastError());
 }
 
 int launch_conv_generic(const ConvDesc& d, int act_silu_out, hipStream_t s) {

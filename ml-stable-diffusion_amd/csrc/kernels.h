@@ -192,7 +192,16 @@ size_t groupnorm_scratch_floats(int B, int HW, int G);
 // epilogue of the kernel that produced x0 (ConvDesc::gn_partial) - the statistics pass is skipped.
 void launch_groupnorm(const half_t* x0, int C0, const half_t* x1, int C1, float* partial, const float* gamma,
                       const float* beta, half_t* y, int B, int HW, int G, float eps, int silu, hipStream_t s,
-                      int producer_entries = 0);
+                      int producer_entries = 0, const ConvDesc* side = nullptr);
+// `side` (round 5): an INDEPENDENT 1x1 GEMM - the resnet's conv_shortcut over the same input (unet.py:483-486) - that runs in the
+// SAME launch as the GroupNorm's apply / single-launch kernel (igemm.hip gn_*_side_kernel: one grid, the first blocks are the
+// GroupNorm, the rest the GEMM's tiles).  Must satisfy gn_side_gemm_ok; its result is complete when the launch is.
+bool gn_side_gemm_ok(const ConvDesc& d);
+void launch_gn_apply_side(const half_t* x0, int C0, const half_t* x1, int C1, const float* partial, int entries, const float* gamma,
+                          const float* beta, half_t* y, int B, int HW, int G, float eps, int silu, int slabs, int ppb, const ConvDesc& side,
+                          hipStream_t s);
+void launch_gn_fused_side(int vw, const half_t* x0, int C0, const half_t* x1, int C1, const float* gamma, const float* beta, half_t* y, int B,
+                          int HW, int G, float eps, int silu, const ConvDesc& side, hipStream_t s);
 // true when a GroupNorm of this shape would run a separate statistics launch, i.e. producer statistics pay
 bool groupnorm_wants_producer_stats(int HW, int C, int G);
 

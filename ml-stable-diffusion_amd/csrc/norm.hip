@@ -161,222 +161,25 @@ __global__ __launch_bounds__(256) void groupnorm_partial_kernel(const half_t* __
   }
 }
 
-// Pass 2, grid (pixel slabs, B): every block first folds the per-slab partials of its sample in a
-// fixed order (4 or 8 lanes per group + shuffles: deterministic), turns them into per-channel
-// scale/shift held in registers, then streams its pixel slab: one 16-B load, 8 FMAs (+SiLU), one
-// 16-B store per thread-iteration.  Fusing the fold here saves a dependent launch per GroupNorm.
-// Everything that does not depend on the statistics - gamma / beta of the thread's channels and its first
-// four pixels - is requested BEFORE the fold, so the kernel pays one memory round trip, not three in a row
-// (partials -> affine -> data; a UNet step has 31 of these launches and each is latency-, not bandwidth-bound).
+// Pass 2 / single-launch GroupNorm: the bodies live in gn_body.inc (shared with igemm.hip's side-by-side launches)
+#include "gn_body.inc"
+
 __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const half_t* __restrict__ x0, int C0,
                                                               const half_t* __restrict__ x1, int C1,
                                                               const float* __restrict__ partial, int slabs,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, half_t* __restrict__ y,
                                                               int HW, int G, float eps, int silu, int pix_per_block) {
-  __shared__ float s_mean[64], s_rstd[64];
-  const int C = C0 + C1;
-  const int ncol = C >> 3;
-  const int cpg = C / G;
-  const int b = blockIdx.y;
-  const int t = threadIdx.x;
-  const int p0 = blockIdx.x * pix_per_block;
-  const int p1 = min(p0 + pix_per_block, HW);
-  // ---- first column block: coordinates + the loads that do not wait for the statistics ----
-  const int cols0 = min(256, ncol);
-  const int rows0 = 256 / cols0;
-  const int c_first = (t % cols0) * 8;
-  const int r_first = t / cols0;
-  const bool act0 = r_first < rows0;
-  floatx4 g_lo = {0.f, 0.f, 0.f, 0.f}, g_hi = g_lo, b_lo = g_lo, b_hi = g_lo;
-  half8 pre[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) pre[u] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-  if (act0) {
-    g_lo = *reinterpret_cast<const floatx4*>(gamma + c_first);
-    g_hi = *reinterpret_cast<const floatx4*>(gamma + c_first + 4);
-    b_lo = *reinterpret_cast<const floatx4*>(beta + c_first);
-    b_hi = *reinterpret_cast<const floatx4*>(beta + c_first + 4);
-    const half_t* src = (c_first < C0) ? x0 + c_first : x1 + (c_first - C0);
-    const int Cs = (c_first < C0) ? C0 : C1;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int pp = p0 + r_first + u * rows0;
-      if (pp < p1) pre[u] = *reinterpret_cast<const half8*>(src + ((size_t)b * HW + pp) * Cs);
-    }
-  }
-  {
-    // fold the entries: LPG lanes per group, each sums a contiguous run of kGnMaxSlabs/LPG entries (those at or
-    // beyond `slabs` count as zero) loaded as independent float4s, then a fixed-order shuffle tree.
-    const int LPG = (G <= 32) ? 8 : 4;
-    const int g = t / LPG, j = t % LPG;
-    const int per = kGnMaxSlabs / LPG;                 // 32 or 64 entries = 16 or 32 float4
-    float s = 0.f, q = 0.f;
-    if (g < G) {
-      const floatx4* src = reinterpret_cast<const floatx4*>(partial + (((size_t)b * G + g) * kGnMaxSlabs + j * per) * 2);
-      for (int k0 = 0; k0 < per / 2; k0 += 16) {       // (block-uniform trip count)
-        if (j * per + 2 * k0 >= slabs) break;          // nothing but masked entries from here on
-        floatx4 v[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          const int e0 = j * per + 2 * (k0 + k);       // first of the two entries of this float4
-          v[k] = (e0 < slabs) ? src[k0 + k] : floatx4{0.f, 0.f, 0.f, 0.f};
-          if (e0 + 1 >= slabs) {
-            v[k][2] = 0.f;
-            v[k][3] = 0.f;
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          s += v[k][0] + v[k][2];
-          q += v[k][1] + v[k][3];
-        }
-      }
-    }
-    for (int o = 1; o < LPG; o <<= 1) {
-      s += __shfl_xor(s, o);
-      q += __shfl_xor(q, o);
-    }
-    if (g < G && j == 0) {
-      const float inv_n = 1.0f / ((float)cpg * (float)HW);
-      const float mean = s * inv_n;
-      const float var = fmaxf(q * inv_n - mean * mean, 0.f);
-      s_mean[g] = mean;
-      s_rstd[g] = rsqrtf(var + eps);
-    }
-  }
-  __syncthreads();
-  auto apply_store = [&](const half8& h, const float (&sc)[8], const float (&sh)[8], int pp, int c) {
-    half8 o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float v = (float)h[e] * sc[e] + sh[e];
-      if (silu) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
-      o[e] = (half_t)v;
-    }
-    *reinterpret_cast<half8*>(y + ((size_t)b * HW + pp) * C + c) = o;
-  };
-  for (int cb = 0; cb < ncol; cb += 256) {
-    const int cols = min(256, ncol - cb);
-    const int rows = 256 / cols;
-    const int col = cb + t % cols;
-    const int r0 = t / cols;
-    if (r0 >= rows) continue;
-    const int c = col * 8;
-    float sc[8], sh[8];
-    if (cb == 0) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int g = (c + e) / cpg;
-        sc[e] = s_rstd[g] * (e < 4 ? g_lo[e & 3] : g_hi[e & 3]);
-        sh[e] = (e < 4 ? b_lo[e & 3] : b_hi[e & 3]) - s_mean[g] * sc[e];
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int g = (c + e) / cpg;
-        sc[e] = s_rstd[g] * gamma[c + e];
-        sh[e] = beta[c + e] - s_mean[g] * sc[e];
-      }
-    }
-    const half_t* src = (c < C0) ? x0 + c : x1 + (c - C0);
-    const int Cs = (c < C0) ? C0 : C1;
-    int p = p0 + r0;
-    if (cb == 0) {                                     // the four pixels requested before the fold
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int pp = p + u * rows;
-        if (pp < p1) apply_store(pre[u], sc, sh, pp, c);
-      }
-      p += 4 * rows;
-    }
-    for (; p < p1; p += 4 * rows) {
-      half8 h[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int pp = p + u * rows;
-        if (pp < p1) h[u] = *reinterpret_cast<const half8*>(src + ((size_t)b * HW + pp) * Cs);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int pp = p + u * rows;
-        if (pp < p1) apply_store(h[u], sc, sh, pp, c);
-      }
-    }
-  }
+  groupnorm_apply_body(x0, C0, x1, C1, partial, slabs, gamma, beta, y, HW, G, eps, silu, pix_per_block, blockIdx.x, blockIdx.y);
 }
 
-// Single-launch GroupNorm for the UNet-sized tensors (<= 128K elements per (sample, group)): one
-// workgroup per (group, sample) reads its strided channel slice twice (second pass from L2): fixed-order
-// reduction, then affine (+SiLU) and the concatenated store.  Replaces the two dependent launches of
-// the slab version - a UNet step is launch-latency-bound on its ~60 GroupNorms (~4 us per dependent
-// launch), not bandwidth-bound.  VW = halves per vector access (alignment of the group's channel run).
-template <int VW, int NT = 256>   // NT threads per (group, sample): 1024 for the 32x32 level (one launch instead of two, 16 waves per slice)
+template <int VW, int NT = 256>
 __global__ __launch_bounds__(NT) void groupnorm_fused_kernel(const half_t* __restrict__ x0, int C0,
                                                               const half_t* __restrict__ x1, int C1,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, half_t* __restrict__ y,
                                                               int HW, int G, float eps, int silu) {
-  typedef _Float16 vec_t __attribute__((ext_vector_type(VW)));
-  __shared__ float red[2 * (NT / 64)];
-  __shared__ float s_sc[128], s_sh[128];
-  const int C = C0 + C1;
-  const int cpg = C / G;
-  const int g = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
-  const int c0 = g * cpg;
-  const int nv = cpg / VW;                       // vectors per pixel
-  const int items = HW * nv;
-  float s = 0.f, q = 0.f;
-  for (int it = t; it < items; it += NT) {
-    const int p = it / nv, v = it - p * nv;
-    const int c = c0 + v * VW;
-    const half_t* src = (c < C0) ? x0 + ((size_t)b * HW + p) * C0 + c : x1 + ((size_t)b * HW + p) * C1 + (c - C0);
-    const vec_t h = *reinterpret_cast<const vec_t*>(src);
-#pragma unroll
-    for (int e = 0; e < VW; ++e) {
-      const float f = (float)h[e];
-      s += f;
-      q += f * f;
-    }
-  }
-  s = wave_sum(s);
-  q = wave_sum(q);
-  constexpr int NW = NT / 64;
-  if ((t & 63) == 0) {
-    red[t >> 6] = s;
-    red[NW + (t >> 6)] = q;
-  }
-  __syncthreads();
-  s = 0.f;
-  q = 0.f;
-#pragma unroll
-  for (int w = 0; w < NW; w += 4) {   // fixed order: deterministic
-    s += (red[w] + red[w + 1]) + (red[w + 2] + red[w + 3]);
-    q += (red[NW + w] + red[NW + w + 1]) + (red[NW + w + 2] + red[NW + w + 3]);
-  }
-  const float inv_n = 1.0f / ((float)cpg * (float)HW);
-  const float mean = s * inv_n;
-  const float rstd = rsqrtf(fmaxf(q * inv_n - mean * mean, 0.f) + eps);
-  if (t < cpg) {
-    const float sc = rstd * gamma[c0 + t];
-    s_sc[t] = sc;
-    s_sh[t] = beta[c0 + t] - mean * sc;
-  }
-  __syncthreads();
-  for (int it = t; it < items; it += NT) {
-    const int p = it / nv, v = it - p * nv;
-    const int c = c0 + v * VW;
-    const half_t* src = (c < C0) ? x0 + ((size_t)b * HW + p) * C0 + c : x1 + ((size_t)b * HW + p) * C1 + (c - C0);
-    const vec_t h = *reinterpret_cast<const vec_t*>(src);
-    vec_t o;
-#pragma unroll
-    for (int e = 0; e < VW; ++e) {
-      float f = (float)h[e] * s_sc[v * VW + e] + s_sh[v * VW + e];
-      if (silu) f = f * __builtin_amdgcn_rcpf(1.0f + __expf(-f));
-      o[e] = (half_t)f;
-    }
-    *reinterpret_cast<vec_t*>(y + ((size_t)b * HW + p) * C + c) = o;
-  }
+  groupnorm_fused_body<VW, NT>(x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu, blockIdx.x, blockIdx.y);
 }
 
 // One workgroup per row: row kept in registers (cols <= 256 threads * 4 chunks * 8), fp32 max / sum
@@ -478,7 +281,7 @@ size_t groupnorm_scratch_floats(int B, int HW, int G) { return (size_t)B * G * k
 
 void launch_groupnorm(const half_t* x0, int C0, const half_t* x1, int C1, float* partial, const float* gamma,
                       const float* beta, half_t* y, int B, int HW, int G, float eps, int silu, hipStream_t s,
-                      int producer_entries) {
+                      int producer_entries, const ConvDesc* side) {
   if (!x1) C1 = 0;
   const int C = C0 + C1;
   SD_REQUIRE(C % G == 0 && C0 % 8 == 0 && C1 % 8 == 0 && G <= 64, kUnsupported, "groupnorm: C0=%d C1=%d G=%d", C0, C1, G);
@@ -489,6 +292,10 @@ void launch_groupnorm(const half_t* x0, int C0, const half_t* x1, int C1, float*
     int slabs = std::max(1, std::min(std::max(1, 512 / std::max(1, B)), std::max(1, HW / 8)));
     const int ppb = cdiv(HW, slabs);
     slabs = cdiv(HW, ppb);
+    if (side) {   // the apply pass and the independent GEMM in one grid
+      launch_gn_apply_side(x0, C0, x1, C1, partial, producer_entries, gamma, beta, y, B, HW, G, eps, silu, slabs, ppb, *side, s);
+      return;
+    }
     hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(slabs, B), dim3(256), 0, s, x0, C0, x1, C1, partial, producer_entries, gamma,
                        beta, y, HW, G, eps, silu, ppb);
     SD_HIP(hipGetLastError());
@@ -497,6 +304,10 @@ void launch_groupnorm(const half_t* x0, int C0, const half_t* x1, int C1, float*
   const long fused_max_hw = gn_fused_max_hw();
   if (HW <= fused_max_hw && cpg <= 128 && cpg % 2 == 0) {
     dim3 grid(G, B);
+    if (side) {   // the single-launch GroupNorm (64 workgroups) and the independent GEMM in one grid
+      launch_gn_fused_side(cpg % 8 == 0 ? 8 : (cpg % 4 == 0 ? 4 : 2), x0, C0, x1, C1, gamma, beta, y, B, HW, G, eps, silu, *side, s);
+      return;
+    }
     if (cpg % 8 == 0)
       hipLaunchKernelGGL(groupnorm_fused_kernel<8>, grid, dim3(256), 0, s, x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu);
     else if (cpg % 4 == 0)
@@ -509,7 +320,7 @@ void launch_groupnorm(const half_t* x0, int C0, const half_t* x1, int C1, float*
   // 32x32 level: one 1024-thread workgroup per (group, sample) instead of the slab pair (in sequence a dependent launch costs
   // more than the second pass over a slice that is still in L2); SD_GN_WIDE=0 switches it off (A/B)
   static const bool wide = tune_env_int("SD_GN_WIDE", 1) != 0;
-  if (wide && HW <= 1024 && cpg >= 16 && cpg <= 48 && cpg % 4 == 0) {   // (60-channel groups measured slower: 20.8 vs 16.0 us)
+  if (wide && !side && HW <= 1024 && cpg >= 16 && cpg <= 48 && cpg % 4 == 0) {   // (1024-thread blocks: no side GEMM there)   // (60-channel groups measured slower: 20.8 vs 16.0 us)
     dim3 grid(G, B);
     if (cpg % 8 == 0)
       hipLaunchKernelGGL((groupnorm_fused_kernel<8, 1024>), grid, dim3(1024), 0, s, x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu);
@@ -522,6 +333,10 @@ void launch_groupnorm(const half_t* x0, int C0, const half_t* x1, int C1, float*
   const int ppb = cdiv(HW, slabs);
   slabs = cdiv(HW, ppb);   // <= groupnorm_num_slabs
   hipLaunchKernelGGL(groupnorm_partial_kernel, dim3(slabs, B), dim3(256), 0, s, x0, C0, x1, C1, partial, HW, G, ppb);
+  if (side) {
+    launch_gn_apply_side(x0, C0, x1, C1, partial, slabs, gamma, beta, y, B, HW, G, eps, silu, slabs, ppb, *side, s);
+    return;
+  }
   hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(slabs, B), dim3(256), 0, s, x0, C0, x1, C1, partial, slabs, gamma, beta,
                      y, HW, G, eps, silu, ppb);
   SD_HIP(hipGetLastError());

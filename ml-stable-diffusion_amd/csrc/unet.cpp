@@ -371,7 +371,8 @@ Tensor UNet::conv_w(std::vector<Op>& ops, const std::string& name, const half_t*
 }
 
 Tensor UNet::group_norm(std::vector<Op>& ops, const std::string& name, const Tensor& x, const Tensor* x2, float eps,
-                        bool silu) {
+                        bool silu, const ConvDesc* side, const std::string& side_label, double side_flop) {
+  SD_REQUIRE(!side || !f32_, kInternal, "%s: side GEMM on the fp32 path", name.c_str());
   const int C = x.C + (x2 ? x2->C : 0);
   const int G = cfg_.norm_num_groups;
   SD_REQUIRE(C % G == 0, kUnsupported, "%s: %d channels not divisible by %d groups", name.c_str(), C, G);
@@ -398,7 +399,7 @@ Tensor UNet::group_norm(std::vector<Op>& ops, const std::string& name, const Ten
     static const int twin_mode = tune_env_int("SD_GN_TWIN", 0);   // measured and rejected: off unless asked for
     const int cpg = C / G;
     const Tensor* srcs[2] = {&x, x2};
-    bool ok = twin_mode != 0 && x.H * x.W <= 256 && cpg % 4 == 0 && (!x2 || x.C % cpg == 0);
+    bool ok = twin_mode != 0 && !side && x.H * x.W <= 256 && cpg % 4 == 0 && (!x2 || x.C % cpg == 0);
     for (int i = 0; i < 2 && ok; ++i) {
       const Tensor* t = srcs[i];
       if (!t) continue;
@@ -450,6 +451,15 @@ Tensor UNet::group_norm(std::vector<Op>& ops, const std::string& name, const Ten
     hook->partial = partial;
     hook->groups = G;
   }
+  if (side) {
+    const ConvDesc sd = *side;
+    ops.push_back([=](hipStream_t s) {
+      launch_groupnorm(p0, C0, p1, C1, partial, gamma, beta, yp, B, HW, G, eps, si, s, hook ? hook->entries : 0, &sd);
+    });
+    ops.back().label = "groupnorm C=" + std::to_string(C) + " @" + std::to_string(x.H) + "x" + std::to_string(x.W) + " " + name + " || " + side_label;
+    ops.back().flop = side_flop;
+    return y;
+  }
   ops.push_back([=](hipStream_t s) {
     launch_groupnorm(p0, C0, p1, C1, partial, gamma, beta, yp, B, HW, G, eps, si, s, hook ? hook->entries : 0);
   });
@@ -482,13 +492,44 @@ const float* UNet::register_temb(const std::string& name, int cout) {
 Tensor UNet::resnet(std::vector<Op>& ops, const std::string& p, const Tensor& x, const Tensor* x2, int cout,
                     bool has_temb) {
   const int cin = x.C + (x2 ? x2->C : 0);
-  Tensor t0 = group_norm(ops, p + ".norm1", x, x2, cfg_.norm_eps, true);
+  // conv_shortcut(x) does not depend on norm1 -> conv1 -> norm2: it rides in norm1's launch (one grid: the GroupNorm's blocks, then
+  // the GEMM's tiles - igemm.hip gn_*_side_kernel) instead of a launch of its own.  SD_GN_SIDE=0 (with SD_TUNE): separate launches (A/B).
+  static const int side_mode = tune_env_int("SD_GN_SIDE", 1);
+  static const int twin_mode = tune_env_int("SD_GN_TWIN", 0);
+  const half_t* side_out = nullptr;
+  Tensor t0;
+  if (cin != cout && side_mode != 0 && twin_mode == 0 && !f32_) {
+    ConvDesc sd;
+    sd.x0 = x.p;
+    sd.C0 = x.C;
+    if (x2) {
+      sd.x1 = x2->p;
+      sd.C1 = x2->C;
+    }
+    sd.B = x.B;
+    sd.Hi = sd.Ho = x.H;
+    sd.Wi = sd.Wo = x.W;
+    sd.N = cout;
+    if (gn_side_gemm_ok(sd)) {
+      sd.w = upload_conv_weight(p + ".conv_shortcut", cout, cin, 1, false);
+      sd.bias = upload_vec(p + ".conv_shortcut.bias", cout);
+      Tensor sc = new_tensor(x.B, x.H, x.W, cout);
+      sd.out = sc.p;
+      side_out = sc.p;
+      char buf[256];
+      snprintf(buf, sizeof(buf), "gemm1x1 %d->%d @%dx%d M=%d K=%d %s.conv_shortcut", cin, cout, x.H, x.W, x.M(), cin, p.c_str());
+      t0 = group_norm(ops, p + ".norm1", x, x2, cfg_.norm_eps, true, &sd, buf, 2.0 * x.M() * (double)cout * cin);
+    }
+  }
+  if (!side_out) t0 = group_norm(ops, p + ".norm1", x, x2, cfg_.norm_eps, true);
   const float* temb = has_temb ? register_temb(p + ".time_emb_proj", cout) : nullptr;
   if (temb && temb_join_pos_ < 0 && &ops == &main_ops_) temb_join_pos_ = (int)ops.size();   // first consumer of the time path
   Tensor h = conv(ops, p + ".conv1", t0, nullptr, cout, 3, 1, 1, true, temb, nullptr);
   Tensor t1 = group_norm(ops, p + ".norm2", h, nullptr, cfg_.norm_eps, true);
   const half_t* shortcut;
-  if (cin != cout) {
+  if (side_out) {
+    shortcut = side_out;
+  } else if (cin != cout) {
     Tensor sc = conv(ops, p + ".conv_shortcut", x, x2, cout, 1, 1, 1, true, nullptr, nullptr);
     shortcut = sc.p;
   } else {

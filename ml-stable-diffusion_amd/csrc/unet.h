@@ -118,8 +118,10 @@ class UNet {
                         bool geglu);
   bool can_fold_ln(const Tensor& x, int cout, bool geglu) const;
   Tensor conv_stacked(std::vector<Op>& ops, const std::vector<std::string>& names, const Tensor& x, int cout_each);
+  // side (round 5): an independent 1x1 GEMM launched in the SAME grid as the GroupNorm's apply / single-launch kernel
+  // (launch_groupnorm); side_label / side_flop describe it in the per-op profile
   Tensor group_norm(std::vector<Op>& ops, const std::string& name, const Tensor& x, const Tensor* x2, float eps,
-                    bool silu);
+                    bool silu, const ConvDesc* side = nullptr, const std::string& side_label = std::string(), double side_flop = 0);
   Tensor layer_norm(std::vector<Op>& ops, const std::string& name, const Tensor& x);
   Tensor resnet(std::vector<Op>& ops, const std::string& p, const Tensor& x, const Tensor* x2, int cout,
                 bool has_temb = true);

@@ -91,6 +91,7 @@ SYMBOLS = [
     ("sd_op_attention", _I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _FP]),
     ("sd_op_layernorm", _I, [_P, _FP, _FP, _P, _I, _I, _I, _F, _I, _FP]),
     ("sd_op_groupnorm", _I, [_P, _FP, _FP, _P, _I, _I, _I, _I, _I, _F, _I, _I, _FP]),
+    ("sd_op_groupnorm_shortcut", _I, [_P, _P, _FP, _FP, _P, _FP, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _FP]),
     ("sd_op_conv2d", _I, [_P, _P, _FP, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _FP]),
     ("sd_op_conv2d_groupnorm", _I, [_P, _P, _FP, _P, _FP, _FP, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, C.POINTER(_I), _I, _FP]),
     ("sd_op_conv2d_groupnorm_proj", _I, [_P, _P, _FP, _P, _FP, _FP, _P, _FP, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, C.POINTER(_I), _I, _FP]),
@@ -209,6 +210,27 @@ def conv2d(x, w, bias=None, res=None, stride=1, upsample=False, tile=0, splitk=0
     check(lib().sd_op_conv2d(ptr(x), ptr(w), fptr(bias), ptr(res), ptr(out), B, Cin, H, W, Cout, k, stride,
                              int(upsample), tile, splitk, int(force_generic), iters, C.byref(ms)))
     return out, ms.value
+
+
+def groupnorm_shortcut(x0, x1, gn_weight, gn_bias, w, bias=None, groups=32, eps=1e-5, silu=True, side=True, iters=1):
+    """norm1 (+SiLU) over the concat (x0 | x1) and conv_shortcut (1x1) over the same concat; side=True: one launch.
+    Returns (normalised tensor, shortcut output, ms)."""
+    x0, w = f16(x0), f16(w)
+    x1 = None if x1 is None else f16(x1)
+    B, C0, H, W = x0.shape
+    C1 = 0 if x1 is None else x1.shape[1]
+    N = w.shape[0]
+    w = np.ascontiguousarray(w.reshape(N, -1))
+    if w.shape[1] != C0 + C1 or (x1 is not None and x1.shape != (B, C1, H, W)):
+        raise ValueError("groupnorm_shortcut: inconsistent shapes")
+    gn_weight, gn_bias = f32(gn_weight), f32(gn_bias)
+    bias = None if bias is None else f32(bias)
+    out_gn = np.empty((B, C0 + C1, H, W), np.float16)
+    out_sc = np.empty((B, N, H, W), np.float16)
+    ms = C.c_float(0)
+    check(lib().sd_op_groupnorm_shortcut(ptr(x0), ptr(x1), fptr(gn_weight), fptr(gn_bias), ptr(w), fptr(bias), ptr(out_gn), ptr(out_sc),
+                                         B, C0, C1, H, W, N, groups, eps, int(silu), int(side), iters, C.byref(ms)))
+    return out_gn, out_sc, ms.value
 
 
 def conv2d_groupnorm(x, w, gn_weight, gn_bias, bias=None, res=None, groups=32, eps=1e-5, silu=False, tile=0,

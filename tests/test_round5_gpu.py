@@ -364,3 +364,52 @@ def test_vae_decoder_matches_the_reference_block_golden_at_the_benchmarked_size(
     p = psnr.compute_psnr(out, ref)
     assert out.shape == ref.shape == (1, 3, 512, 512) and p >= 60.0, f"VAE decoder @64x64: PSNR {p:.1f} dB vs the reference-block golden"
     vae.close()
+
+
+# ---------------------------------------------------------------- norm1 and conv_shortcut in one launch (gn_*_side_kernel)
+SIDE_CASES = [  # (B, C0, C1, H, N): the resnets with a channel change, unet.py:470-489
+    (2, 1280, 1280, 16, 1280),   # up_blocks.1.resnets.0 at full size: single-launch GroupNorm (64 workgroups) + 160 GEMM tiles
+    (2, 1280, 640, 16, 1280),    # 1920 channels: 60 per group (vector width 4)
+    (2, 640, 320, 32, 640),      # up_blocks.2.resnets.2: partial + apply pair, the GEMM rides in the apply launch; 30 per group (width 2)
+    (2, 320, 320, 64, 320),      # up_blocks.3.resnets.1 at full size
+    (2, 640, 0, 16, 1280),       # down_blocks.2.resnets.0: single source
+    (1, 128, 64, 16, 64),        # one sample, M = 256: the smallest side GEMM
+    (3, 64, 64, 24, 192),        # odd batch, ragged M tiles (M = 1728), groups of 4
+]
+
+
+@pytest.mark.parametrize("case", SIDE_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_groupnorm_and_shortcut_gemm_in_one_launch(case):
+    """The GroupNorm's blocks and the shortcut GEMM's tiles in one grid: both results bit-identical to the two separate launches of
+    the same kernels' code paths where they exist, and equal to torch (GroupNorm(32) + SiLU over the concat; 1x1 conv over the concat)."""
+    b, c0, c1, hw, n = case
+    rs = np.random.RandomState(c0 + c1 + hw + n)
+    x0 = h16(rs.randn(b, c0, hw, hw))
+    x1 = h16(rs.randn(b, c1, hw, hw) * 1.5 + 0.3) if c1 else None
+    c = c0 + c1
+    gw = (1.0 + 0.2 * rs.randn(c)).astype(np.float32)
+    gb = (0.2 * rs.randn(c)).astype(np.float32)
+    w = h16(rs.randn(n, c) / np.sqrt(c))
+    bias = (0.1 * rs.randn(n)).astype(np.float32)
+    gn_a, sc_a, _ = _lib.groupnorm_shortcut(x0, x1, gw, gb, w, bias, side=True)
+    gn_b, sc_b, _ = _lib.groupnorm_shortcut(x0, x1, gw, gb, w, bias, side=False)
+    xc = np.concatenate([x0] + ([x1] if c1 else []), axis=1).astype(np.float32)
+    z = F.silu(F.group_norm(torch.from_numpy(xc), 32, torch.from_numpy(gw), torch.from_numpy(gb), 1e-5)).numpy()
+    y = F.conv2d(torch.from_numpy(xc), torch.from_numpy(w.astype(np.float32)).reshape(n, c, 1, 1), torch.from_numpy(bias)).numpy()
+    close(gn_a, z, f"GroupNorm beside the GEMM {case}")
+    close(sc_a, y, f"shortcut GEMM beside the GroupNorm {case}")
+    close(gn_b, z, f"GroupNorm alone {case}")
+    close(sc_b, y, f"shortcut GEMM alone {case}")
+    if hw * hw <= 256 or hw * hw > 1024:   # same GroupNorm kernel body in both modes (32x32: the stand-alone launch is the 1024-thread one)
+        assert np.array_equal(gn_a, gn_b)
+    again = _lib.groupnorm_shortcut(x0, x1, gw, gb, w, bias, side=True, iters=3)
+    assert np.array_equal(gn_a, again[0]) and np.array_equal(sc_a, again[1])
+
+
+def test_shortcut_gemm_too_small_for_the_side_launch_is_refused():
+    """M = 128 (the 8x8 level): the shortcut stays a launch of its own (split-K weight stream); the op-level entry says so"""
+    rs = np.random.RandomState(1)
+    x0 = h16(rs.randn(2, 128, 8, 8))
+    g = np.ones(128, np.float32)
+    with pytest.raises(NotImplementedError):
+        _lib.groupnorm_shortcut(x0, None, g, g, h16(rs.randn(64, 128)), side=True)
