@@ -668,8 +668,12 @@ Tensor UNet::transformer_block(std::vector<Op>& ops, const std::string& b, const
 Tensor UNet::transformer(std::vector<Op>& ops, const std::string& p, const Tensor& x, int heads, int depth) {
   // norm -> proj_in as ONE launch where x's producer can leave the GroupNorm statistics (GnHook): the 1x1 GEMM folds them into a
   // per-channel scale / shift of its activation fragments (gemm_pipe_kernel GNF).  When the producer's plan wrote none (split-K)
-  // the op falls back, at launch time, to the GroupNorm launch + the plain GEMM.  SD_GN_FOLD=0 (with SD_TUNE): always the pair (A/B).
-  static const int fold_mode = tune_env_int("SD_GN_FOLD", 1);
+  // the op falls back, at launch time, to the GroupNorm launch + the plain GEMM.
+  // MEASURED AND NOT ADOPTED (LAB_NOTES.md r5): the folded GEMM (table build behind two barriers in its prologue, three table reads
+  // and eight packed ops per activation fragment) takes 17.4 / 13.9 us where the plain one takes 9.2 / 10.0 - what the 7-8 us
+  // GroupNorm launch cost; the step is unchanged on a fast box (4.40 ms both ways) and 0.1 ms SLOWER on a slow one (5.43 vs 5.33).
+  // Off unless SD_GN_FOLD=1 (with SD_TUNE); the kernel stays tested at operator level (tests/test_round5_gpu.py).
+  static const int fold_mode = tune_env_int("SD_GN_FOLD", 0);
   const int G = cfg_.norm_num_groups, C = x.C, HW = x.H * x.W;
   ConvDesc d;
   d.x0 = x.p;
