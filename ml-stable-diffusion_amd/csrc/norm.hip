@@ -283,6 +283,8 @@ void launch_groupnorm(const half_t* x0, int C0, const half_t* x1, int C1, float*
                       const float* beta, half_t* y, int B, int HW, int G, float eps, int silu, hipStream_t s,
                       int producer_entries, const ConvDesc* side) {
   if (!x1) C1 = 0;
+  static const int resident_mode = tune_env_int("SD_GN_RESIDENT", 1);   // 0: the single-launch kernels run their two-pass form (A/B)
+  const int silu_f = (silu ? 1 : 0) | (resident_mode == 0 ? 2 : 0);      // bit 1 only reaches groupnorm_fused_body
   const int C = C0 + C1;
   SD_REQUIRE(C % G == 0 && C0 % 8 == 0 && C1 % 8 == 0 && G <= 64, kUnsupported, "groupnorm: C0=%d C1=%d G=%d", C0, C1, G);
   const int cpg = C / G;
@@ -305,15 +307,15 @@ void launch_groupnorm(const half_t* x0, int C0, const half_t* x1, int C1, float*
   if (HW <= fused_max_hw && cpg <= 128 && cpg % 2 == 0) {
     dim3 grid(G, B);
     if (side) {   // the single-launch GroupNorm (64 workgroups) and the independent GEMM in one grid
-      launch_gn_fused_side(cpg % 8 == 0 ? 8 : (cpg % 4 == 0 ? 4 : 2), x0, C0, x1, C1, gamma, beta, y, B, HW, G, eps, silu, *side, s);
+      launch_gn_fused_side(cpg % 8 == 0 ? 8 : (cpg % 4 == 0 ? 4 : 2), x0, C0, x1, C1, gamma, beta, y, B, HW, G, eps, silu_f, *side, s);
       return;
     }
     if (cpg % 8 == 0)
-      hipLaunchKernelGGL(groupnorm_fused_kernel<8>, grid, dim3(256), 0, s, x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu);
+      hipLaunchKernelGGL(groupnorm_fused_kernel<8>, grid, dim3(256), 0, s, x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu_f);
     else if (cpg % 4 == 0)
-      hipLaunchKernelGGL(groupnorm_fused_kernel<4>, grid, dim3(256), 0, s, x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu);
+      hipLaunchKernelGGL(groupnorm_fused_kernel<4>, grid, dim3(256), 0, s, x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu_f);
     else
-      hipLaunchKernelGGL(groupnorm_fused_kernel<2>, grid, dim3(256), 0, s, x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu);
+      hipLaunchKernelGGL(groupnorm_fused_kernel<2>, grid, dim3(256), 0, s, x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu_f);
     SD_HIP(hipGetLastError());
     return;
   }
@@ -323,9 +325,9 @@ void launch_groupnorm(const half_t* x0, int C0, const half_t* x1, int C1, float*
   if (wide && !side && HW <= 1024 && cpg >= 16 && cpg <= 48 && cpg % 4 == 0) {   // (1024-thread blocks: no side GEMM there)   // (60-channel groups measured slower: 20.8 vs 16.0 us)
     dim3 grid(G, B);
     if (cpg % 8 == 0)
-      hipLaunchKernelGGL((groupnorm_fused_kernel<8, 1024>), grid, dim3(1024), 0, s, x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu);
+      hipLaunchKernelGGL((groupnorm_fused_kernel<8, 1024>), grid, dim3(1024), 0, s, x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu_f);
     else
-      hipLaunchKernelGGL((groupnorm_fused_kernel<4, 1024>), grid, dim3(1024), 0, s, x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu);
+      hipLaunchKernelGGL((groupnorm_fused_kernel<4, 1024>), grid, dim3(1024), 0, s, x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu_f);
     SD_HIP(hipGetLastError());
     return;
   }
