@@ -222,9 +222,10 @@ def test_conv2d_every_tile_and_splitk(tile, splitk):
     close(gen, conv_ref(x, w, bias, res, 1, False), "generic conv")
 
 
-# tile % 10: 7 = the K-split software-pipelined halo kernel; tile // 10 = weight-ring code (3 / 4 / 6 / 8 stages).  5 / 6 / 8 / 9 were
-# kernels removed in round 4: asking for them must still give the right answer (the heuristic picks a live kernel)
-@pytest.mark.parametrize("tile", [7, 27, 37, 47, 57, 5, 26, 8, 9])
+# tile % 10: 7 = the K-split software-pipelined halo kernel; tile // 10 = weight-ring code (3 / 4 / 6 / 8 stages).  5 / 6 / 8 were
+# kernels removed in round 4: asking for them must still give the right answer (the heuristic picks a live kernel).  (9 was one of
+# them too; since round 5 it names the weight-streaming kernel, which refuses shapes it cannot run: tests/test_round5_gpu.py)
+@pytest.mark.parametrize("tile", [7, 27, 37, 47, 57, 5, 26, 8])
 @pytest.mark.parametrize("splitk", [0, 1, 2, 3])
 @pytest.mark.parametrize("shape", [(2, 128, 16, 16, 128), (1, 64, 24, 40, 96), (2, 320, 32, 32, 320), (1, 192, 9, 17, 68)],
                          ids=lambda s: "x".join(map(str, s)))
