@@ -397,9 +397,10 @@ Tensor UNet::group_norm(std::vector<Op>& ops, const std::string& name, const Ten
   // SD_GN_TWIN=0 (with SD_TUNE) keeps the launch: A/B.
   {
     static const int twin_mode = tune_env_int("SD_GN_TWIN", 0);   // measured and rejected: off unless asked for
+    static const int twin_max_hw = tune_env_int("SD_GN_TWIN_MAX_HW", 256);   // (A/B: 64 = the 8x8 level only)
     const int cpg = C / G;
     const Tensor* srcs[2] = {&x, x2};
-    bool ok = twin_mode != 0 && !side && x.H * x.W <= 256 && cpg % 4 == 0 && (!x2 || x.C % cpg == 0);
+    bool ok = twin_mode != 0 && !side && x.H * x.W <= std::min(256, twin_max_hw) && cpg % 4 == 0 && (!x2 || x.C % cpg == 0);
     for (int i = 0; i < 2 && ok; ++i) {
       const Tensor* t = srcs[i];
       if (!t) continue;
@@ -496,9 +497,11 @@ Tensor UNet::resnet(std::vector<Op>& ops, const std::string& p, const Tensor& x,
   // the GEMM's tiles - igemm.hip gn_*_side_kernel) instead of a launch of its own.  SD_GN_SIDE=0 (with SD_TUNE): separate launches (A/B).
   static const int side_mode = tune_env_int("SD_GN_SIDE", 1);
   static const int twin_mode = tune_env_int("SD_GN_TWIN", 0);
+  static const int twin_max_hw = tune_env_int("SD_GN_TWIN_MAX_HW", 256);
+  const bool twin_here = twin_mode != 0 && x.H * x.W <= std::min(256, twin_max_hw);   // norm1 may become a twin of its producers
   const half_t* side_out = nullptr;
   Tensor t0;
-  if (cin != cout && side_mode != 0 && twin_mode == 0 && !f32_) {
+  if (cin != cout && side_mode != 0 && !twin_here && !f32_) {
     ConvDesc sd;
     sd.x0 = x.p;
     sd.C0 = x.C;
