@@ -6,6 +6,11 @@
 //   empty_launch_us a captured graph of 323 empty 256-workgroup launches (the step's launch count): the launch floor
 //   chain_us        the same graph shape, each launch reading 8 MB it has never touched and writing 0.5 MB the next one
 //                   reads back: a dependent chain of short kernels on cold operands - what the batch-2 step actually is
+// Round 5 found the four figures above IDENTICAL (to 1 %) on boxes that run the step 4.40 and 5.52 ms apart, so two more:
+//   handover_us     323 launches, each reading ALL 8 MB the previous one wrote - every workgroup the 16 KB of a workgroup that
+//                   ran on ANOTHER XCD - and writing 8 MB: the producer -> consumer hand-over of activations between the L2s
+//   latency_ns      one wave chasing 512 dependent 64-byte-strided pointers through a 1-GiB table (never-touched lines: HBM
+//                   latency) and latency_l2_ns the same through a 2-MB table after a warm-up pass (L2 / Infinity-Cache latency)
 #include "kernels.h"
 
 namespace sd {
@@ -56,6 +61,32 @@ __global__ __launch_bounds__(256) void calib_chain_kernel(const floatx4* __restr
   next[t] = s;
 }
 
+// 512 workgroups x 256 threads x 4 x 16 B = 8 MB in, 8 MB out.  Workgroup i reads what workgroup (37 i + 11) mod 512 wrote:
+// XCDs are assigned round-robin (id mod 8) and 37 i + 11 = 5 i + 3 (mod 8) != i for every i, so every line comes from another L2.
+__global__ __launch_bounds__(256) void calib_handover_kernel(const floatx4* __restrict__ prev, floatx4* __restrict__ next) {
+  const unsigned src = (blockIdx.x * 37u + 11u) & 511u;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const floatx4 v = prev[((size_t)src * 4 + k) * 256 + threadIdx.x];
+    next[((size_t)blockIdx.x * 4 + k) * 256 + threadIdx.x] = v + floatx4{1.f, 1.f, 1.f, 1.f};
+  }
+}
+
+// the table holds, at element i * stride, the index of the next element; one lane walks it
+__global__ void calib_chase_init_kernel(unsigned* tab, unsigned n, unsigned stride) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) tab[(size_t)i * stride] = ((i * 40503u + 12345u) % n) * stride;   // (a fixed pseudo-random successor)
+}
+__global__ void calib_chase_kernel(const unsigned* __restrict__ tab, int hops, unsigned start, unsigned* out, long long* cycles) {
+  if (threadIdx.x != 0) return;
+  unsigned p = start;
+  const long long t0 = wall_clock64();
+  for (int h = 0; h < hops; ++h) p = __builtin_nontemporal_load(tab + p);
+  const long long t1 = wall_clock64();
+  out[0] = p;
+  cycles[0] = t1 - t0;   // ticks of the 100-MHz constant clock
+}
+
 float time_graph(hipStream_t st, hipGraphExec_t g, int reps) {
   hipEvent_t e0, e1;
   SD_HIP(hipEventCreate(&e0));
@@ -75,7 +106,7 @@ float time_graph(hipStream_t st, hipGraphExec_t g, int reps) {
 
 }  // namespace
 
-// out[0..3] = copy_gbs, mfma_tflops, empty_launch_us, chain_us
+// out[0..6] = copy_gbs, mfma_tflops, empty_launch_us, chain_us, handover_us, latency_ns (HBM), latency_l2_ns
 void run_calibration(int device, float* out) {
   SD_HIP(hipSetDevice(device));
   hipStream_t st;
@@ -148,6 +179,36 @@ void run_calibration(int device, float* out) {
     });
     out[3] = time_graph(st, ge, 10) * 1e3f / (float)kLaunches;
     (void)hipGraphExecDestroy(ge);
+  }
+  {   // (e) hand-over chain: ping-pong between two 8-MB buffers at the start of src / dst
+    floatx4* b0 = src;
+    floatx4* b1 = dst;
+    hipGraphExec_t ge = capture([&] {
+      for (int i = 0; i < kLaunches; ++i)
+        hipLaunchKernelGGL(calib_handover_kernel, dim3(512), dim3(256), 0, st, (i & 1) ? b1 : b0, (i & 1) ? b0 : b1);
+    });
+    out[4] = time_graph(st, ge, 10) * 1e3f / (float)kLaunches;
+    (void)hipGraphExecDestroy(ge);
+  }
+  {   // (f) dependent-load latency: never-touched lines of the 1-GiB table, then a 2-MB table that was just walked
+    unsigned* tab = reinterpret_cast<unsigned*>(src);
+    unsigned* sink = reinterpret_cast<unsigned*>(dst);
+    long long* cyc = reinterpret_cast<long long*>(dst) + 8;
+    auto chase = [&](unsigned n, unsigned stride, int hops, int passes) {
+      hipLaunchKernelGGL(calib_chase_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, tab, n, stride);
+      if (passes == 1) {   // big table: evict what the initialisation left in the caches
+        SD_HIP(hipMemsetAsync(dst + (size_t)4096, 0, bytes - 65536, st));
+      }
+      long long ticks = 0;
+      for (int p = 0; p < passes; ++p) {
+        hipLaunchKernelGGL(calib_chase_kernel, dim3(1), dim3(64), 0, st, tab, hops, 0u, sink, cyc);
+        SD_HIP(hipStreamSynchronize(st));
+        SD_HIP(hipMemcpy(&ticks, cyc, sizeof(ticks), hipMemcpyDeviceToHost));
+      }
+      return (float)ticks * 10.0f / (float)hops;   // ns per hop (last pass)
+    };
+    out[5] = chase((unsigned)(bytes / 4096), 1024u, 512, 1);          // 262 144 entries, 4 KB apart: 512 hops on cold lines
+    out[6] = chase(32768u, 16u, 4096, 2);                              // 2 MB: the second pass walks what the first pulled in
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);

@@ -929,11 +929,11 @@ int sd_philox_randn(uint64_t seed, uint32_t offset, double* out, size_t n) {
   });
 }
 
-int sd_calibrate(int device, float* out4) {
+int sd_calibrate(int device, float* out7) {
   return guarded([&] {
-    SD_REQUIRE(out4, kInvalidArgument, "NULL argument");
+    SD_REQUIRE(out7, kInvalidArgument, "NULL argument");
     require_device();
-    run_calibration(device, out4);
+    run_calibration(device, out7);
   });
 }
 

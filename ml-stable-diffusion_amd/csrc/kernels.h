@@ -114,8 +114,9 @@ bool reduce_twin_ok(int HW, int N, int n_twins, const GnTwin* tw);
 void launch_reduce_twin(const float* partial, int S, int M, int N, int HW, const float* bias, const float* temb, int temb_stride,
                         const half_t* res, half_t* out, int n_twins, const GnTwin* tw, hipStream_t s);
 
-// calib.hip: box calibration for bench.py - out[0..3] = copy GB/s, dense MFMA TFLOP/s, us per launch of a 323-launch empty
-// graph, us per launch of a 323-launch chain of short kernels on cold operands
+// calib.hip: box calibration for bench.py - out[0..6] = copy GB/s, dense MFMA TFLOP/s, us per launch of a 323-launch empty
+// graph, us per launch of a 323-launch chain of short kernels on cold operands, us per launch of a 323-launch chain handing 8 MB
+// over between the XCDs' L2s, ns per dependent load from HBM / from the caches
 void run_calibration(int device, float* out);
 
 // direct conv for tiny / odd shapes (any Cin, any N): fp32 accumulate, one thread per output

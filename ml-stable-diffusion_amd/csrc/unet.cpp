@@ -347,13 +347,13 @@ Tensor UNet::conv_w(std::vector<Op>& ops, const std::string& name, const half_t*
     ws_need_ = std::max(ws_need_, conv_workspace_bytes(d));
     ops.push_back([this, d, hook, with_hook](hipStream_t s) {
       const int n = launch_conv(with_hook(d), ws_conv_, s);
-      if (hook) hook->entries = n;
+      if (hook) hook->produced(n);
     });
   } else {
     const int so = silu_out ? 1 : 0;
     ops.push_back([d, so, hook, with_hook](hipStream_t s) {
       const int n = launch_conv_generic(with_hook(d), so, s);
-      if (hook) hook->entries = n;
+      if (hook) hook->produced(n);
     });
   }
   {
@@ -455,14 +455,14 @@ Tensor UNet::group_norm(std::vector<Op>& ops, const std::string& name, const Ten
   if (side) {
     const ConvDesc sd = *side;
     ops.push_back([=](hipStream_t s) {
-      launch_groupnorm(p0, C0, p1, C1, partial, gamma, beta, yp, B, HW, G, eps, si, s, hook ? hook->entries : 0, &sd);
+      launch_groupnorm(p0, C0, p1, C1, partial, gamma, beta, yp, B, HW, G, eps, si, s, hook ? hook->consume() : 0, &sd);
     });
     ops.back().label = "groupnorm C=" + std::to_string(C) + " @" + std::to_string(x.H) + "x" + std::to_string(x.W) + " " + name + " || " + side_label;
     ops.back().flop = side_flop;
     return y;
   }
   ops.push_back([=](hipStream_t s) {
-    launch_groupnorm(p0, C0, p1, C1, partial, gamma, beta, yp, B, HW, G, eps, si, s, hook ? hook->entries : 0);
+    launch_groupnorm(p0, C0, p1, C1, partial, gamma, beta, yp, B, HW, G, eps, si, s, hook ? hook->consume() : 0);
   });
   ops.back().label = "groupnorm C=" + std::to_string(C) + " @" + std::to_string(x.H) + "x" + std::to_string(x.W) + " " + name;
   return y;
@@ -704,7 +704,7 @@ Tensor UNet::transformer(std::vector<Op>& ops, const std::string& p, const Tenso
     const int B = x.B;
     const half_t* xp = x.p;
     ops.push_back([this, d, hook, partial, gamma, beta, t0, xp, B, HW, G, C](hipStream_t s) {
-      const int n = hook->entries;
+      const int n = hook->consume();
       if (n >= 1 && n <= 128) {
         ConvDesc dd = d;
         dd.gnf_partial = partial;
@@ -1410,10 +1410,23 @@ void UNet::run_attached() {
     for (UNet* cn : attached_) cn->run_as_controlnet(stream_, x_in_.p, tbuf_);
     return;
   }
+  //  a stale flag from a run that threw between the fork and the join must not survive; every attached handle is
+  // checked BEFORE the fork so that the usual error - no conditioning image - cannot leave the side stream forked
+  cn_join_pending_ = false;
+  for (UNet* cn : attached_)
+    SD_REQUIRE(cn->have_cond_, kInvalidArgument, "ControlNet has no conditioning image: call sd_controlnet_set_cond first");
   // fork behind the sample / timestep hand-over (everything queued on stream_ so far); run_main joins in front of the first residual add
   SD_HIP(hipEventRecord(ev_cn_fork_, stream_));
   SD_HIP(hipStreamWaitEvent(cn_stream_, ev_cn_fork_, 0));
-  for (UNet* cn : attached_) cn->run_as_controlnet(cn_stream_, x_in_.p, tbuf_);
+  try {
+    for (UNet* cn : attached_) cn->run_as_controlnet(cn_stream_, x_in_.p, tbuf_);
+  } catch (...) {
+    // join what was forked (eagerly: the main stream waits for the side stream; under capture: the side stream re-joins the
+    // capture so that hipStreamEndCapture can discard it), then let the error travel on
+    (void)hipEventRecord(ev_cn_join_, cn_stream_);
+    (void)hipStreamWaitEvent(stream_, ev_cn_join_, 0);
+    throw;
+  }
   SD_HIP(hipEventRecord(ev_cn_join_, cn_stream_));
   cn_join_pending_ = true;
 }

@@ -12,8 +12,10 @@ namespace sd {
 // Link between a conv / GEMM op and the GroupNorm that consumes its output: the GroupNorm (built later) asks the
 // producer to leave per-tile (sum, sumsq) partials of the tensor in `partial`; at launch time the producer reports how
 // many entries per (sample, group) its plan wrote (0: none - split-K, ragged tiles - the GroupNorm runs its own pass).
-// `entries` is written by the producer's launch closure and read by the GroupNorm's: the GroupNorm op MUST sit behind its
-// producer in the launch list (UNet::group_norm asserts the positions at build time: ops_pos of the producer < its own).
+// `entries` is written by the producer's launch closure (produced()) and taken by the GroupNorm's (consume()): the GroupNorm op
+// sits behind its producer in the launch list (UNet::group_norm asserts the positions at build time: ops_pos of the producer <
+// its own), and at LAUNCH time a consumer that runs without its producer having run since the last consumption - an op timed on
+// its own, a list walked out of order - gets 0 entries, i.e. runs its own statistics pass: stale partials are never folded.
 //
 // Twins (round 5): at the 8x8 / 16x16 levels (Ho * Wo <= 256) the producer can leave through fp32 slabs and the group-organised
 // combine of wstream.hip, which holds whole (sample, group) slices and writes the GroupNorm(+SiLU) the consumer asks for next to
@@ -24,6 +26,16 @@ struct GnHook {
   float* partial = nullptr;
   int groups = 0;
   int entries = 0;
+  bool fresh = false;            // produced() since the last consume()
+  void produced(int n) {
+    entries = n;
+    fresh = true;
+  }
+  int consume() {
+    const int n = fresh ? entries : 0;
+    fresh = false;
+    return n;
+  }
   int ops_pos = -1;              // index of the producing op in its launch list
   const void* ops_list = nullptr;
   bool twin_capable = false;     // the producer can run the slab + reduce_twin path

@@ -128,10 +128,12 @@ class _Base:
             if k in c and c[k] not in allowed:
                 # a checkpoint config that does NOT name the key gets the diffusers class default (DDIM: clip_sample=True,
                 # PNDM: skip_prk_steps=False): the Stable Diffusion checkpoints all spell these keys out, community ones may not
-                raise NotImplementedError(
-                    f"{type(self).__name__}: {k}={c[k]!r} is not implemented (supported: {allowed}).  If the checkpoint's "
-                    f"scheduler/scheduler_config.json simply omits \"{k}\" (the diffusers default then applies), add "
-                    f"\"{k}\": {json.dumps(allowed[0])} to it - Stable Diffusion 1.x / 2.x / XL checkpoints are trained for that value")
+                msg = f"{type(self).__name__}: {k}={c[k]!r} is not implemented (supported: {allowed})."
+                if k in ("clip_sample", "skip_prk_steps"):   # (only these two have ONE value every SD checkpoint uses)
+                    msg += (f"  If the checkpoint's scheduler/scheduler_config.json simply omits \"{k}\" (the diffusers default then "
+                            f"applies), add \"{k}\": {json.dumps(allowed[0])} to it - Stable Diffusion 1.x / 2.x / XL checkpoints "
+                            f"are trained for that value")
+                raise NotImplementedError(msg)
         if c["prediction_type"] not in self.PREDICTION_TYPES:
             raise NotImplementedError(f"{type(self).__name__}: prediction_type={c['prediction_type']!r} "
                                       f"(supported: {self.PREDICTION_TYPES})")

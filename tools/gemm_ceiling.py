@@ -40,7 +40,7 @@ def torch_us(fn, iters=30):
 say("1x1 GEMM (bias + residual epilogue), fp16: best plan code of libsdmi355 vs hipBLASLt (F.linear, no epilogue), us and TFLOP/s; peak 2500")
 rs = np.random.RandomState(0)
 for cin, cout in ((320, 320), (640, 640), (1280, 1280), (1280, 320), (2560, 640), (5120, 1280), (320, 2560), (1280, 10240)):
-    for m in (128, 512, 2048, 8192, 32768, 131072):
+    for m in (128, 512, 2048, 8192, 32768):   # (131 072 rows: round 3, profiles/r03_gemm_ceiling.txt)
         if m < 8192 and not ((m <= 512 and cin >= 1280) or (m == 2048 and cin in (640, 2560)) ):
             continue   # small M: only the shapes the 8x8 / 16x16 / 32x32 levels of the SD2.1 step have
         hw = int(round((m // 2) ** 0.5))
@@ -62,7 +62,7 @@ for cin, cout in ((320, 320), (640, 640), (1280, 1280), (1280, 320), (2560, 640)
             f" | hipBLASLt {lib_us:7.1f} us {flop / lib_us / 1e6:6.0f} TF")
         del xt, wt
 say("3x3 conv stride 1 (bias + residual), fp16: conv3x3_halo_ks_kernel (plan from the table / heuristic) vs MIOpen (F.conv2d channels_last)")
-for c, hw_list in ((320, (64, 128, 256)), (640, (32, 64, 128)), (1280, (16, 32, 64))):
+for c, hw_list in ((320, (64, 128)), (640, (32, 64)), (1280, (8, 16, 32))):
     for hw in hw_list:
         m = 2 * hw * hw
         x = rs.randn(2, c, hw, hw).astype(np.float16)

@@ -29,7 +29,7 @@ for step in "$@"; do
     ab:*)
       kv=${step#ab:}; fl=""
       case "$kv" in *@*) fl=${kv#*@}; kv=${kv%%@*} ;; esac      # "ab:ENV=VAL@--prompts-per-gpu 8": extra bench flags behind @
-      r=$(env ${kv//,/ } timeout 300 python bench.py --cpu-steps 0 --repeats 5 $fl 2>/dev/null | tail -n 1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); g=(d.get('gpu_state') or {}).get('after_timed_region') or {}; c=d.get('calibration') or {}; print(d['ms_per_step'], d['value'], 'calib', c.get('copy_gbs'), c.get('mfma_tflops'), c.get('empty_launch_us'), c.get('chain_us'), 'sclk', g.get('sclk clock speed:'), 'W', g.get('Current Socket Graphics Package Power (W)'))" 2>&1)
+      r=$(env ${kv//,/ } timeout 300 python bench.py --cpu-steps 0 --repeats 5 $fl 2>/dev/null | tail -n 1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); g=(d.get('gpu_state') or {}).get('after_timed_region') or {}; c=d.get('calibration') or {}; print(d['ms_per_step'], d['value'], 'calib', c.get('copy_gbs'), c.get('mfma_tflops'), c.get('empty_launch_us'), c.get('chain_us'), c.get('handover_us'), c.get('latency_hbm_ns'), c.get('latency_cache_ns'), 'sclk', g.get('sclk clock speed:'), 'W', g.get('Current Socket Graphics Package Power (W)'))" 2>&1)
       note "ab[$kv $fl] ms/step, it/s: $r" ;;
     profile)
       timeout 300 python tools/op_profile.py $OUT/op_profile_$TAG.json 2 ORIGINAL > $OUT/op_profile_$TAG.txt 2>&1; note "profile rc=$?"; head -n 28 $OUT/op_profile_$TAG.txt | cut -c1-150 ;;
