@@ -396,7 +396,7 @@ Tensor UNet::group_norm(std::vector<Op>& ops, const std::string& name, const Ten
   // group boundaries fall on the source boundaries -> the producers write this GroupNorm themselves (GnHook twins), no launch.
   // SD_GN_TWIN=0 (with SD_TUNE) keeps the launch: A/B.
   {
-    static const int twin_mode = tune_env_int("SD_GN_TWIN", 0);   // measured and rejected: off unless asked for
+    static const int twin_mode = tune_env_int("SD_GN_TWIN", 0);   // measured and rejected (LAB_NOTES.md r5): off unless asked for
     static const int twin_max_hw = tune_env_int("SD_GN_TWIN_MAX_HW", 256);   // (A/B: 64 = the 8x8 level only)
     const int cpg = C / G;
     const Tensor* srcs[2] = {&x, x2};

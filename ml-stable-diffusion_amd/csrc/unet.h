@@ -168,7 +168,7 @@ class UNet {
   hipStream_t stream_ = nullptr;
   // SD_SIDE_TIME=1 (experiment, off by default): the time-embedding chain (depends only on the timestep)
   // runs on a forked stream beside conv_in / the first GroupNorm and joins before the first consumer of
-  // its output.  Measured: the fork/join costs the captured step +0.22 ms while hiding 65 us.
+  // its output.  Measured: the fork/join costs the captured step +0.22 ms while hiding 65 us (LAB_NOTES.md, round 4).
   hipStream_t side_ = nullptr;
   hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   int temb_join_pos_ = -1;

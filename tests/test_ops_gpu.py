@@ -288,7 +288,7 @@ def test_splitk_is_complete_and_bit_reproducible(tile, splitk):
     """Split-K: fp32 slabs per K slice, combined in slice order by the reduce kernel (no atomics): repeated launches
     must agree bit for bit, and with torch.  A weight-streaming shape (M = 128 rows, K = 11520), up to 16 slices.
     (An in-launch last-arriver combine was built and measured in round 2: correct, but 1.5-3x slower on these shapes
-    - one workgroup per tile re-reading 256-512 KB of slabs behind a release fence - and was dropped, DESIGN.md.)"""
+    - one workgroup per tile re-reading 256-512 KB of slabs behind a release fence - and was dropped, LAB_NOTES.md.)"""
     rs = np.random.RandomState(tile * 100 + splitk)
     x = h16(rs.randn(2, 1280, 8, 8))
     w = h16(rs.randn(320, 1280, 3, 3) / np.sqrt(1280 * 9))
