@@ -287,6 +287,17 @@ int sd_op_conv2d_groupnorm_proj(const void* x, const void* w, const float* bias,
                                 const float* gn_bias, const void* proj_w, const float* proj_bias, void* conv_out, void* out, int B,
                                 int Cin, int H, int W, int Cout, int ksize, int Nproj, int groups, float eps, int fold, int tile,
                                 int* entries, int iters, float* ms);
+/* conv -> torch.nn.GroupNorm (+ SiLU) -> 3x3 conv (stride 1, padding 1): a ResnetBlock2D's norm2 -> SiLU -> conv2 behind conv1, or
+ * norm1 -> SiLU -> conv1 behind the previous block (unet.py:470-489).  fold = 1: the GroupNorm (+ SiLU) is applied in the HALO
+ * LOADER of the second conv (statistics from the first conv's epilogue; every wave normalises the halo pieces it fetched, in LDS;
+ * pixels outside the image stay zero - the conv pads the NORMALISED tensor): no GroupNorm launch, no round trip of the normalised
+ * tensor; fold = 0: GroupNorm launch + plain conv.  *entries (may be NULL): statistics entries the loader consumed (0: it fell
+ * back).  w2 (N2, Cout, 3, 3) f16, bias2 (N2) f32 or NULL, res2 (B, N2, H, W) f16 or NULL; staging2: ring code of the second conv
+ * (0 = plan table).  conv_out (may be NULL) (B, Cout, H, W), out (B, N2, H, W) f16 NCHW. */
+int sd_op_conv2d_groupnorm_conv3x3(const void* x, const void* w, const float* bias, const void* res, const float* gn_weight,
+                                   const float* gn_bias, const void* w2, const float* bias2, const void* res2, void* conv_out, void* out,
+                                   int B, int Cin, int H, int W, int Cout, int ksize, int N2, int groups, float eps, int silu, int fold,
+                                   int tile, int staging2, int* entries, int iters, float* ms);
 /* Cross-attention front half as one launch (unet.py:87-118 inside :586-591): out = softmax(to_q(LayerNormANE(x)) k^T / 8) v
  * per head, head dim 64, Sk <= 96 (the prompt), any Sq >= 1 (ragged last token tile).  V^T columns [Sk, round_up(Sk, 8)) must be
  * zero (this entry point zero-fills them; the masked probabilities there are 0 but 0 * inf would be NaN).  x (B, heads*64, 1, Sq), k / v (B, heads*64, 1, Sk) f16 BC1S,

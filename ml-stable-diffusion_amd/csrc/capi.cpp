@@ -679,6 +679,106 @@ int sd_op_conv2d_groupnorm_proj(const void* x, const void* w, const float* bias,
   });
 }
 
+int sd_op_conv2d_groupnorm_conv3x3(const void* x, const void* w, const float* bias, const void* res, const float* gn_weight,
+                                   const float* gn_bias, const void* w2, const float* bias2, const void* res2, void* conv_out, void* out,
+                                   int B, int Cin, int H, int W, int Cout, int ksize, int N2, int groups, float eps, int silu, int fold,
+                                   int tile, int staging2, int* entries, int iters, float* ms) {
+  return guarded([&] {
+    SD_REQUIRE(x && w && gn_weight && gn_bias && w2 && out, kInvalidArgument, "NULL argument");
+    SD_REQUIRE(ksize == 1 || ksize == 3, kInvalidArgument, "conv2d_groupnorm_conv3x3: ksize %d", ksize);
+    Scratch sc;
+    std::vector<half_t> xt = nchw_to_nhwc(reinterpret_cast<const half_t*>(x), B, Cin, H, W);
+    auto retile = [](const half_t* wh, int co, int ci, int kk) {   // [Cout][Cin][ky][kx] -> [Cout][ky][kx][Cin]
+      std::vector<half_t> wt((size_t)co * ci * kk);
+      for (int o = 0; o < co; ++o)
+        for (int c = 0; c < ci; ++c)
+          for (int t = 0; t < kk; ++t) wt[((size_t)o * kk + t) * ci + c] = wh[((size_t)o * ci + c) * kk + t];
+      return wt;
+    };
+    std::vector<half_t> wt = retile(reinterpret_cast<const half_t*>(w), Cout, Cin, ksize * ksize);
+    std::vector<half_t> wt2 = retile(reinterpret_cast<const half_t*>(w2), N2, Cout, 9);
+    ConvDesc d;
+    d.x0 = sc.dev<half_t>(xt.size(), xt.data());
+    d.C0 = Cin;
+    d.w = sc.dev<half_t>(wt.size(), wt.data());
+    d.bias = bias ? sc.dev<float>(Cout, bias) : nullptr;
+    std::vector<half_t> rt, rt2;
+    if (res) {
+      rt = nchw_to_nhwc(reinterpret_cast<const half_t*>(res), B, Cout, H, W);
+      d.res = sc.dev<half_t>(rt.size(), rt.data());
+    }
+    const size_t on = (size_t)B * H * W * Cout, pn = (size_t)B * H * W * N2;
+    half_t* dconv = sc.dev<half_t>(on);
+    half_t* dnorm = sc.dev<half_t>(on);
+    half_t* dy = sc.dev<half_t>(pn);
+    d.out = dconv;
+    d.B = B; d.Hi = H; d.Wi = W; d.Ho = H; d.Wo = W;
+    d.ksize = ksize; d.stride = 1; d.up = 1; d.N = Cout;
+    d.tile = tile % 10;
+    d.staging = tile / 10;
+    d.splitk = 1;
+    SD_REQUIRE(conv_fast_path_ok(d), kInvalidArgument, "conv2d_groupnorm_conv3x3: the producer must run on the MFMA path");
+    const size_t pf = groupnorm_scratch_floats(B, H * W, groups);
+    float* partial = sc.dev<float>(pf);
+    {   // poison: the loader's fold must only use what the producer wrote
+      std::vector<float> poison(pf, 1.0e30f);
+      SD_HIP(hipMemcpy(partial, poison.data(), pf * sizeof(float), hipMemcpyHostToDevice));
+    }
+    d.gn_partial = partial;
+    d.gn_groups = groups;
+    float* dgw = sc.dev<float>(Cout, gn_weight);
+    float* dgb = sc.dev<float>(Cout, gn_bias);
+    ConvDesc cd;   // the 3x3 conv over the normalised tensor
+    cd.C0 = Cout;
+    cd.w = sc.dev<half_t>(wt2.size(), wt2.data());
+    cd.bias = bias2 ? sc.dev<float>(N2, bias2) : nullptr;
+    if (res2) {
+      rt2 = nchw_to_nhwc(reinterpret_cast<const half_t*>(res2), B, N2, H, W);
+      cd.res = sc.dev<half_t>(rt2.size(), rt2.data());
+    }
+    cd.out = dy;
+    cd.B = B; cd.Hi = H; cd.Wi = W; cd.Ho = H; cd.Wo = W;
+    cd.ksize = 3; cd.stride = 1; cd.up = 1; cd.N = N2;
+    cd.staging = staging2;
+    cd.gnf_groups = groups;
+    SD_REQUIRE(conv_fast_path_ok(cd), kInvalidArgument, "conv2d_groupnorm_conv3x3: the second conv must run on the MFMA path");
+    const bool can_fold = fold && silu && conv_gn_loader_ok(cd);   // (the loader always applies SiLU: every such GroupNorm of the graph has one)
+    SD_REQUIRE(!fold || can_fold, kUnsupported, "conv2d_groupnorm_conv3x3: the halo loader cannot normalise C=%d groups=%d @%dx%d", Cout, groups, H, W);
+    cd.gnf_groups = 0;
+    ConvWorkspace ws;
+    ws.partial_bytes = std::max(conv_workspace_bytes(d), conv_workspace_bytes(cd));
+    if (ws.partial_bytes) ws.partial = reinterpret_cast<float*>(sc.dev<char>(ws.partial_bytes));
+    int n_entries = 0;
+    sc.timed(iters, ms, [&] {
+      n_entries = launch_conv(d, ws, sc.stream);
+      ConvDesc cc = cd;
+      if (fold && n_entries >= 1 && n_entries <= 128) {
+        cc.x0 = dconv;
+        cc.gnf_partial = partial;
+        cc.gnf_gamma = dgw;
+        cc.gnf_beta = dgb;
+        cc.gnf_eps = eps;
+        cc.gnf_groups = groups;
+        cc.gnf_entries = n_entries;
+        cc.gnf_silu = silu ? 1 : 0;
+      } else {
+        launch_groupnorm(dconv, Cout, nullptr, 0, partial, dgw, dgb, dnorm, B, H * W, groups, eps, silu ? 1 : 0, sc.stream, n_entries);
+        cc.x0 = dnorm;
+      }
+      launch_conv(cc, ws, sc.stream);
+    });
+    if (entries) *entries = (fold && n_entries >= 1 && n_entries <= 128) ? n_entries : 0;
+    if (conv_out) {
+      std::vector<half_t> ot(on);
+      SD_HIP(hipMemcpy(ot.data(), dconv, on * 2, hipMemcpyDeviceToHost));
+      nhwc_to_nchw(ot.data(), reinterpret_cast<half_t*>(conv_out), B, Cout, H, W);
+    }
+    std::vector<half_t> ot(pn);
+    SD_HIP(hipMemcpy(ot.data(), dy, pn * 2, hipMemcpyDeviceToHost));
+    nhwc_to_nchw(ot.data(), reinterpret_cast<half_t*>(out), B, N2, H, W);
+  });
+}
+
 int sd_op_cross_attention_fused(const void* x, const float* ln_weight, const float* ln_bias, const void* wq, const void* k,
                                 const void* v, void* out, int B, int heads, int Sq, int Sk, float eps, int nst, int iters,
                                 float* ms) {

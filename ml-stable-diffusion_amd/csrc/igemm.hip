@@ -867,7 +867,14 @@ __device__ __forceinline__ void wait_vmcnt_barrier() {   // counted wait + raw b
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 constexpr int halo_mod9(int t) { return ((t % 9) + 9) % 9; }
-constexpr int halo_x_issued(int tap) { return halo_mod9(tap) < HALO_PPW ? 1 : 0; }
+// halo pieces of the NEXT chunk a wave issues in tap step `tap`.  Plain kernel: one per step in steps 0-5.  GNL (GroupNorm in the
+// loader): two in step 0, one in steps 1-4 - the last piece must have LANDED one step before the halo is first read (step 8), so
+// that its owner can still transform it in place behind the barrier of step 7.
+template <bool GNL = false>
+constexpr int halo_x_issued(int tap) {
+  const int t = halo_mod9(tap);
+  return GNL ? (t == 0 ? 2 : (t <= 4 ? 1 : 0)) : (t < HALO_PPW ? 1 : 0);
+}
 // D = stages of the weight ring (D - 1 tap steps of weights in flight; 2 = the round-1 double buffer).
 constexpr size_t halo_lds_bytes(int bn, int d) {
   return ((size_t)2 * HALO_LDS_ROWS * BK + (size_t)d * bn * BK) * sizeof(half_t) + bn * sizeof(float);
@@ -892,29 +899,29 @@ constexpr size_t halo_lds_bytes(int bn, int d) {
 //     of the K range is a separate instantiation (no DMA past the end), and nothing in a tap step is conditional: one
 //     basic block per nine steps, so the interleaving above is what the scheduler emits.
 // ---------------------------------------------------------------------------------------------
-template <int D, int WR>
+template <int D, int WR, bool GNL = false>
 constexpr int halo_ks_wait_count(int tap) {
   // VMEM ops a wave has issued after the weight tile of step s+1 when it waits in step s (tap `tap`): per step, in
   // order, [WR weight pieces of step s'+D] [one halo piece of the next chunk when tap(s') < HALO_PPW]
   // (the halo piece issued in the same step as the awaited tile is waited for too: the count then does not depend on
   // the order of the DMA instructions inside one step)
   int n = 0;
-  for (int i = 2; i <= D - 1; ++i) n += WR + halo_x_issued(tap - D + i);
+  for (int i = 2; i <= D - 1; ++i) n += WR + halo_x_issued<GNL>(tap - D + i);
   if (tap == 8 && n > 2 * WR) n = 2 * WR;   // the next chunk's halo (last piece went out at tap 5) is read right after
   return n;
 }
-template <int D, int WR>
+template <int D, int WR, bool GNL = false>
 __device__ __forceinline__ void halo_ks_wait(int tap) {
   switch (tap) {
-    case 0: wait_vmcnt_barrier<halo_ks_wait_count<D, WR>(0)>(); break;
-    case 1: wait_vmcnt_barrier<halo_ks_wait_count<D, WR>(1)>(); break;
-    case 2: wait_vmcnt_barrier<halo_ks_wait_count<D, WR>(2)>(); break;
-    case 3: wait_vmcnt_barrier<halo_ks_wait_count<D, WR>(3)>(); break;
-    case 4: wait_vmcnt_barrier<halo_ks_wait_count<D, WR>(4)>(); break;
-    case 5: wait_vmcnt_barrier<halo_ks_wait_count<D, WR>(5)>(); break;
-    case 6: wait_vmcnt_barrier<halo_ks_wait_count<D, WR>(6)>(); break;
-    case 7: wait_vmcnt_barrier<halo_ks_wait_count<D, WR>(7)>(); break;
-    default: wait_vmcnt_barrier<halo_ks_wait_count<D, WR>(8)>(); break;
+    case 0: wait_vmcnt_barrier<halo_ks_wait_count<D, WR, GNL>(0)>(); break;
+    case 1: wait_vmcnt_barrier<halo_ks_wait_count<D, WR, GNL>(1)>(); break;
+    case 2: wait_vmcnt_barrier<halo_ks_wait_count<D, WR, GNL>(2)>(); break;
+    case 3: wait_vmcnt_barrier<halo_ks_wait_count<D, WR, GNL>(3)>(); break;
+    case 4: wait_vmcnt_barrier<halo_ks_wait_count<D, WR, GNL>(4)>(); break;
+    case 5: wait_vmcnt_barrier<halo_ks_wait_count<D, WR, GNL>(5)>(); break;
+    case 6: wait_vmcnt_barrier<halo_ks_wait_count<D, WR, GNL>(6)>(); break;
+    case 7: wait_vmcnt_barrier<halo_ks_wait_count<D, WR, GNL>(7)>(); break;
+    default: wait_vmcnt_barrier<halo_ks_wait_count<D, WR, GNL>(8)>(); break;
   }
 }
 
@@ -940,15 +947,30 @@ __device__ __forceinline__ void halo_ks_wait_last(int tap) {
   }
 }
 
-template <int D, int DBG = 0>
+// GNL (round 5): GroupNorm(+SiLU) of the INPUT applied in the halo loader (ResnetBlock2D norm1 -> SiLU -> conv1
+// and norm2 -> SiLU -> conv2, unet.py:472-481): x0 is the UN-normalised tensor, its producer left (sum, sumsq) partials
+// (gnf_partial / gnf_entries); every workgroup folds the ones of its sample into a per-channel (mean, scale, shift) table in LDS
+// (the GNF prologue of gemm_pipe_body) and every wave transforms the halo pieces IT fetched, in place, once they have landed -
+// each halo element once per workgroup, not once per tap: read back its own 16 bytes, (x - mean) * scale + shift in packed
+// fp16, SiLU in fp32, write back.  Pixels outside the image keep the zeros of the range-checked DMA (the conv pads the
+// NORMALISED tensor).  The pieces of the next chunk go out two in step 0, one in steps 1-4 and are transformed in steps 3-7
+// (landed: the counted wait of step t covers everything issued in steps <= t - (D - 1)); step 8 reads the halo as before.
+// The GroupNorm launch and the round trip of the normalised tensor through HBM are gone.  D <= 4.
+template <int D, int DBG = 0, bool GNL = false>
 __global__ __launch_bounds__(256, halo_lds_bytes(64, D) <= 80 * 1024 ? 2 : 1) void conv3x3_halo_ks_kernel(IgemmArgs a) {
   constexpr int BN = 64, BM = 128, WR = 2, ROWB = BK * 2;   // ROWB: bytes per LDS row
-  static_assert(halo_ks_wait_count<D, WR>(1) <= 63 && (D - 1) * WR <= 63, "vmcnt range");
+  static_assert(halo_ks_wait_count<D, WR, GNL>(1) <= 63 && (D - 1) * WR <= 63, "vmcnt range");
   static_assert(halo_lds_bytes(64, D) >= 32 * 1024 + BM * (BN + 8) * 2 + BN * 4, "epilogue buffers fit the K-loop buffers");
+  static_assert(!GNL || (D <= 4 && DBG == 0), "GroupNorm in the loader: rings of <= 4 stages");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const Xh = smem;                                          // [2][HALO_LDS_ROWS][BK] halves
   char* const Ws = smem + 2 * HALO_LDS_ROWS * ROWB;               // [D][BN][BK]
-  float* sconst = reinterpret_cast<float*>(Ws + D * BN * ROWB);   // [BN] bias + timestep-embedding row
+  // [BN] bias + timestep-embedding row, written in the epilogue only.  GNL: behind the epilogue's staging buffers (the K-loop
+  // buffers are free by then) - its place behind the ring holds the GroupNorm table [Ctot] mean | scale | shift (halves), so the
+  // 320-channel convs of the 64x64 level still fit two workgroups per CU (81 792 B with the 4-stage ring)
+  float* sconst = GNL ? reinterpret_cast<float*>(smem + 32 * 1024 + BM * (BN + 8) * 2) : reinterpret_cast<float*>(Ws + D * BN * ROWB);
+  half_t* const gn_tab = reinterpret_cast<half_t*>(Ws + D * BN * ROWB);
+  float* const gn_stat = reinterpret_cast<float*>(Xh + HALO_LDS_ROWS * ROWB);   // [64] mean | [64] rstd: prologue only (halo buffer 1 is idle until step 0)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -988,9 +1010,13 @@ __global__ __launch_bounds__(256, halo_lds_bytes(64, D) <= 80 * 1024 ? 2 : 1) vo
       __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.w), 0, (int)((size_t)a.N * a.K * 2), 0x00020000);
   const size_t xpix = (size_t)a.B * a.Hi * a.Wi;
   unsigned hoff0[HALO_PPW], hoff1[HALO_PPW];            // byte offset of this lane's 16 bytes of halo piece j at channel 0
+  // piece of slot j.  The 24th slot (wave 3, j = 5) has no piece of its own: plain kernel - it fetches piece 22 a second time
+  // (same bytes); GNL - it must not touch another wave's piece (that wave transforms it in place), so it re-fetches the wave's
+  // OWN previous piece, and that piece is transformed once, behind the later of its two fetches (slot 5 instead of slot 4)
+  auto piece_of = [&](int j) { return (wave + 4 * j < HALO_PIECES) ? wave + 4 * j : (GNL ? wave + 4 * (j - 1) : HALO_PIECES - 1); };
 #pragma unroll
   for (int j = 0; j < HALO_PPW; ++j) {
-    const int p = (wave + 4 * j < HALO_PIECES) ? wave + 4 * j : HALO_PIECES - 1;
+    const int p = piece_of(j);
     const int hr = 8 * p + (lane >> 3);
     const int hy = hr / HALO_W, hx = hr - hy * HALO_W;
     const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
@@ -1013,7 +1039,7 @@ __global__ __launch_bounds__(256, halo_lds_bytes(64, D) <= 80 * 1024 ? 2 : 1) vo
   // the halo of one channel chunk: which of the two concatenated sources it comes from is decided once per chunk
   // (HALO_SRC declares rs / off[] / soff for chunk `ch` as plain locals)
 #define HALO_SRC(rs, off, soff, ch)                                                                                        \
-  const bool rs##_second = (ch) * BK >= a.C0; /* wave-uniform */                                                           \
+  const bool rs##_second = !GNL && (ch) * BK >= a.C0; /* wave-uniform; GNL: single source (6 VGPRs of offsets less) */    \
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(                                                     \
       const_cast<half_t*>(rs##_second ? a.x1 : a.x0), 0, (int)(xpix * (rs##_second ? a.C1 : a.C0) * 2), 0x00020000);       \
   const int soff = (rs##_second ? (ch) * BK - a.C0 : (ch) * BK) * 2;                                                       \
@@ -1021,9 +1047,39 @@ __global__ __launch_bounds__(256, halo_lds_bytes(64, D) <= 80 * 1024 ? 2 : 1) vo
   _Pragma("unroll") for (int j_ = 0; j_ < HALO_PPW; ++j_) off[j_] = rs##_second ? hoff1[j_] : hoff0[j_];
   auto issue_x_piece = [&](int j, const __amdgpu_buffer_rsrc_t& rs, unsigned off, int soff, int xstage) {
     if constexpr ((DBG & 8) != 0) return;
-    const int p = wave + 4 * j;
-    char* dst = Xh + xstage * (HALO_LDS_ROWS * ROWB) + (p < HALO_PIECES ? p : HALO_PIECES - 1) * 1024;
+    char* dst = Xh + xstage * (HALO_LDS_ROWS * ROWB) + piece_of(j) * 1024;
     dma16_to_lds(rs, dst, off, soff);
+  };
+  // GNL: GroupNorm(+SiLU) of slot j of this wave, in place, in halo buffer `xstage` holding channel chunk `ch`.  Only called
+  // once the piece has landed (this wave's own DMA: no other wave touches these 16 bytes before the next barrier).
+  // Branch-free on purpose (selects, no exec-masked store): a tap step stays ONE basic block, so the MFMA / read / DMA interleaving
+  // of the loop body is still what the scheduler emits.
+  auto gn_transform = [&](int j, int xstage, int ch) {
+    if constexpr (GNL) {
+      char* pp = Xh + xstage * (HALO_LDS_ROWS * ROWB) + piece_of(j) * 1024 + lane * 16;
+      const half8 raw = *reinterpret_cast<const half8*>(pp);
+      half8 v = raw;
+      // the lane's channel group is the swizzled 16-B slot it fetched: bits 4-6 of its source offset (pixel offsets are multiples
+      // of 128 B); a lane outside the image (kOob) reads some row of the table and stores nothing
+      const int k0 = ch * BK + (int)((hoff0[j] >> 4) & 7u) * 8;
+      const half8 gm = *reinterpret_cast<const half8*>(gn_tab + k0);
+      const half8 gs = *reinterpret_cast<const half8*>(gn_tab + a.Ctot + k0);
+      const half8 gh = *reinterpret_cast<const half8*>(gn_tab + 2 * a.Ctot + k0);
+      v = __builtin_elementwise_fma(v - gm, gs, gh);   // rounding relative to |x - mean| (gemm_pipe_body GNF)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {                    // SiLU in fp32 (unet.py:474, :480: every GroupNorm in front of a 3x3 conv has one)
+        const float f = (float)v[e];
+        v[e] = (half_t)(f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * f)));
+      }
+      // what goes back: the raw bytes for a pixel outside the image (the DMA's zeros: the conv pads the NORMALISED tensor) and for
+      // wave 3's slot 4, whose piece slot 5 fetches a second time and transforms (a second landing after a transform here would
+      // put raw data back; transforming twice would be wrong; writing raw over raw is harmless)
+      const bool keep_raw = hoff0[j] == kOob || (j == HALO_PPW - 2 && wave + 4 * (HALO_PPW - 1) >= HALO_PIECES);
+      half8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = keep_raw ? raw[e] : v[e];
+      *reinterpret_cast<half8*>(pp) = o;
+    }
   };
   const int total_steps = (ch_end - ch_begin) * 9;
   int iw_koff = ch_begin * BK * 2, iw_tap = 0, iw_step = 0;   // issue cursor of the weight ring (koff in bytes)
@@ -1104,6 +1160,25 @@ __global__ __launch_bounds__(256, halo_lds_bytes(64, D) <= 80 * 1024 ? 2 : 1) vo
 
   half8 xfA[2][2], wfA[2][2], xfB[2][2], wfB[2][2];
   if (ch_begin < ch_end) {
+    // GNL prologue, part 1 (oldest VMEM ops of the wave, before the first DMA; inside this branch, so that no path reaches the
+    // join behind it with these loads outstanding - the compiler would drain vmcnt(0), ring and all, there): this sample's partial
+    // statistics - eight lanes per group, 16 entries (8 float4) each, entries <= 128; entries past the count are allocated but
+    // stale, so they are loaded unconditionally (no branch, no early wait) and masked - and gamma / beta of the channels whose
+    // table rows this thread writes
+    floatx4 gnl_v[GNL ? 8 : 1];
+    float gnl_g[GNL ? 8 : 1], gnl_b[GNL ? 8 : 1];
+    if constexpr (GNL) {
+      const int g = tid >> 3, j = tid & 7;
+      const floatx4* src = reinterpret_cast<const floatx4*>(a.gnf_partial + (((size_t)b * a.gnf_G + (g < a.gnf_G ? g : 0)) * kGnMaxSlabs + j * 16) * 2);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) gnl_v[k] = src[k];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = min(tid + 256 * i, a.Ctot - 1);
+        gnl_g[i] = a.gnf_gamma[k];
+        gnl_b[i] = a.gnf_beta[k];
+      }
+    }
     HALO_SRC(rs0, off0, soff0, ch_begin)
 #pragma unroll
     for (int j = 0; j < HALO_PPW; ++j) issue_x_piece(j, rs0, off0[j], soff0, 0);
@@ -1112,8 +1187,50 @@ __global__ __launch_bounds__(256, halo_lds_bytes(64, D) <= 80 * 1024 ? 2 : 1) vo
       asm volatile("" ::: "memory");                      // keep the DMA issue order: the counted wait below relies on it
       if (p < total_steps) issue_next_w();
     }
-    if (total_steps >= D) wait_vmcnt_barrier<(D - 1) * WR>();   // the first halo and weight tile 0 have landed
+    if constexpr (GNL) {
+      // part 2: fold (fixed order), statistics -> LDS, per-channel table -> LDS; the barrier below publishes it
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int e0 = (tid & 7) * 16 + 2 * k;            // first of the two entries of this float4
+        const bool l0 = e0 < a.gnf_entries, l1 = e0 + 1 < a.gnf_entries;
+        s += (l0 ? gnl_v[k][0] : 0.f) + (l1 ? gnl_v[k][2] : 0.f);
+        q += (l0 ? gnl_v[k][1] : 0.f) + (l1 ? gnl_v[k][3] : 0.f);
+      }
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) {
+        s += __shfl_xor(s, o);
+        q += __shfl_xor(q, o);
+      }
+      const int cpg = a.Ctot / a.gnf_G;
+      if ((tid & 7) == 0 && (tid >> 3) < a.gnf_G) {
+        const float inv_n = 1.0f / ((float)cpg * (float)(a.Hi * a.Wi));
+        const float mean = s * inv_n;
+        gn_stat[tid >> 3] = mean;
+        gn_stat[64 + (tid >> 3)] = rsqrtf(fmaxf(q * inv_n - mean * mean, 0.f) + a.gnf_eps);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = tid + 256 * i;
+        if (k < a.Ctot) {
+          const int g = k / cpg;
+          const float sc = gnl_g[i] * gn_stat[64 + g];
+          const half_t mh = (half_t)gn_stat[g];
+          gn_tab[k] = mh;
+          gn_tab[a.Ctot + k] = (half_t)sc;
+          gn_tab[2 * a.Ctot + k] = (half_t)(gnl_b[i] - (gn_stat[g] - (float)mh) * sc);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (total_steps >= D) wait_vmcnt_barrier<(D - 1) * WR>();   // the first halo and weight tile 0 have landed (GNL: and the table is visible)
     else wait_vmcnt_barrier<0>();
+    if constexpr (GNL) {   // the first chunk's halo: every wave normalises the pieces it fetched, then all of them meet
+#pragma unroll
+      for (int j = 0; j < HALO_PPW; ++j) gn_transform(j, 0, ch_begin);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
     read_step(xfA, wfA, Xh, Ws, 0);
   }
   int st = 0;
@@ -1142,15 +1259,33 @@ __global__ __launch_bounds__(256, halo_lds_bytes(64, D) <= 80 * 1024 ? 2 : 1) vo
           if (tap == 8) wait_vmcnt_barrier<((D - 2) * WR < 2 * WR ? (D - 2) * WR : 2 * WR)>();
           else wait_vmcnt_barrier<(D - 2) * WR>();
         }
-        else halo_ks_wait<D, WR>(tap);
+        else halo_ks_wait<D, WR, GNL>(tap);
         const int tapn = tap == 8 ? 0 : tap + 1;
         const char* xs = Xh + (tap == 8 ? xst ^ 1 : xst) * (HALO_LDS_ROWS * ROWB);
         const char* ws = Ws + ((unsigned)(st + 1) % D) * (BN * ROWB);
         read_step(nx, nw, xs, ws, tapn);                  // fragments of step st+1 -> the other register set
         const bool w_live = !LAST || tap + D < 9;
         if (w_live) issue_next_w();                       // weight tile st+D -> stage st % D
-        const bool x_live = !LAST && tap < HALO_PPW;
-        if (x_live) issue_x_piece(tap, rsn, offn[tap < HALO_PPW ? tap : 0], soffn, xst ^ 1);
+        if constexpr (GNL) {
+          if (!LAST) {
+            if (tap == 0) {
+              issue_x_piece(0, rsn, offn[0], soffn, xst ^ 1);
+              issue_x_piece(1, rsn, offn[1], soffn, xst ^ 1);
+            } else if (tap <= 4) {
+              issue_x_piece(tap + 1, rsn, offn[tap + 1 < HALO_PPW ? tap + 1 : 0], soffn, xst ^ 1);
+            }
+            // pieces issued in steps <= tap - 3 have landed behind the wait above (D <= 4): normalise them in place
+            if (tap == 3) {
+              gn_transform(0, xst ^ 1, ch + 1);
+              gn_transform(1, xst ^ 1, ch + 1);
+            } else if (tap >= 4 && tap <= 7) {
+              gn_transform(tap - 2, xst ^ 1, ch + 1);
+            }
+          }
+        } else {
+          const bool x_live = !LAST && tap < HALO_PPW;
+          if (x_live) issue_x_piece(tap, rsn, offn[tap < HALO_PPW ? tap : 0], soffn, xst ^ 1);
+        }
         mfma_step(cx, cw);
         // issue order: an MFMA, then two of the next step's reads ... the DMA pieces behind the later MFMAs
         if constexpr (DBG == 0) {
@@ -2315,13 +2450,20 @@ Plan choose_plan(const ConvDesc& d, const IgemmArgs& a) {
 }
 
 // staging (the table's ring code): 0 = 2 weight stages (two workgroups per CU), 2 / 3 = 3 / 4 stages, 4 / 5 = 6 / 8 stages
-template <int D, int DBG = 0>
+// GNL: the [3][Ctot] fp16 GroupNorm table takes the place of the epilogue constants behind the ring (conv3x3_halo_ks_kernel)
+constexpr size_t halo_gnl_lds_cap = 160 * 1024;
+inline size_t halo_gnl_lds_bytes(int d, int ctot) {
+  const size_t k_loop = halo_lds_bytes(64, d) - 64 * sizeof(float) + (((size_t)6 * ctot + 15) & ~(size_t)15);
+  const size_t epilogue = 32 * 1024 + 128 * (64 + 8) * 2 + 64 * sizeof(float);
+  return std::max(k_loop, epilogue);
+}
+template <int D, int DBG = 0, bool GNL = false>
 void launch_halo_ks_d(const IgemmArgs& a, hipStream_t s) {
-  const size_t lds = halo_lds_bytes(64, D);
+  const size_t lds = GNL ? halo_gnl_lds_bytes(D, a.Ctot) : halo_lds_bytes(64, D);
   static_assert(halo_lds_bytes(64, D) <= 160 * 1024, "LDS");
-  auto k = conv3x3_halo_ks_kernel<D, DBG>;
+  auto k = conv3x3_halo_ks_kernel<D, DBG, GNL>;
   static DynLdsOnce once;
-  once.set(k, lds);
+  once.set(k, GNL ? halo_gnl_lds_cap : lds);   // GNL: the table grows with Ctot - allow the full LDS once
   dim3 grid(a.B * a.tiles_x * a.tiles_y * cdiv(a.N, 64), a.splitk);
   hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
 }
@@ -2345,6 +2487,11 @@ void launch_halo_ks(IgemmArgs a, int splitk, int staging, hipStream_t s) {
       case 15: launch_halo_ks_d<4, 15>(a, s); return;
       default: break;
     }
+  }
+  if (a.gnf_partial) {   // GroupNorm in the loader: rings of 3 / 4 stages only (launch_conv checked the shape)
+    if (staging >= 3 && halo_gnl_lds_bytes(4, a.Ctot) <= halo_gnl_lds_cap) launch_halo_ks_d<4, 0, true>(a, s);
+    else launch_halo_ks_d<3, 0, true>(a, s);
+    return;
   }
   if (staging >= 5) { launch_halo_ks_d<8>(a, s); return; }
   if (staging >= 4) { launch_halo_ks_d<6>(a, s); return; }
@@ -2631,6 +2778,15 @@ void choose_tile_order(IgemmArgs& a, int tile) {
 }
 }  // namespace
 
+// GroupNorm(+SiLU) of the input applied in the loader of the 3x3 halo kernel (ConvDesc::gnf_* on a ksize-3 conv): shapes it takes
+bool conv_gn_loader_ok(const ConvDesc& d) {
+  const int c1 = d.x1 ? d.C1 : 0;
+  const int ctot = d.C0 + c1;
+  return d.ksize == 3 && d.stride == 1 && d.up == 1 && halo_ks_ok(d) && !d.ln_colsum && !d.out_t && d.out_mode == kOutHalf && !d.debug &&
+         d.gnf_groups >= 1 && d.gnf_groups <= 32 && ctot % d.gnf_groups == 0 && ctot <= 2048 && d.Hi == d.Ho && d.Wi == d.Wo &&
+         halo_gnl_lds_bytes(3, ctot) <= halo_gnl_lds_cap;
+}
+
 int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
   SD_REQUIRE(conv_fast_path_ok(d), kInvalidArgument, "launch_conv: shape not MFMA-tileable (C0=%d C1=%d N=%d k=%d)",
              d.C0, d.C1, d.N, d.ksize);
@@ -2643,11 +2799,17 @@ int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
   SD_REQUIRE(d.q_cols == 0 || (d.out_t && d.q_cols % 4 == 0 && d.q_cols <= d.n_trans), kInvalidArgument, "pre-scaled queries need the fused q|k|v epilogue (q_cols %d)", d.q_cols);
   IgemmArgs a = make_args(d);
   Plan p = choose_plan(d, a);
-  const bool halo = p.tile == 7;
+  bool halo = p.tile == 7;
   const bool twins = d.n_twins > 0;
   SD_REQUIRE(!twins || (d.out_mode == kOutHalf && !d.ln_colsum && !d.out_t && !d.debug && reduce_twin_ok(a.HoWo, a.N, d.n_twins, d.twin)),
              kInvalidArgument, "GroupNorm twins need a plain fp16 output and whole (sample, group) slices (HoWo=%d N=%d)", a.HoWo, a.N);
-  if (d.gnf_partial) {   // GroupNorm folded into this 1x1 GEMM: gemm_pipe_kernel's 64 x 64 tile (the only GNF instantiation)
+  if (d.gnf_partial && d.ksize == 3) {   // GroupNorm(+SiLU) applied in the halo loader of the K-split 3x3 kernel (GNL)
+    SD_REQUIRE(conv_gn_loader_ok(d) && d.gnf_silu == 1 && d.gnf_gamma && d.gnf_beta && d.gnf_entries >= 1 && d.gnf_entries <= 128 && !twins, kInvalidArgument,
+               "GroupNorm in the conv loader: Ctot=%d groups=%d entries=%d up=%d", a.Ctot, d.gnf_groups, d.gnf_entries, d.up);
+    p.tile = 7;
+    if (p.staging != 2 && p.staging != 3) p.staging = 3;
+    p.splitk = 1;
+  } else if (d.gnf_partial) {   // GroupNorm folded into this 1x1 GEMM: gemm_pipe_kernel's 64 x 64 tile (the only GNF instantiation)
     SD_REQUIRE(d.ksize == 1 && d.stride == 1 && !d.x1 && d.out_mode == kOutHalf && !d.ln_colsum && !d.out_t && !twins && gemm_pipe_ok(a) &&
                    d.gnf_gamma && d.gnf_beta && d.gnf_groups >= 1 && d.gnf_groups <= 32 && a.K % d.gnf_groups == 0 && a.K <= 2048 &&
                    d.gnf_entries >= 1 && d.gnf_entries <= 128 && a.HoWo % 64 == 0,
@@ -2656,6 +2818,7 @@ int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
     if (p.staging != 6 && p.staging != 7 && p.staging != 8) p.staging = 6;
     p.splitk = 1;
   }
+  halo = p.tile == 7;
   if (p.tile == 9) {
     // weight-streaming kernel: slabs, then the group-organised combine (with the consumer's GroupNorm twins) or the plain one
     const int nw = p.staging == 4 ? 4 : 8;

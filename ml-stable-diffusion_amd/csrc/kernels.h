@@ -80,6 +80,11 @@ struct ConvDesc {
   const float* gnf_beta = nullptr;
   float gnf_eps = 1e-6f;
   int gnf_groups = 0, gnf_entries = 0;
+  // The same fields on a 3x3 / stride-1 conv (round 5): GroupNorm + SiLU (gnf_silu must be 1) of the input applied in the halo LOADER of
+  // conv3x3_halo_ks_kernel (ResnetBlock2D norm1 -> conv1, norm2 -> conv2: unet.py:472-481) - every wave normalises the halo pieces
+  // it fetched, in LDS, once per workgroup; pixels outside the image stay zero (the conv pads the normalised tensor).  Shapes:
+  // conv_gn_loader_ok; the concatenated channel count indexes gamma / beta / the partials.
+  int gnf_silu = 0;
   // weights in the fragment-major layout of wstream.hip (launch_wstream_retile), or null: plan tile 9 needs them
   const half_t* w_tiled = nullptr;
   // n_twins > 0: the output leaves through fp32 slabs and reduce_twin_kernel, which also writes the GroupNorm twins
@@ -100,6 +105,7 @@ size_t conv_workspace_bytes(const ConvDesc& d);
 // returns the number of GroupNorm partial entries per (sample, group) written to d.gn_partial (0: none)
 int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s);
 bool conv_fast_path_ok(const ConvDesc& d);
+bool conv_gn_loader_ok(const ConvDesc& d);   // gnf_* on a 3x3 conv (gnf_groups set): the halo kernel can normalise this input in its loader
 // tuning hook: plan (tile 1-6, staging 0-5, splitk) forced on every conv that admits it; tile 0 = off
 void conv_tune_set_candidate(int tile, int staging, int splitk);
 int conv_plan_table_set(const char* text);   // rows of tuned_convs.inc format; returns the number of plans read

@@ -273,6 +273,7 @@ Tensor UNet::conv_w(std::vector<Op>& ops, const std::string& name, const half_t*
   d.out_mode = out_mode;
   d.ldT = ldT;
   Tensor out;
+  std::string gn_in_name;   // set when a queued GroupNorm (pending_gn_in_) became part of this op
   if (ex) d.ln_colsum = ex->ln_colsum;
   if (ex) d.vt_perm = ex->vt_perm ? 1 : 0;
   if (ex) {
@@ -345,10 +346,36 @@ Tensor UNet::conv_w(std::vector<Op>& ops, const std::string& name, const half_t*
       hook->desc = d;
     }
     ws_need_ = std::max(ws_need_, conv_workspace_bytes(d));
-    ops.push_back([this, d, hook, with_hook](hipStream_t s) {
-      const int n = launch_conv(with_hook(d), ws_conv_, s);
-      if (hook) hook->produced(n);
-    });
+    std::shared_ptr<GnIn> gi = std::move(pending_gn_in_);
+    pending_gn_in_.reset();
+    if (gi) {   // x is the UN-normalised tensor (gn_loader_conv checked the shape)
+      gn_in_name = gi->norm_name;
+      const half_t* xp = x.p;
+      const int C = x.C, B = x.B, HW = x.H * x.W;
+      ops.push_back([this, d, hook, with_hook, gi, xp, C, B, HW](hipStream_t s) {
+        ConvDesc dd = with_hook(d);
+        const int e = gi->hook->consume();
+        if (e >= 1 && e <= 128) {   // the producer left its statistics: GroupNorm(+SiLU) in the halo loader
+          dd.gnf_partial = gi->partial;
+          dd.gnf_gamma = gi->gamma;
+          dd.gnf_beta = gi->beta;
+          dd.gnf_eps = gi->eps;
+          dd.gnf_groups = gi->groups;
+          dd.gnf_entries = e;
+          dd.gnf_silu = gi->silu;
+        } else {                    // split-K / ragged producer: the GroupNorm launch, then the plain conv
+          launch_groupnorm(xp, C, nullptr, 0, gi->partial, gi->gamma, gi->beta, gi->y, B, HW, gi->groups, gi->eps, gi->silu, s, e);
+          dd.x0 = gi->y;
+        }
+        const int n = launch_conv(dd, ws_conv_, s);
+        if (hook) hook->produced(n);
+      });
+    } else {
+      ops.push_back([this, d, hook, with_hook](hipStream_t s) {
+        const int n = launch_conv(with_hook(d), ws_conv_, s);
+        if (hook) hook->produced(n);
+      });
+    }
   } else {
     const int so = silu_out ? 1 : 0;
     ops.push_back([d, so, hook, with_hook](hipStream_t s) {
@@ -356,15 +383,21 @@ Tensor UNet::conv_w(std::vector<Op>& ops, const std::string& name, const half_t*
       if (hook) hook->produced(n);
     });
   }
+  SD_REQUIRE(!pending_gn_in_, kInternal, "%s: a GroupNorm was queued for a conv that cannot take it", name.c_str());
   {
     const int cin = x.C + (x2 ? x2->C : 0);
-    char buf[256];
+    char buf[320];
     // trailing "#kind,ksize,stride,up,Ctot,N,M" is the plan-table key of this op (tools/tune_plans.py)
     const int kind = d.out_t ? 3 : (geglu ? 2 : (d.ln_colsum ? 1 : 0));
     snprintf(buf, sizeof(buf), "%s%s %d->%d @%dx%d M=%d K=%d %s #%d,%d,%d,%d,%d,%d,%d", k == 3 ? "conv3x3" : (geglu ? "geglu1x1" : "gemm1x1"),
              ex && ex->ln_colsum ? "+ln" : "", cin, cout, d.Ho, d.Wo, x.B * d.Ho * d.Wo, cin * k * k, name.c_str(), kind, k,
              stride, up, cin, cout, x.B * d.Ho * d.Wo);
     ops.back().label = buf;
+    if (!gn_in_name.empty()) {   // "... <conv name> +gn(<norm name>) #key": the family prefix and the plan key stay where the tools look
+      std::string l = buf;
+      const size_t at = l.rfind(" #");
+      ops.back().label = l.substr(0, at) + " +gn(" + gn_in_name + ")" + l.substr(at);
+    }
     ops.back().flop = 2.0 * x.B * d.Ho * d.Wo * (double)cout * cin * k * k;
   }
   return out;
@@ -524,11 +557,23 @@ Tensor UNet::resnet(std::vector<Op>& ops, const std::string& p, const Tensor& x,
       t0 = group_norm(ops, p + ".norm1", x, x2, cfg_.norm_eps, true, &sd, buf, 2.0 * x.M() * (double)cout * cin);
     }
   }
-  if (!side_out) t0 = group_norm(ops, p + ".norm1", x, x2, cfg_.norm_eps, true);
   const float* temb = has_temb ? register_temb(p + ".time_emb_proj", cout) : nullptr;
-  if (temb && temb_join_pos_ < 0 && &ops == &main_ops_) temb_join_pos_ = (int)ops.size();   // first consumer of the time path
-  Tensor h = conv(ops, p + ".conv1", t0, nullptr, cout, 3, 1, 1, true, temb, nullptr);
-  Tensor t1 = group_norm(ops, p + ".norm2", h, nullptr, cfg_.norm_eps, true);
+  // norm1 -> SiLU -> conv1 and norm2 -> SiLU -> conv2 as ONE op each where the 3x3 kernel can normalise its input in the halo loader
+  // (gn_loader_conv; SD_GN_LOADER with SD_TUNE).  norm1 keeps its own launch when it carries the shortcut GEMM or a concat.
+  Tensor h;
+  bool conv1_done = false;
+  if (!side_out && !x2) {
+    if (temb && temb_join_pos_ < 0 && &ops == &main_ops_) temb_join_pos_ = (int)ops.size();
+    conv1_done = gn_loader_conv(ops, p + ".norm1", p + ".conv1", x, cout, temb, nullptr, &h);
+  }
+  if (!conv1_done) {
+    if (!side_out) t0 = group_norm(ops, p + ".norm1", x, x2, cfg_.norm_eps, true);
+    if (temb && temb_join_pos_ < 0 && &ops == &main_ops_) temb_join_pos_ = (int)ops.size();   // first consumer of the time path
+    h = conv(ops, p + ".conv1", t0, nullptr, cout, 3, 1, 1, true, temb, nullptr);
+  }
+  const bool fuse2 = gn_loader_ok(ops, h, cout);          // norm2 inside conv2's loader
+  Tensor t1;
+  if (!fuse2) t1 = group_norm(ops, p + ".norm2", h, nullptr, cfg_.norm_eps, true);
   const half_t* shortcut;
   if (side_out) {
     shortcut = side_out;
@@ -539,7 +584,54 @@ Tensor UNet::resnet(std::vector<Op>& ops, const std::string& p, const Tensor& x,
     SD_REQUIRE(x2 == nullptr, kInternal, "%s: concat input with identity shortcut", p.c_str());
     shortcut = x.p;
   }
+  if (fuse2) {
+    Tensor out2;
+    SD_REQUIRE(gn_loader_conv(ops, p + ".norm2", p + ".conv2", h, cout, nullptr, shortcut, &out2), kInternal, "%s: norm2 -> conv2", p.c_str());
+    return out2;
+  }
   return conv(ops, p + ".conv2", t1, nullptr, cout, 3, 1, 1, true, nullptr, shortcut);
+}
+
+bool UNet::gn_loader_ok(const std::vector<Op>& ops, const Tensor& x, int cout) const {
+  static const int mode = tune_env_int("SD_GN_LOADER", 0);
+  static const int min_hw = tune_env_int("SD_GN_LOADER_MIN_HW", 1024);
+  const int G = cfg_.norm_num_groups, C = x.C, HW = x.H * x.W;
+  if (mode == 0 || f32_ || HW < min_hw || C % G != 0 || (C / G) > 64) return false;
+  if (!x.gn || x.gn->partial || x.gn->n_twins != 0 || x.gn->ops_list != &ops) return false;   // the raw tensor's producer must be able to leave statistics
+  ConvDesc d;
+  d.x0 = x.p;
+  d.C0 = C;
+  d.B = x.B;
+  d.Hi = d.Ho = x.H;
+  d.Wi = d.Wo = x.W;
+  d.N = cout;
+  d.ksize = 3;
+  d.gnf_groups = G;
+  return conv_fast_path_ok(d) && conv_gn_loader_ok(d);
+}
+
+// GroupNorm(+SiLU) -> 3x3 conv as one op: the conv's halo loader normalises (conv3x3_halo_ks_kernel GNL) when x's producer left
+// the statistics; VERDICT r4 item 2c.  SD_GN_LOADER=1 (with SD_TUNE) switches it on for levels of at least SD_GN_LOADER_MIN_HW
+// pixels (default 1024: the 64x64 / 32x32 levels); measured in LAB_NOTES.md r5.
+bool UNet::gn_loader_conv(std::vector<Op>& ops, const std::string& norm, const std::string& cv, const Tensor& x, int cout, const float* temb,
+                          const half_t* res, Tensor* out) {
+  if (!gn_loader_ok(ops, x, cout)) return false;
+  const int G = cfg_.norm_num_groups, C = x.C, HW = x.H * x.W;
+  auto gi = std::make_shared<GnIn>();
+  gi->hook = x.gn;
+  gi->partial = arena_.alloc_n<float>(groupnorm_scratch_floats(x.B, HW, G));
+  gi->hook->partial = gi->partial;
+  gi->hook->groups = G;
+  gi->gamma = upload_vec(norm + ".weight", C);
+  gi->beta = upload_vec(norm + ".bias", C);
+  gi->y = new_tensor(x.B, x.H, x.W, C).p;
+  gi->eps = cfg_.norm_eps;
+  gi->groups = G;
+  gi->silu = 1;
+  gi->norm_name = norm;
+  pending_gn_in_ = gi;
+  *out = conv(ops, cv, x, nullptr, cout, 3, 1, 1, true, temb, res);
+  return true;
 }
 
 Tensor UNet::attention(std::vector<Op>& ops, const Tensor& q, const half_t* k, const half_t* vt, int heads, int Sq,

@@ -164,6 +164,23 @@ class UNet {
   const WeightStore* ws_ = nullptr;   // only valid during construction
   int device_ = 0;
   bool f32_ = false;                  // VAE handle with cfg.compute_fp32: fp32 activations on the vae_f32.hip kernels
+  // build time: the GroupNorm(+SiLU) in front of the next conv_w (UNet::gn_loader_conv): applied in the 3x3 kernel's halo loader when
+  // the producer of the raw tensor left its statistics, else by a GroupNorm launch inside the same op (ConvDesc::gnf_* on ksize 3)
+  struct GnIn {
+    std::shared_ptr<GnHook> hook;   // producer of the raw input
+    float* partial = nullptr;
+    const float* gamma = nullptr;
+    const float* beta = nullptr;
+    half_t* y = nullptr;            // normalised tensor of the fallback path
+    float eps = 1e-5f;
+    int groups = 32, silu = 1;
+    std::string norm_name;
+  };
+  std::shared_ptr<GnIn> pending_gn_in_;
+  // norm -> SiLU -> 3x3 conv as ONE op; false when the shape / the build does not admit it (then the caller builds the two ops)
+  bool gn_loader_conv(std::vector<Op>& ops, const std::string& norm, const std::string& cv, const Tensor& x, int cout, const float* temb,
+                      const half_t* res, Tensor* out);
+  bool gn_loader_ok(const std::vector<Op>& ops, const Tensor& x, int cout) const;
   bool w_f32_pending_ = false;        // build time: the weight pointer handed to conv_w holds fp32 values (UNet::conv on an fp32 handle)
   hipStream_t stream_ = nullptr;
   // SD_SIDE_TIME=1 (experiment, off by default): the time-embedding chain (depends only on the timestep)

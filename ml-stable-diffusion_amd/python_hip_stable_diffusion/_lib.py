@@ -95,6 +95,8 @@ SYMBOLS = [
     ("sd_op_conv2d", _I, [_P, _P, _FP, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _FP]),
     ("sd_op_conv2d_groupnorm", _I, [_P, _P, _FP, _P, _FP, _FP, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, C.POINTER(_I), _I, _FP]),
     ("sd_op_conv2d_groupnorm_proj", _I, [_P, _P, _FP, _P, _FP, _FP, _P, _FP, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, C.POINTER(_I), _I, _FP]),
+    ("sd_op_conv2d_groupnorm_conv3x3", _I, [_P, _P, _FP, _P, _FP, _FP, _P, _FP, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _I,
+                                            C.POINTER(_I), _I, _FP]),
     ("sd_op_cross_attention_fused", _I, [_P, _FP, _FP, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _FP]),
     ("sd_op_geglu", _I, [_P, _P, _FP, _P, _I, _I, _I, _I, _FP]),
     ("sd_op_timestep_embedding", _I, [_FP, _FP, _I, _I, _I, _F]),
@@ -275,6 +277,30 @@ def conv2d_groupnorm_proj(x, w, gn_weight, gn_bias, proj_w, proj_bias=None, bias
     check(lib().sd_op_conv2d_groupnorm_proj(ptr(x), ptr(w), fptr(bias), ptr(res), fptr(gn_weight), fptr(gn_bias), ptr(proj_w),
                                             fptr(proj_bias), ptr(conv_out), ptr(out), B, Cin, H, W, Cout, k, Np, groups, eps,
                                             int(fold), tile, C.byref(entries), iters, C.byref(ms)))
+    return conv_out, out, entries.value, ms.value
+
+
+def conv2d_groupnorm_conv3x3(x, w, gn_weight, gn_bias, w2, bias2=None, res2=None, bias=None, res=None, groups=32, eps=1e-5, silu=True,
+                             fold=True, tile=0, staging2=0, iters=1):
+    """conv3x3(silu(GroupNorm(conv(x)))) - a resnet's norm -> SiLU -> conv behind its producer; fold=True applies the GroupNorm
+    (+ SiLU) in the halo loader of the second conv.  Returns (conv_out, out, entries consumed by the loader, ms)."""
+    x, w, w2 = f16(x), f16(w), f16(w2)
+    B, Cin, H, W = x.shape
+    Cout, k = w.shape[0], w.shape[2]
+    N2 = w2.shape[0]
+    if w.shape[1] != Cin or w2.shape[1:] != (Cout, 3, 3):
+        raise ValueError("conv2d_groupnorm_conv3x3: inconsistent shapes")
+    gn_weight, gn_bias = f32(gn_weight), f32(gn_bias)
+    bias = None if bias is None else f32(bias)
+    bias2 = None if bias2 is None else f32(bias2)
+    res = None if res is None else f16(res)
+    res2 = None if res2 is None else f16(res2)
+    conv_out = np.empty((B, Cout, H, W), np.float16)
+    out = np.empty((B, N2, H, W), np.float16)
+    ms, entries = C.c_float(0), C.c_int(0)
+    check(lib().sd_op_conv2d_groupnorm_conv3x3(ptr(x), ptr(w), fptr(bias), ptr(res), fptr(gn_weight), fptr(gn_bias), ptr(w2), fptr(bias2),
+                                               ptr(res2), ptr(conv_out), ptr(out), B, Cin, H, W, Cout, k, N2, groups, eps, int(silu),
+                                               int(fold), tile, staging2, C.byref(entries), iters, C.byref(ms)))
     return conv_out, out, entries.value, ms.value
 
 

@@ -413,3 +413,61 @@ def test_shortcut_gemm_too_small_for_the_side_launch_is_refused():
     g = np.ones(128, np.float32)
     with pytest.raises(NotImplementedError):
         _lib.groupnorm_shortcut(x0, None, g, g, h16(rs.randn(64, 128)), side=True)
+
+
+# ---------------------------------------------------------------- GroupNorm(+SiLU) in the 3x3 conv's halo loader
+GNL_CASES = [  # (B, Cin, H, W, C, producer k, N2, staging of the 3x3 conv, silu, group mean offset)
+    (2, 320, 64, 64, 320, 3, 320, 3, True, 0.0),    # SD2.1-base level 0: conv1 -> norm2 -> SiLU -> conv2 at full size, 4-stage ring, two workgroups per CU
+    (2, 640, 32, 32, 640, 3, 640, 3, True, 0.0),    # level 1 (table 3.8 KB: one workgroup per CU)
+    (2, 320, 64, 64, 320, 1, 320, 2, True, 0.0),    # 3-stage ring; 1x1 producer (attention to_out -> next resnet's norm1 -> conv1)
+    (1, 64, 16, 16, 64, 1, 128, 3, True, 0.0),      # ONE channel chunk: the prologue's transform only, 2 channels per group
+    (2, 128, 16, 16, 128, 3, 64, 3, True, 0.0),     # two chunks
+    (3, 192, 16, 16, 192, 3, 192, 2, True, 0.0),    # three chunks, odd batch, 6 channels per group (groups straddle the 8-channel runs)
+    (2, 128, 24, 24, 128, 3, 128, 3, True, 0.0),    # 24 x 24: ragged 8 x 16 tiles - halo pixels beyond the image on every side must stay zero
+    (2, 128, 32, 32, 128, 3, 128, 3, True, 6.0),    # groups far from zero (|mean| ~ 6 sigma): the subtraction-first form keeps its digits
+    (2, 256, 8, 16, 256, 3, 256, 3, True, 0.0),     # a single tile row per image, four chunks
+]
+
+
+@pytest.mark.parametrize("case", GNL_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_groupnorm_in_the_conv_halo_loader(case):
+    """ResnetBlock2D norm -> SiLU -> 3x3 conv as ONE launch (unet.py:472-481): the GroupNorm statistics come from the producing
+    conv's epilogue, every wave of conv3x3_halo_ks_kernel<D, 0, GNL> normalises the halo pieces it fetched, in LDS, and the conv's
+    zero padding applies to the NORMALISED tensor.  Checked against fp32 torch on the producer output the kernel itself wrote, and
+    against the GroupNorm launch + plain conv pair."""
+    b, cin, hh, ww, c, k, n2, st2, silu, off = case
+    rs = np.random.RandomState(cin + c + hh + 3 * ww + b + n2)
+    x = h16(rs.randn(b, cin, hh, ww))
+    w = h16(rs.randn(c, cin, k, k) / np.sqrt(cin * k * k))
+    bias = (0.1 * rs.randn(c)).astype(np.float32) + off * np.repeat(rs.randn(32), c // 32).astype(np.float32)
+    gw = (1.0 + 0.2 * rs.randn(c)).astype(np.float32)
+    gb = (0.2 * rs.randn(c)).astype(np.float32)
+    w2 = h16(rs.randn(n2, c, 3, 3) / np.sqrt(c * 9))
+    b2 = (0.1 * rs.randn(n2)).astype(np.float32)
+    res2 = h16(rs.randn(b, n2, hh, ww) * 0.5)
+    kw = dict(bias2=b2, res2=res2, bias=bias, groups=32, eps=1e-5, silu=silu, staging2=st2)
+    conv_a, out_a, entries, _ = _lib.conv2d_groupnorm_conv3x3(x, w, gw, gb, w2, fold=True, **kw)
+    conv_b, out_b, none, _ = _lib.conv2d_groupnorm_conv3x3(x, w, gw, gb, w2, fold=False, **kw)
+    assert entries >= 1 and none == 0, (entries, none)
+    assert np.array_equal(conv_a, conv_b)
+    z = F.group_norm(torch.from_numpy(conv_a.astype(np.float32)), 32, torch.from_numpy(gw), torch.from_numpy(gb), 1e-5)
+    if silu:
+        z = F.silu(z)
+    y = (F.conv2d(z, torch.from_numpy(w2.astype(np.float32)), torch.from_numpy(b2), padding=1) + torch.from_numpy(res2.astype(np.float32))).numpy()
+    close(out_b, y, f"GroupNorm launch + conv {case}")
+    close(out_a, y, f"GroupNorm in the halo loader {case}")
+    _, again, _, _ = _lib.conv2d_groupnorm_conv3x3(x, w, gw, gb, w2, fold=True, iters=3, **kw)
+    assert np.array_equal(out_a, again)
+
+
+def test_groupnorm_in_the_loader_refuses_what_it_cannot_take():
+    rs = np.random.RandomState(5)
+    x = h16(rs.randn(1, 64, 4, 4))               # 4 x 4 image: below the halo kernel's 8 x 8
+    w = h16(rs.randn(64, 64, 1, 1) / 8)
+    w2 = h16(rs.randn(64, 64, 3, 3) / 24)
+    g = np.ones(64, np.float32)
+    with pytest.raises(NotImplementedError):
+        _lib.conv2d_groupnorm_conv3x3(x, w, g, g, w2, fold=True)
+    x = h16(rs.randn(1, 64, 16, 16))
+    with pytest.raises(NotImplementedError):     # no SiLU: the loader has no such form (no GroupNorm of the graph needs it)
+        _lib.conv2d_groupnorm_conv3x3(x, w, g, g, w2, silu=False, fold=True)

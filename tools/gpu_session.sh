@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box session, parameterised (replaces the per-session scripts of rounds 1-2):
 #   tools/gpu_session.sh <tag> <step> [<step> ...]
-# steps: new (round-3 kernel tests)  tests (full -m gpu suite)  smoke  bench  bench:<flags>  ab:<ENV=VAL> (bench with an env switch)  pmc
+# steps: epytest:<ENV=VAL,..>@<selection>  eprofile:<ENV=VAL,..>  new (round-3 kernel tests)  tests (full -m gpu suite)  smoke  bench  bench:<flags>  ab:<ENV=VAL> (bench with an env switch)  pmc
 #        profile (per-op table)  trace (rocprofv3 kernel trace of the bench)  py:<script and args> (python tools/<script>)
 # Logs go to gpurun_out/<name>_<tag>.*; a one-line verdict per step is echoed (what gpurun shows at the end).
 set -u
@@ -56,6 +56,14 @@ for step in "$@"; do
       sel=${step#pytest:}
       timeout 1700 python -m pytest $sel -m gpu -q -x > $OUT/pytest_${TAG}_$i.log 2>&1; note "pytest[$sel] rc=$? $(tail -n 1 $OUT/pytest_${TAG}_$i.log | cut -c1-200)"
       grep -E "^(FAILED|ERROR)|Error|assert" $OUT/pytest_${TAG}_$i.log | head -n 12 | cut -c1-400 ;;
+    epytest:*)   # a test selection under env switches: "epytest:ENV=VAL,ENV2=VAL2@<selection>"
+      kv=${step#epytest:}; sel=${kv#*@}; kv=${kv%%@*}
+      env ${kv//,/ } timeout 1700 python -m pytest $sel -m gpu -q -x > $OUT/pytest_${TAG}_$i.log 2>&1; note "pytest[$kv $sel] rc=$? $(tail -n 1 $OUT/pytest_${TAG}_$i.log | cut -c1-200)"
+      grep -E "^(FAILED|ERROR)|Error|assert" $OUT/pytest_${TAG}_$i.log | head -n 12 | cut -c1-400 ;;
+    eprofile:*)   # per-op table under env switches: "eprofile:ENV=VAL,ENV2=VAL2"
+      kv=${step#eprofile:}
+      env ${kv//,/ } timeout 300 python tools/op_profile.py $OUT/op_profile_${TAG}_$i.json 2 ORIGINAL > $OUT/op_profile_${TAG}_$i.txt 2>&1; note "profile[$kv] rc=$? $(sed -n 2p $OUT/op_profile_${TAG}_$i.txt)"
+      grep -E "conv3x3|groupnorm" $OUT/op_profile_${TAG}_$i.txt | head -n 30 | cut -c1-140 ;;
     tune:*)   # end-to-end plan tuner: "tune:<candidates.json> [model] [latent]" -> gpurun_out/tuned_e2e_<tag>.inc
       ar=${step#tune:}
       SD_TUNE=1 timeout 1200 python tools/tune_e2e.py ${ar%% *} $OUT/tuned_e2e_$TAG.inc $OUT/tune_e2e_report_$TAG.json $( [ "$ar" != "${ar#* }" ] && echo ${ar#* } ) > $OUT/tune_e2e_$TAG.log 2>&1; note "tune_e2e rc=$?"
