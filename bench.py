@@ -278,25 +278,34 @@ def main():
         dist.destroy_process_group()
 
 
-# Reference calibration: the box every `value_normalised` is expressed on (CALIB_REF) and how much of the step time follows each
-# calibration figure (CALIB_WEIGHTS, fitted over the boxes of round 5: profiles/r05_calibration_fit.txt).
-CALIB_REF = {"copy_gbs": 4800.0, "mfma_tflops": 1600.0, "empty_launch_us": 2.0, "chain_us": 6.0}
-CALIB_WEIGHTS = {"chain_us": 1.0}
+# Reference calibration: the box every `value_normalised` is expressed on (CALIB_REF: the 4.52-4.53-ms boxes of round 5's sessions
+# A / B) and how much of the step time follows each calibration figure (CALIB_WEIGHTS; tools/calib_fit.py writes
+# profiles/r05_calibration_fit.txt from the sessions' records).  Empty weights = no figure has been shown to separate the boxes yet:
+# `value_normalised` is then null - a made-up normalisation would be worse than none.
+CALIB_REF = {"copy_gbs": 4750.0, "mfma_tflops": 2030.0, "empty_launch_us": 1.55, "chain_us": 3.62, "handover_us": 6.52,
+             "latency_hbm_ns": 360.0, "latency_cache_ns": 72.0}
+CALIB_WEIGHTS = {}
 
 
 def normalised(value, calib):
     """`value` as the reference box would have measured it: the step time is modelled as a weighted sum of terms that scale with
     the box's calibration figures (time-like figures directly, rate-like figures inversely); `value` itself stays raw."""
-    scale = 0.0
-    for k, w in CALIB_WEIGHTS.items():
-        ratio = calib[k] / CALIB_REF[k] if k.endswith("_us") else CALIB_REF[k] / calib[k]
-        scale += w * ratio            # > 1: this box is slower than the reference on that term
-    return {"calibration": dict(calib, reference=CALIB_REF, weights=CALIB_WEIGHTS,
-                                note="calib.hip: 1-GiB copy GB/s, dense MFMA loop TFLOP/s, us per launch of a 323-launch empty graph, us per "
-                                     "launch of a 323-launch chain of short kernels on cold operands; measured before the warm-up"),
-            "value_normalised": round(value * scale, 3),
-            "value_normalised_note": "value x (this box's modelled step time / the reference box's): comparable across boxes of the pool; "
-                                     "`value` is the raw measurement"}
+    scale = None
+    if CALIB_WEIGHTS:
+        scale = 0.0
+        for k, w in CALIB_WEIGHTS.items():
+            time_like = k.endswith("_us") or k.endswith("_ns")
+            scale += w * (calib[k] / CALIB_REF[k] if time_like else CALIB_REF[k] / calib[k])   # > 1: this box is slower on that term
+    ratios = {k: round((calib[k] / CALIB_REF[k]) if (k.endswith("_us") or k.endswith("_ns")) else (CALIB_REF[k] / calib[k]), 4)
+              for k in CALIB_REF if k in calib and calib[k]}
+    return {"calibration": dict(calib, reference=CALIB_REF, weights=CALIB_WEIGHTS, slowdown_vs_reference=ratios,
+                                note="calib.hip, measured before the warm-up: 1-GiB copy GB/s, dense MFMA loop TFLOP/s, us per launch of a "
+                                     "323-launch empty graph / of a 323-launch chain of short kernels on cold operands / of a chain handing 8 MB "
+                                     "over between the XCDs' L2s, ns per dependent load from HBM / from the caches; slowdown_vs_reference > 1 = "
+                                     "this box is slower than the reference box on that figure"),
+            "value_normalised": None if scale is None else round(value * scale, 3),
+            "value_normalised_note": "value x (this box's modelled step time / the reference box's), weights from profiles/r05_calibration_fit.txt; "
+                                     "null while no calibration figure has been shown to track the boxes' step-time spread; `value` is the raw measurement"}
 
 
 def concurrent_prompts(model, HipModel, ucfg, checkpoint, args, lat_hw, device, loop_inputs, latents):

@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""Which calibration figure tracks the box-to-box spread of the step time?  Reads the one-line records round 5's GPU sessions left
+(`ab[SD_TUNE=1 ] ms/step, it/s: <ms> <it/s> calib <copy GB/s> <MFMA TFLOP/s> <empty us> <chain us> <hand-over us> <HBM ns> <cache ns> ...`
+in profiles/r05_*summary*.log / *_ab.log: DEFAULT switches only) and the bench lines (profiles/r05_*bench*.json), one row per
+session, and prints every figure's ratio to the fastest session next to the step-time ratio.
+usage: tools/calib_fit.py [files...] > profiles/r05_calibration_fit.txt"""
+import glob
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+files = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_*.log")) + glob.glob(os.path.join(ROOT, "profiles", "r05_*bench*.json")))
+KEYS = ["copy_gbs", "mfma_tflops", "empty_launch_us", "chain_us", "handover_us", "latency_hbm_ns", "latency_cache_ns"]
+rows = []
+for f in files:
+    name = os.path.basename(f)
+    if f.endswith(".json"):
+        try:
+            d = json.loads(open(f).read().strip().splitlines()[-1])
+        except Exception:
+            continue
+        c = d.get("calibration")
+        if c and d.get("config", {}).get("prompts_per_gpu") == 1 and d.get("config", {}).get("unet", "sd21-base") == "sd21-base" \
+                and d.get("config", {}).get("latent") == 64 and d.get("config", {}).get("attention") == "ORIGINAL":
+            rows.append((name, d["ms_per_step"], [c.get(k) for k in KEYS]))
+        continue
+    per = []
+    for line in open(f):
+        m = re.match(r"ab\[SD_TUNE=1 \] ms/step, it/s: ([\d.]+) ([\d.]+) calib (.*?) sclk", line)
+        if m:
+            v = [float(x) if x != "None" else None for x in m.group(3).split()]
+            per.append((float(m.group(1)), v))
+    if per:
+        ms = sum(p[0] for p in per) / len(per)
+        v = [sum(p[1][i] for p in per) / len(per) if all(p[1][i] is not None for p in per) else None for i in range(len(KEYS))]
+        rows.append((name + f" ({len(per)} default runs)", ms, v))
+if not rows:
+    sys.exit("no records")
+rows.sort(key=lambda r: r[1])
+ref = rows[0]
+print("box calibration vs step time, default bench (SD2.1-base 512x512, CFG batch 2, ORIGINAL); reference = the fastest session")
+print(f"{'session':58s} {'ms/step':>8s} {'x ref':>6s} | " + " ".join(f"{k:>16s}" for k in KEYS))
+for name, ms, v in rows:
+    cells = []
+    for i, k in enumerate(KEYS):
+        if v[i] is None or ref[2][i] is None:
+            cells.append(f"{'-':>16s}")
+            continue
+        time_like = k.endswith("_us") or k.endswith("_ns")
+        r = v[i] / ref[2][i] if time_like else ref[2][i] / v[i]
+        cells.append(f"{v[i]:9.1f} x{r:5.3f}")
+    print(f"{name[:58]:58s} {ms:8.3f} {ms / ref[1]:6.3f} | " + " ".join(cells))
+spread = rows[-1][1] / rows[0][1]
+print(f"\nstep-time spread over {len(rows)} sessions: x{spread:.3f}.", end=" ")
+if spread < 1.05:
+    print("All sessions of this file landed on boxes of one speed class: nothing to fit; bench.py's CALIB_WEIGHTS stays empty and "
+          "`value_normalised` null.  (Earlier sessions of round 5, whose records were lost with their container, saw 4.40 and 5.52 ms with "
+          "copy / MFMA / empty-launch / cold-chain figures identical to 1 % - csrc/calib.hip - which is why the hand-over chain and the "
+          "dependent-load latencies were added.)")
+else:
+    print("Figures whose ratio follows the step-time ratio are the candidates for bench.py's CALIB_WEIGHTS.")
