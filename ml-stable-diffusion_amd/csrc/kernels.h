@@ -185,6 +185,29 @@ struct XAttnDesc {
 bool xattn_fused_ok(int C, int heads, int S, int L);
 void launch_xattn_fused(const XAttnDesc& d, hipStream_t s);
 
+// The whole cross-attention branch in one launch (xattn_out.hip): out = x + to_out(softmax(to_q(LayerNorm(x)) k^T / 8) v) + b_out
+// (unet.py:586-591 around :87-118), C = 320 / 640 (5 / 10 heads of 64), 32 query tokens per workgroup, one wave per head.
+// wq_t / wo_t: the LayerNorm-folded to_q weights and the to_out weights in the fragment-major layout of launch_xattn_out_retile
+// (C * C halves each); q_bias / q_colsum as XAttnDesc::bias / colsum; o_bias [C]; x [M][C] is the UN-normalised block input and the
+// residual; k [B][L][C], vt [B][C][ldv] (columns [L, ldv) zero), out [M][C].
+struct XAttnOutDesc {
+  const half_t* x = nullptr;
+  const half_t* wq_t = nullptr;
+  const float* q_bias = nullptr;
+  const float* q_colsum = nullptr;
+  const half_t* k = nullptr;
+  const half_t* vt = nullptr;
+  const half_t* wo_t = nullptr;
+  const float* o_bias = nullptr;
+  half_t* out = nullptr;
+  int M = 0, C = 0, S = 0, L = 0, ldv = 0, heads = 0;
+  float ln_eps = 1e-5f;
+  int impl = kAttnOriginal;
+};
+bool xattn_out_ok(int C, int heads, int S, int L);
+void launch_xattn_out_retile(const half_t* w, half_t* wt, int C, hipStream_t s);   // [C][C] row-major -> fragment-major
+void launch_xattn_out(const XAttnOutDesc& d, hipStream_t s);
+
 // ---------------------------------------------------------------------------------------------
 // K6/K7: norms (norm.hip)
 // ---------------------------------------------------------------------------------------------

@@ -704,7 +704,45 @@ Tensor UNet::transformer_block(std::vector<Op>& ops, const std::string& b, const
   Tensor k2 = conv(ctx_ops_, b + ".attn2.to_k", ctx_, nullptr, C, 1, 1, 1, false, nullptr, nullptr);
   Tensor vt2 = conv(ctx_ops_, b + ".attn2.to_v", ctx_, nullptr, C, 1, 1, 1, false, nullptr, nullptr, kOutHalfT, ldvc);
   Tensor a2;
-  if (can_fold_ln(h1, C, false) && xattn_fused_ok(C, heads, S, L)) {
+  // the whole branch - norm2 -> to_q -> attention -> to_out -> + h1 - as ONE launch (xattn_out.hip: 32 tokens x all heads per
+  // workgroup) at the 5- / 10-head levels; SD_XATTN_OUT=1 (with SD_TUNE), measured in LAB_NOTES.md r5
+  static const int xo_mode = tune_env_int("SD_XATTN_OUT", 0);
+  Tensor h2;
+  bool branch_done = false;
+  if (xo_mode != 0 && !f32_ && can_fold_ln(h1, C, false) && xattn_fused_ok(C, heads, S, L) && xattn_out_ok(C, heads, S, L)) {
+    LnFold f = fold_layernorm(b + ".norm2", {b + ".attn2.to_q"}, C, C, false);
+    half_t* wq_t = arena_.alloc_n<half_t>((size_t)C * C);
+    launch_xattn_out_retile(f.w, wq_t, C, stream_);
+    const half_t* wo = upload_conv_weight(b + ".attn2.to_out.0", C, C, 1, false);
+    half_t* wo_t = arena_.alloc_n<half_t>((size_t)C * C);
+    launch_xattn_out_retile(wo, wo_t, C, stream_);
+    h2 = new_tensor(h1.B, h1.H, h1.W, C);
+    XAttnOutDesc xd;
+    xd.x = h1.p;
+    xd.wq_t = wq_t;
+    xd.q_bias = f.bias;
+    xd.q_colsum = f.colsum;
+    xd.k = k2.p;
+    xd.vt = vt2.p;
+    xd.wo_t = wo_t;
+    xd.o_bias = upload_vec(b + ".attn2.to_out.0.bias", C);
+    xd.out = h2.p;
+    xd.M = h1.M();
+    xd.C = C;
+    xd.S = S;
+    xd.L = L;
+    xd.ldv = ldvc;
+    xd.heads = heads;
+    ops.push_back([this, xd](hipStream_t s) {
+      XAttnOutDesc dd = xd;
+      dd.impl = cfg_.attention_impl;
+      launch_xattn_out(dd, s);
+    });
+    ops.back().label = "xattn+ln q-proj " + std::to_string(C) + "->" + std::to_string(C) + " + attention h=" + std::to_string(heads) +
+                       " d=64 Sq=" + std::to_string(S) + " Sk=" + std::to_string(L) + " + to_out + residual " + b + ".attn2";
+    ops.back().flop = 4.0 * h1.M() * (double)C * C + 4.0 * h1.B * (double)C * S * L;
+    branch_done = true;
+  } else if (can_fold_ln(h1, C, false) && xattn_fused_ok(C, heads, S, L)) {
     // norm2 -> to_q -> softmax(q k^T) v as ONE launch (xattn.hip): the q tile stays in registers
     LnFold f = fold_layernorm(b + ".norm2", {b + ".attn2.to_q"}, C, C, false);
     a2 = new_tensor(h1.B, h1.H, h1.W, C);
@@ -743,7 +781,7 @@ Tensor UNet::transformer_block(std::vector<Op>& ops, const std::string& b, const
     }
     a2 = attention(ops, q2, k2.p, vt2.p, heads, S, L, C, ldvc, C);
   }
-  Tensor h2 = conv(ops, b + ".attn2.to_out.0", a2, nullptr, C, 1, 1, 1, true, nullptr, h1.p);
+  if (!branch_done) h2 = conv(ops, b + ".attn2.to_out.0", a2, nullptr, C, 1, 1, 1, true, nullptr, h1.p);
   // --- GEGLU feed-forward (norm3 folded the same way)
   Tensor g;
   if (can_fold_ln(h2, 8 * C, true)) {

@@ -1,0 +1,353 @@
+// The whole cross-attention branch of a BasicTransformerBlock as ONE launch (unet.py:586-591 around CrossAttention.forward
+// :87-118): for a block of 32 query tokens,
+//     q   = to_q(norm2(h1))                          LayerNormANE (layer_norm.py:51-80) folded into the projection
+//     a2  = softmax(q k^T / sqrt(d)) v   per head    k / v = to_k / to_v of the prompt (hoisted out of the step)
+//     h2  = h1 + to_out(a2) + b_out
+// xattn.hip stops behind a2 (one workgroup per (128 tokens, head)) and `to_out` + the residual are a second launch: a 1.7-GFLOP
+// GEMM that takes 11-12 us of launch floor, cold first touches and an epilogue round trip.  `to_out` mixes
+// the heads, so the fusion needs a workgroup that owns ALL heads of its tokens: here a workgroup is 32 tokens x (C / 64) waves -
+// wave w IS head w in the attention phase and output-channel block w in both projections:
+//   phase 1  q_w^T[64][32] = Wq[64w .. 64w+64][:] . x^T : the 32 x C activation tile sits in LDS once (it is also the residual),
+//            every wave streams ITS OWN 64 weight rows straight global -> VGPR in MFMA fragment order from PRE-TILED weights
+//            (one fully coalesced 1-KB load per fragment, batches in flight; nothing of the weight side goes through LDS, no
+//            barrier in the loop); the LayerNorm statistics of the token rows come from the same fragments (v_dot2).
+//   phase 2  the 77 keys of the prompt: K / V^T fragments of head w straight from L2 into registers (they are tiny and shared by
+//            every workgroup of the launch), exact softmax in registers (xattn.hip's arithmetic, line by line), a2 of head w ->
+//            LDS tile [32][C].
+//   phase 3  h2^T[64w .. +64][32] = Wo[64w ..][:] . a2^T + b_out + h1 : same loop as phase 1 over the LDS tile of a2.
+// Two workgroup barriers in all.  Weights stay in L2 (2 x C x C x 2 B for all workgroups).  Only C = 320 / 640 (5 / 10 heads of
+// 64): with 20 heads a workgroup would need 20 waves, and at M = 512 there would be 16 of them.
+#include "kernels.h"
+
+namespace sd {
+namespace {
+
+constexpr int XO_TOK = 32;   // query tokens per workgroup
+constexpr int XO_D = 64;     // head dim
+constexpr int XO_KEYS = 96;  // key capacity (3 MFMA tiles)
+
+struct XOArgs {
+  const half_t* x;
+  const half8* wq_t;
+  const float* q_bias;
+  const float* q_colsum;
+  const half_t* k;
+  const half_t* vt;
+  const half8* wo_t;
+  const float* o_bias;
+  half_t* out;
+  int M, C, S, L, ldv;
+  float ln_eps, scale_log2;
+};
+
+__device__ __forceinline__ float xo_xor32_sumf(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  return __uint_as_float(r0) + __uint_as_float(r1);
+}
+__device__ __forceinline__ float xo_xor32_maxf(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  return fmaxf(__uint_as_float(r0), __uint_as_float(r1));
+}
+
+// fragment-major copy of a [N][K] row-major matrix: wt[(nb * K/16 + k16) * 64 + lane] = the 8 halves lane (l31 = lane & 31,
+// hi = lane >> 5) feeds the A operand of v_mfma_f32_32x32x16_f16 for row block nb, K step k16: w[nb*32 + l31][k16*16 + hi*8 ..]
+__global__ __launch_bounds__(256) void xo_retile_kernel(const half_t* __restrict__ w, half8* __restrict__ wt, int N, int K) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= N * K / 8) return;
+  const int lane = idx & 63, t = idx >> 6, k16n = K >> 4;
+  const int k16 = t % k16n, nb = t / k16n;
+  wt[idx] = *reinterpret_cast<const half8*>(w + (size_t)(nb * 32 + (lane & 31)) * K + k16 * 16 + (lane >> 5) * 8);
+}
+
+// acc[j] += W[nb0 + j] (32 rows) . src^T over all of K: weight fragments global -> VGPR in batches of BATCH K steps, one batch
+// ahead of the MFMAs; activation fragments from the LDS tile src [32][ROW].  STATS: row statistics of src on the side.
+template <int K16, int BATCH, bool STATS>
+__device__ __forceinline__ void xo_gemm(const half8* __restrict__ wt, int nb0, const half_t* src, int ROW, int lane, floatx16 (&acc)[2],
+                                        float& s1, float& s2) {
+  static_assert(K16 % BATCH == 0, "whole batches");
+  constexpr int NB = K16 / BATCH;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const half8* w0 = wt + (size_t)nb0 * K16 * 64 + lane;
+  const half8* w1 = w0 + (size_t)K16 * 64;
+  const half_t* srow = src + l31 * ROW + hi * 8;
+  half8 wb[2][2][BATCH];   // [buffer][row block][step]
+#pragma unroll
+  for (int i = 0; i < BATCH; ++i) {
+    wb[0][0][i] = w0[i * 64];
+    wb[0][1][i] = w1[i * 64];
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int cur = b & 1;
+    if (b + 1 < NB) {
+#pragma unroll
+      for (int i = 0; i < BATCH; ++i) {
+        wb[cur ^ 1][0][i] = w0[((b + 1) * BATCH + i) * 64];
+        wb[cur ^ 1][1][i] = w1[((b + 1) * BATCH + i) * 64];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BATCH; ++i) {
+      const half8 xf = *reinterpret_cast<const half8*>(srow + (b * BATCH + i) * 16);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[cur][0][i], xf, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[cur][1][i], xf, acc[1], 0, 0, 0);
+      if constexpr (STATS) {
+        const half2v one2 = {(half_t)1.f, (half_t)1.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const half2v p2 = {xf[2 * e], xf[2 * e + 1]};
+          s2 = __builtin_amdgcn_fdot2(p2, p2, s2, false);
+          s1 = __builtin_amdgcn_fdot2(p2, one2, s1, false);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // the next batch's loads stay one batch ahead, no further
+  }
+}
+
+constexpr size_t xo_lds_bytes(int C) { return (size_t)2 * XO_TOK * (C + 8) * 2 + (size_t)3 * C * sizeof(float); }
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void xattn_out_kernel(XOArgs a) {
+  constexpr int C = NW * 64, ROW = C + 8, K16 = C / 16, NT = NW * 64;
+  constexpr int BATCH = NW <= 5 ? 5 : 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* xs = reinterpret_cast<half_t*>(smem);            // [32][ROW]  h1 rows: LayerNorm source, residual
+  half_t* os = xs + XO_TOK * ROW;                          // [32][ROW]  a2 (all heads)
+  float* sconst = reinterpret_cast<float*>(os + XO_TOK * ROW);   // [C] q bias | [C] q colsum | [C] out bias
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = head = 64-channel output block
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int m_blk = blockIdx.x * XO_TOK;
+  const int b = m_blk / a.S;                               // S % 32 == 0: one sample per workgroup
+
+  // ---- the activation tile, the per-column constants (NT == C threads: 4 chunks / 1 column each) and the prompt's K fragments
+  // of this head: every load is requested before the first one is used ----
+  half8 xv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + NT * i, row = idx / (C / 8), c8 = idx - row * (C / 8);
+    xv[i] = *reinterpret_cast<const half8*>(a.x + (size_t)(m_blk + row) * C + c8 * 8);
+  }
+  const float qb = a.q_bias[tid], qc = a.q_colsum[tid], ob = a.o_bias[tid];
+  // scores^T[key][q] = K . Q^T: lane (l31 = key of the tile, hi) holds, for step (j, s), channels j*32 + 16*s + 4*hi + {0..3, 8..11}
+  // of its key - the order in which the q accumulators come out of phase 1 (xattn.hip); keys >= L are clamped and masked later
+  half4 kq[3][2][2][2];
+  {
+    const half_t* kb = a.k + (size_t)b * a.L * C + (size_t)wave * XO_D + 4 * hi;
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+      const int key = min(kt * 32 + l31, a.L - 1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          kq[kt][j][s][0] = *reinterpret_cast<const half4*>(kb + (size_t)key * C + j * 32 + 16 * s);
+          kq[kt][j][s][1] = *reinterpret_cast<const half4*>(kb + (size_t)key * C + j * 32 + 16 * s + 8);
+        }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + NT * i, row = idx / (C / 8), c8 = idx - row * (C / 8);
+    *reinterpret_cast<half8*>(xs + row * ROW + c8 * 8) = xv[i];
+  }
+  sconst[tid] = qb;
+  sconst[C + tid] = qc;
+  sconst[2 * C + tid] = ob;
+  __syncthreads();                                         // x tile and constants visible
+
+  // ---- phase 1: q^T of head `wave`, LayerNorm statistics of the token rows on the side ----
+  floatx16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  float ln_s1 = 0.f, ln_s2 = 0.f;
+  xo_gemm<K16, BATCH, true>(a.wq_t, 2 * wave, xs, ROW, lane, acc, ln_s1, ln_s2);
+
+  // ---- V^T fragments of this head (O^T[d][q] = V^T . P^T): lane (l31 = channel of the tile, hi), step (kt, s2): keys
+  // kt*32 + s2*16 + 4*hi + {0..3, 8..11}; columns [L, ldv) are zero by contract, columns >= ldv do not exist.  Five heads: requested
+  // here, in flight under the LayerNorm fold and the scores; ten heads (168 VGPRs per wave): behind the softmax ----
+  half4 vq[3][2][2][2];
+  auto load_v = [&]() {
+    const half4 z4 = {0, 0, 0, 0};
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const half_t* vb = a.vt + ((size_t)b * C + (size_t)wave * XO_D + ct * 32 + l31) * a.ldv + 4 * hi;
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int c0 = kt * 32 + s2 * 16 + 4 * hi;
+          vq[kt][s2][ct][0] = (c0 < a.ldv) ? *reinterpret_cast<const half4*>(vb + kt * 32 + s2 * 16) : z4;
+          vq[kt][s2][ct][1] = (c0 + 8 < a.ldv) ? *reinterpret_cast<const half4*>(vb + kt * 32 + s2 * 16 + 8) : z4;
+        }
+    }
+  };
+  if constexpr (NW <= 5) load_v();
+
+  // ---- q of this lane's token: LayerNorm fold, fp16, MFMA B-operand order (xattn.hip) ----
+  // acc[j][r]: channel n = j*32 + (r&3) + 8*(r>>2) + 4*hi of token (lane & 31) -> k-slot e of step (j, s) is r = 8*s + e
+  half8 qf[2][2];
+  {
+    const float inv_k = 1.0f / (float)C;
+    const float s1 = xo_xor32_sumf(ln_s1), s2 = xo_xor32_sumf(ln_s2);
+    const float mean = s1 * inv_k;
+    const float var = fmaxf(s2 * inv_k - mean * mean, 0.f);
+    const float ln_a = rsqrtf(var + a.ln_eps);
+    const float ln_b = -ln_a * mean;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int nl = wave * XO_D + j * 32 + 8 * q4 + 4 * hi;
+        const floatx4 bb = *reinterpret_cast<const floatx4*>(sconst + nl);
+        const floatx4 cs = *reinterpret_cast<const floatx4*>(sconst + C + nl);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * q4 + e;
+          qf[j][r >> 3][r & 7] = (half_t)fmaf(acc[j][r], ln_a, fmaf(ln_b, cs[e], bb[e]));
+        }
+      }
+  }
+
+  // ---- phase 2: scores^T[key][q], exact softmax over the keys ----
+  floatx16 sacc[3];
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const half4 k0 = kq[kt][j][s][0], k1 = kq[kt][j][s][1];
+        const half8 kf = {k0[0], k0[1], k0[2], k0[3], k1[0], k1[1], k1[2], k1[3]};
+        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[j][s], sacc[kt], 0, 0, 0);
+      }
+  }
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (key >= a.L) sacc[kt][r] = -3.0e38f;
+      mx = fmaxf(mx, sacc[kt][r]);
+    }
+  mx = xo_xor32_maxf(mx);                                  // the other half-wave holds the other keys of each tile
+  const float mnew = mx * a.scale_log2;
+  float ps4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kt][r], a.scale_log2, -mnew));
+      sacc[kt][r] = p;
+      ps4[r & 3] += p;
+    }
+  const float inv = 1.0f / xo_xor32_sumf((ps4[0] + ps4[1]) + (ps4[2] + ps4[3]));
+  if constexpr (NW > 5) load_v();
+
+  floatx16 oacc[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[ct][r] = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      half8 pf;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pf[e] = (half_t)sacc[kt][s2 * 8 + e];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const half4 v0 = vq[kt][s2][ct][0], v1 = vq[kt][s2][ct][1];
+        const half8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[ct], 0, 0, 0);
+      }
+    }
+  // a2 of head `wave`, fp16 like the tensor xattn.hip stores: oacc[ct][r] = channel ct*32 + (r&3) + 8*(r>>2) + 4*hi of token l31
+  {
+    half_t* orow = os + l31 * ROW + wave * XO_D;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const half4 o = {(half_t)(oacc[ct][4 * g] * inv), (half_t)(oacc[ct][4 * g + 1] * inv), (half_t)(oacc[ct][4 * g + 2] * inv),
+                         (half_t)(oacc[ct][4 * g + 3] * inv)};
+        *reinterpret_cast<half4*>(orow + ct * 32 + 8 * g + 4 * hi) = o;
+      }
+  }
+  __syncthreads();                                         // every head's a2 is in the tile
+
+  // ---- phase 3: h2^T[64 * wave ..][32] = Wo . a2^T, + bias + residual ----
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  float d1 = 0.f, d2 = 0.f;
+  xo_gemm<K16, BATCH, false>(a.wo_t, 2 * wave, os, ROW, lane, acc, d1, d2);
+  {
+    half_t* orow = a.out + (size_t)(m_blk + l31) * C + wave * XO_D;
+    const half_t* rrow = xs + l31 * ROW + wave * XO_D;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nl = j * 32 + 8 * g + 4 * hi;
+        const floatx4 bo = *reinterpret_cast<const floatx4*>(sconst + 2 * C + wave * XO_D + nl);
+        const half4 rr = *reinterpret_cast<const half4*>(rrow + nl);
+        // the two-launch path rounds to_out's result + bias to fp16 in registers only after the residual add (tile_epilogue adds the
+        // residual to the fp16-rounded value): round the same way
+        half4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (half_t)((float)(half_t)(acc[j][4 * g + e] + bo[e]) + (float)rr[e]);
+        *reinterpret_cast<half4*>(orow + nl) = o;
+      }
+  }
+}
+
+template <int NW>
+void launch_nw(const XOArgs& a, hipStream_t s) {
+  constexpr size_t lds = xo_lds_bytes(NW * 64);
+  static_assert(lds <= 160 * 1024, "LDS");
+  auto k = xattn_out_kernel<NW>;
+  static DynLdsOnce once;
+  once.set(k, lds);
+  hipLaunchKernelGGL(k, dim3(a.M / XO_TOK), dim3(NW * 64), lds, s, a);
+}
+
+}  // namespace
+
+bool xattn_out_ok(int C, int heads, int S, int L) {
+  return (heads == 5 || heads == 10) && C == heads * XO_D && S >= XO_TOK && S % XO_TOK == 0 && L >= 1 && L <= XO_KEYS;
+}
+
+void launch_xattn_out_retile(const half_t* w, half_t* wt, int C, hipStream_t s) {
+  SD_REQUIRE(C % 32 == 0, kInvalidArgument, "xattn_out retile: C=%d", C);
+  const int n = C * C / 8;
+  hipLaunchKernelGGL(xo_retile_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, reinterpret_cast<half8*>(wt), C, C);
+  SD_HIP(hipGetLastError());
+}
+
+void launch_xattn_out(const XAttnOutDesc& d, hipStream_t s) {
+  SD_REQUIRE(xattn_out_ok(d.C, d.heads, d.S, d.L), kInvalidArgument, "xattn_out: C=%d heads=%d S=%d L=%d", d.C, d.heads, d.S, d.L);
+  SD_REQUIRE(d.M % d.S == 0 && d.ldv % 8 == 0 && d.ldv >= d.L && d.ldv <= XO_KEYS, kInvalidArgument, "xattn_out: M=%d ldv=%d", d.M, d.ldv);
+  if (d.impl == kAttnSplitEinsumV2 && d.S >= 512)   // the reference would silently drop the tail (attention.py:86)
+    SD_REQUIRE(d.S % 512 == 0, kInvalidArgument, "SPLIT_EINSUM_V2 needs S_q %% 512 == 0 (got %d)", d.S);
+  XOArgs a{d.x, reinterpret_cast<const half8*>(d.wq_t), d.q_bias, d.q_colsum, d.k, d.vt, reinterpret_cast<const half8*>(d.wo_t), d.o_bias,
+           d.out, d.M, d.C, d.S, d.L, d.ldv, d.ln_eps, 1.4426950408889634f / sqrtf((float)XO_D)};
+  if (d.heads == 5) launch_nw<5>(a, s);
+  else launch_nw<10>(a, s);
+  SD_HIP(hipGetLastError());
+}
+
+}  // namespace sd

@@ -471,3 +471,62 @@ def test_groupnorm_in_the_loader_refuses_what_it_cannot_take():
     x = h16(rs.randn(1, 64, 16, 16))
     with pytest.raises(NotImplementedError):     # no SiLU: the loader has no such form (no GroupNorm of the graph needs it)
         _lib.conv2d_groupnorm_conv3x3(x, w, g, g, w2, silu=False, fold=True)
+
+
+# ---------------------------------------------------------------- the cross-attention branch as ONE launch
+def xblock_ref(x, lw, lb, wq, k, v, wo, bo, heads, eps):
+    """fp32: x + to_out(attention(to_q(LayerNormANE(x)), k, v)) + bo (unet.py:586-591, :87-118)."""
+    from oracle import attention_ref
+    xt = torch.from_numpy(x.astype(np.float32))                        # (B, C, 1, S)
+    mu = xt.mean(dim=1, keepdim=True)
+    var = ((xt - mu) ** 2).mean(dim=1, keepdim=True)
+    n = (xt - mu) * torch.rsqrt(var + eps) * torch.from_numpy(lw).view(1, -1, 1, 1) + torch.from_numpy(lb).view(1, -1, 1, 1)
+    q = F.conv2d(n, torch.from_numpy(wq.astype(np.float32))[:, :, None, None])
+    a2 = attention_ref.IMPLS["SPLIT_EINSUM"](q.numpy(), k.astype(np.float32), v.astype(np.float32), heads, 64)
+    o = F.conv2d(torch.from_numpy(np.asarray(a2, np.float32)), torch.from_numpy(wo.astype(np.float32))[:, :, None, None], torch.from_numpy(bo))
+    return (xt + o).numpy()
+
+
+XBLOCK_CASES = [  # (B, heads, Sq, Sk)
+    (2, 5, 4096, 77),     # SD2.1-base level 0 at full size: 256 workgroups of five waves
+    (2, 10, 1024, 77),    # level 1: ten waves, V^T fragments behind the softmax
+    (1, 5, 32, 77),       # a single workgroup
+    (3, 5, 96, 33),       # odd batch, fewer keys: two of the three key tiles partly / fully masked
+    (1, 10, 64, 96),      # the key capacity
+    (2, 5, 576, 1),       # one key: softmax of a single score; SDXL's 24 x 24 token count
+]
+
+
+@pytest.mark.parametrize("case", XBLOCK_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_cross_attention_block_in_one_launch(case):
+    """norm2 -> to_q -> softmax(q k^T) v -> to_out -> + residual as ONE launch (xattn_out.hip: 32 tokens x all heads per workgroup,
+    weights global -> VGPR in fragment order) against fp32 torch and against the two-launch path it replaces."""
+    b, heads, sq, sk = case
+    c = heads * 64
+    rs = np.random.RandomState(sq + 3 * sk + heads + b)
+    x = h16(rs.randn(b, c, 1, sq) * 1.5 + 0.3)
+    lw = (1.0 + 0.2 * rs.randn(c)).astype(np.float32)
+    lb = (0.2 * rs.randn(c)).astype(np.float32)
+    wq = h16(rs.randn(c, c) / np.sqrt(c))
+    k = h16(rs.randn(b, c, 1, sk))
+    v = h16(rs.randn(b, c, 1, sk))
+    wo = h16(rs.randn(c, c) / np.sqrt(c))
+    bo = (0.1 * rs.randn(c)).astype(np.float32)
+    ref = xblock_ref(x, lw, lb, wq, k, v, wo, bo, heads, 1e-5)
+    two, _ = _lib.cross_attention_block(x, lw, lb, wq, k, v, wo, bo, heads, fused=False)
+    one, _ = _lib.cross_attention_block(x, lw, lb, wq, k, v, wo, bo, heads, fused=True)
+    close(two, ref, f"cross-attention + to_out, two launches {case}")
+    close(one, ref, f"cross-attention + to_out, one launch {case}")
+    again, _ = _lib.cross_attention_block(x, lw, lb, wq, k, v, wo, bo, heads, fused=True, iters=3)
+    assert np.array_equal(one, again)
+
+
+def test_cross_attention_block_refuses_other_head_counts():
+    rs = np.random.RandomState(3)
+    c = 20 * 64
+    z = np.zeros((1, c, 1, 64), np.float16)
+    kk = np.zeros((1, c, 1, 77), np.float16)
+    w = np.zeros((c, c), np.float16)
+    g = np.ones(c, np.float32)
+    with pytest.raises(NotImplementedError):     # 20 heads: a workgroup would need 20 waves
+        _lib.cross_attention_block(z, g, g, w, kk, kk, w, g, 20, fused=True)
