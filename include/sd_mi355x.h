@@ -309,10 +309,13 @@ int sd_op_cross_attention_fused(const void* x, const float* ln_weight, const flo
 /* The whole cross-attention branch of a BasicTransformerBlock (unet.py:586-591 around :87-118):
  * out = x + to_out(softmax(to_q(LayerNormANE(x)) k^T / 8) v) + bo.  fused = 1: ONE launch (xattn_out.hip: 32 tokens x all heads per
  * workgroup; 5 or 10 heads of 64, Sq % 32 == 0), fused = 0: the fused q-projection + attention launch followed by the to_out GEMM
- * with its residual epilogue.  Layouts as sd_op_cross_attention_fused; wo (C, C) f16, bo (C) f32. */
+ * with its residual epilogue.  Layouts as sd_op_cross_attention_fused; wo (C, C) f16, bo (C) f32.
+ * a1 != NULL (with wo1, bo1): the SELF-attention's output projection in front (unet.py:588): the branch runs on
+ * h1 = x + to_out1(a1) + bo1 (a1 the self-attention's output, x the block input) and out = h1 + to_out(...) + bo; the one-launch
+ * form (5 heads only) never stores h1. */
 int sd_op_cross_attention_block(const void* x, const float* ln_weight, const float* ln_bias, const void* wq, const void* k, const void* v,
-                                const void* wo, const float* bo, void* out, int B, int heads, int Sq, int Sk, float eps, int fused, int iters,
-                                float* ms);
+                                const void* wo, const float* bo, const void* a1, const void* wo1, const float* bo1, void* out, int B, int heads,
+                                int Sq, int Sk, float eps, int fused, int iters, float* ms);
 /* GEGLU feed-forward first half (unet.py:609-617): x (M, C) f16, w (8C', C) f16, bias (8C'/.. ) */
 int sd_op_geglu(const void* x, const void* w, const float* bias, void* out, int M, int C, int N2, int iters, float* ms);
 /* unet.py:703-728 */

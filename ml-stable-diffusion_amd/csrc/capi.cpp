@@ -840,30 +840,39 @@ int sd_op_cross_attention_fused(const void* x, const float* ln_weight, const flo
 }
 
 int sd_op_cross_attention_block(const void* x, const float* ln_weight, const float* ln_bias, const void* wq, const void* k, const void* v,
-                                const void* wo, const float* bo, void* out, int B, int heads, int Sq, int Sk, float eps, int fused, int iters,
-                                float* ms) {
+                                const void* wo, const float* bo, const void* a1, const void* wo1, const float* bo1, void* out, int B, int heads,
+                                int Sq, int Sk, float eps, int fused, int iters, float* ms) {
   return guarded([&] {
     SD_REQUIRE(x && ln_weight && ln_bias && wq && k && v && wo && bo && out, kInvalidArgument, "NULL argument");
+    const bool pre = a1 != nullptr;
+    SD_REQUIRE(!pre || (wo1 && bo1), kInvalidArgument, "cross_attention_block: a1 needs wo1 and bo1");
     const int C = heads * 64;
     SD_REQUIRE(B > 0 && heads > 0 && xattn_fused_ok(C, heads, Sq, Sk), kUnsupported,
                "cross_attention_block: heads %d x 64 channels, Sq %d, Sk %d (<= 96)", heads, Sq, Sk);
-    SD_REQUIRE(!fused || xattn_out_ok(C, heads, Sq, Sk), kUnsupported,
-               "cross_attention_block: the one-launch form takes 5 or 10 heads and Sq %% 32 == 0 (heads %d, Sq %d)", heads, Sq);
+    SD_REQUIRE(!fused || (xattn_out_ok(C, heads, Sq, Sk) && (!pre || heads == 5)), kUnsupported,
+               "cross_attention_block: the one-launch form takes 5 or 10 heads (with a1: 5) and Sq %% 32 == 0 (heads %d, Sq %d)", heads, Sq);
     Scratch sc;
     const int ldv = (Sk + 7) / 8 * 8;
-    const half_t* xh = reinterpret_cast<const half_t*>(x);
     const half_t* kh = reinterpret_cast<const half_t*>(k);
     const half_t* vh = reinterpret_cast<const half_t*>(v);
     const half_t* wh = reinterpret_cast<const half_t*>(wq);
-    std::vector<half_t> xt((size_t)B * Sq * C), kt((size_t)B * Sk * C), vt((size_t)B * C * ldv, (half_t)0);
+    auto to_tokens = [&](const void* p) {   // (B, C, 1, Sq) -> [B * Sq][C]
+      const half_t* h = reinterpret_cast<const half_t*>(p);
+      std::vector<half_t> t((size_t)B * Sq * C);
+      for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c)
+          for (int s = 0; s < Sq; ++s) t[((size_t)b * Sq + s) * C + c] = h[((size_t)b * C + c) * Sq + s];
+      return t;
+    };
+    std::vector<half_t> xt = to_tokens(x), a1t;
+    if (pre) a1t = to_tokens(a1);
+    std::vector<half_t> kt((size_t)B * Sk * C), vt((size_t)B * C * ldv, (half_t)0);
     for (int b = 0; b < B; ++b)
-      for (int c = 0; c < C; ++c) {
-        for (int s = 0; s < Sq; ++s) xt[((size_t)b * Sq + s) * C + c] = xh[((size_t)b * C + c) * Sq + s];
+      for (int c = 0; c < C; ++c)
         for (int s = 0; s < Sk; ++s) {
           kt[((size_t)b * Sk + s) * C + c] = kh[((size_t)b * C + c) * Sk + s];
           vt[((size_t)b * C + c) * ldv + s] = vh[((size_t)b * C + c) * Sk + s];
         }
-      }
     // the LayerNorm fold of UNet::fold_layernorm: w' = W * gamma (fp16), colsum of what the MFMA multiplies, bias' = W . beta
     std::vector<half_t> wf((size_t)C * C);
     std::vector<float> colsum(C), biasf(C);
@@ -880,6 +889,7 @@ int sd_op_cross_attention_block(const void* x, const float* ln_weight, const flo
       biasf[o] = (float)bb;
     }
     half_t* dx = sc.dev<half_t>(xt.size(), xt.data());
+    half_t* da1 = pre ? sc.dev<half_t>(a1t.size(), a1t.data()) : nullptr;
     half_t* dwq = sc.dev<half_t>(wf.size(), wf.data());
     float* dqb = sc.dev<float>(C, biasf.data());
     float* dqc = sc.dev<float>(C, colsum.data());
@@ -887,6 +897,9 @@ int sd_op_cross_attention_block(const void* x, const float* ln_weight, const flo
     half_t* dvt = sc.dev<half_t>(vt.size(), vt.data());
     half_t* dwo = sc.dev<half_t>((size_t)C * C, reinterpret_cast<const half_t*>(wo));
     float* dbo = sc.dev<float>(C, bo);
+    half_t* dwo1 = pre ? sc.dev<half_t>((size_t)C * C, reinterpret_cast<const half_t*>(wo1)) : nullptr;
+    float* dbo1 = pre ? sc.dev<float>(C, bo1) : nullptr;
+    half_t* dh1 = sc.dev<half_t>((size_t)B * Sq * C);
     half_t* da2 = sc.dev<half_t>((size_t)B * Sq * C);
     half_t* o = sc.dev<half_t>((size_t)B * Sq * C);
     if (fused) {
@@ -895,23 +908,35 @@ int sd_op_cross_attention_block(const void* x, const float* ln_weight, const flo
       launch_xattn_out_retile(dwq, wq_t, C, sc.stream);
       launch_xattn_out_retile(dwo, wo_t, C, sc.stream);
       XAttnOutDesc d;
-      d.x = dx; d.wq_t = wq_t; d.q_bias = dqb; d.q_colsum = dqc; d.k = dk; d.vt = dvt; d.wo_t = wo_t; d.o_bias = dbo; d.out = o;
+      d.x = pre ? da1 : dx; d.wq_t = wq_t; d.q_bias = dqb; d.q_colsum = dqc; d.k = dk; d.vt = dvt; d.wo_t = wo_t; d.o_bias = dbo; d.out = o;
       d.M = B * Sq; d.C = C; d.S = Sq; d.L = Sk; d.ldv = ldv; d.heads = heads; d.ln_eps = eps;
+      if (pre) {
+        half_t* wo1_t = sc.dev<half_t>((size_t)C * C);
+        launch_xattn_out_retile(dwo1, wo1_t, C, sc.stream);
+        d.h0 = dx; d.wo1_t = wo1_t; d.o1_bias = dbo1;
+      }
       sc.timed(iters, ms, [&] { launch_xattn_out(d, sc.stream); });
     } else {
+      auto gemm_res = [&](const half_t* in, const half_t* w, const float* bias, const half_t* res, half_t* dst) {   // 1x1 GEMM + residual
+        ConvDesc cd;
+        cd.x0 = in; cd.C0 = C; cd.w = w; cd.bias = bias; cd.res = res; cd.out = dst;
+        cd.B = B; cd.Hi = 1; cd.Wi = Sq; cd.Ho = 1; cd.Wo = Sq; cd.N = C;
+        SD_REQUIRE(conv_fast_path_ok(cd), kInvalidArgument, "cross_attention_block: to_out off the MFMA path");
+        return cd;
+      };
+      const half_t* h1 = pre ? dh1 : dx;
       XAttnDesc d;
-      d.x = dx; d.wq = dwq; d.bias = dqb; d.colsum = dqc; d.k = dk; d.vt = dvt; d.out = da2;
+      d.x = h1; d.wq = dwq; d.bias = dqb; d.colsum = dqc; d.k = dk; d.vt = dvt; d.out = da2;
       d.M = B * Sq; d.C = C; d.S = Sq; d.L = Sk; d.ldv = ldv; d.heads = heads; d.ln_eps = eps;
-      ConvDesc cd;   // to_out + residual as the 1x1 GEMM of the two-launch path
-      cd.x0 = da2; cd.C0 = C; cd.w = dwo; cd.bias = dbo; cd.res = dx; cd.out = o;
-      cd.B = B; cd.Hi = 1; cd.Wi = Sq; cd.Ho = 1; cd.Wo = Sq; cd.N = C;
-      SD_REQUIRE(conv_fast_path_ok(cd), kInvalidArgument, "cross_attention_block: to_out off the MFMA path");
+      ConvDesc c1 = gemm_res(da1 ? da1 : dx, dwo1 ? dwo1 : dwo, dbo1 ? dbo1 : dbo, dx, dh1);   // (only launched with a1)
+      ConvDesc c2 = gemm_res(da2, dwo, dbo, h1, o);
       ConvWorkspace ws;
-      ws.partial_bytes = conv_workspace_bytes(cd);
+      ws.partial_bytes = std::max(conv_workspace_bytes(c1), conv_workspace_bytes(c2));
       if (ws.partial_bytes) ws.partial = reinterpret_cast<float*>(sc.dev<char>(ws.partial_bytes));
       sc.timed(iters, ms, [&] {
+        if (pre) launch_conv(c1, ws, sc.stream);
         launch_xattn_fused(d, sc.stream);
-        launch_conv(cd, ws, sc.stream);
+        launch_conv(c2, ws, sc.stream);
       });
     }
     std::vector<half_t> ot((size_t)B * Sq * C);

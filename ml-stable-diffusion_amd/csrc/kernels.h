@@ -203,6 +203,12 @@ struct XAttnOutDesc {
   int M = 0, C = 0, S = 0, L = 0, ldv = 0, heads = 0;
   float ln_eps = 1e-5f;
   int impl = kAttnOriginal;
+  // five heads only: the SELF-attention's output projection in front, in the same launch (unet.py:588): x is then a1 (the
+  // self-attention's output), the kernel first forms h1 = h0 + to_out1(a1) + o1_bias - which never goes to HBM - and runs the
+  // cross-attention branch on it.  wo1_t fragment-major like wo_t; null = off.
+  const half_t* h0 = nullptr;
+  const half_t* wo1_t = nullptr;
+  const float* o1_bias = nullptr;
 };
 bool xattn_out_ok(int C, int heads, int S, int L);
 void launch_xattn_out_retile(const half_t* w, half_t* wt, int C, hipStream_t s);   // [C][C] row-major -> fragment-major

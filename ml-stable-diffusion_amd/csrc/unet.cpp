@@ -698,27 +698,41 @@ Tensor UNet::transformer_block(std::vector<Op>& ops, const std::string& b, const
   Tensor q = qk;
   q.C = C;   // logical width of q; rows are 2C apart
   Tensor a1 = attention(ops, q, qk.p + C, vtp, heads, S, S, 2 * C, ldv, 2 * C, vt_perm, q_pre);
-  Tensor h1 = conv(ops, b + ".attn1.to_out.0", a1, nullptr, C, 1, 1, 1, true, nullptr, h.p);
+  // the cross-attention branch - norm2 -> to_q -> attention -> to_out -> + h1 - as ONE launch (xattn_out.hip: 32 tokens x all heads
+  // per workgroup).  SD_XATTN_OUT (with SD_TUNE): 1 = at the 5-head level, 2 = at the 10-head level too (measured slower there:
+  // 64 workgroups of ten waves), 3 = 5-head level with the self-attention's to_out + residual in front, in the same launch (h1 then
+  // never goes to HBM); measured in LAB_NOTES.md r5
+  static const int xo_mode = tune_env_int("SD_XATTN_OUT", 0);
+  const bool xo_branch = xo_mode != 0 && !f32_ && can_fold_ln(h, C, false) && xattn_fused_ok(C, heads, S, L) && xattn_out_ok(C, heads, S, L) &&
+                         (heads == 5 || xo_mode == 2);
+  const bool xo_pre = xo_branch && xo_mode == 3 && heads == 5;
+  Tensor h1;
+  if (!xo_pre) h1 = conv(ops, b + ".attn1.to_out.0", a1, nullptr, C, 1, 1, 1, true, nullptr, h.p);
   // --- cross attention: K / V^T of the prompt are computed by ctx_ops_ when the prompt changes
   const int ldvc = round_up(L, 8);
   Tensor k2 = conv(ctx_ops_, b + ".attn2.to_k", ctx_, nullptr, C, 1, 1, 1, false, nullptr, nullptr);
   Tensor vt2 = conv(ctx_ops_, b + ".attn2.to_v", ctx_, nullptr, C, 1, 1, 1, false, nullptr, nullptr, kOutHalfT, ldvc);
   Tensor a2;
-  // the whole branch - norm2 -> to_q -> attention -> to_out -> + h1 - as ONE launch (xattn_out.hip: 32 tokens x all heads per
-  // workgroup) at the 5- / 10-head levels; SD_XATTN_OUT=1 (with SD_TUNE), measured in LAB_NOTES.md r5
-  static const int xo_mode = tune_env_int("SD_XATTN_OUT", 0);
   Tensor h2;
   bool branch_done = false;
-  if (xo_mode != 0 && !f32_ && can_fold_ln(h1, C, false) && xattn_fused_ok(C, heads, S, L) && xattn_out_ok(C, heads, S, L)) {
+  if (xo_branch) {
     LnFold f = fold_layernorm(b + ".norm2", {b + ".attn2.to_q"}, C, C, false);
     half_t* wq_t = arena_.alloc_n<half_t>((size_t)C * C);
     launch_xattn_out_retile(f.w, wq_t, C, stream_);
     const half_t* wo = upload_conv_weight(b + ".attn2.to_out.0", C, C, 1, false);
     half_t* wo_t = arena_.alloc_n<half_t>((size_t)C * C);
     launch_xattn_out_retile(wo, wo_t, C, stream_);
-    h2 = new_tensor(h1.B, h1.H, h1.W, C);
+    h2 = new_tensor(h.B, h.H, h.W, C);
     XAttnOutDesc xd;
-    xd.x = h1.p;
+    xd.x = xo_pre ? a1.p : h1.p;
+    if (xo_pre) {
+      const half_t* wo1 = upload_conv_weight(b + ".attn1.to_out.0", C, C, 1, false);
+      half_t* wo1_t = arena_.alloc_n<half_t>((size_t)C * C);
+      launch_xattn_out_retile(wo1, wo1_t, C, stream_);
+      xd.h0 = h.p;
+      xd.wo1_t = wo1_t;
+      xd.o1_bias = upload_vec(b + ".attn1.to_out.0.bias", C);
+    }
     xd.wq_t = wq_t;
     xd.q_bias = f.bias;
     xd.q_colsum = f.colsum;
@@ -727,7 +741,7 @@ Tensor UNet::transformer_block(std::vector<Op>& ops, const std::string& b, const
     xd.wo_t = wo_t;
     xd.o_bias = upload_vec(b + ".attn2.to_out.0.bias", C);
     xd.out = h2.p;
-    xd.M = h1.M();
+    xd.M = h.M();
     xd.C = C;
     xd.S = S;
     xd.L = L;
@@ -738,9 +752,10 @@ Tensor UNet::transformer_block(std::vector<Op>& ops, const std::string& b, const
       dd.impl = cfg_.attention_impl;
       launch_xattn_out(dd, s);
     });
-    ops.back().label = "xattn+ln q-proj " + std::to_string(C) + "->" + std::to_string(C) + " + attention h=" + std::to_string(heads) +
-                       " d=64 Sq=" + std::to_string(S) + " Sk=" + std::to_string(L) + " + to_out + residual " + b + ".attn2";
-    ops.back().flop = 4.0 * h1.M() * (double)C * C + 4.0 * h1.B * (double)C * S * L;
+    ops.back().label = std::string("xattn") + (xo_pre ? " attn1.to_out + residual +" : "") + "+ln q-proj " + std::to_string(C) + "->" + std::to_string(C) +
+                       " + attention h=" + std::to_string(heads) + " d=64 Sq=" + std::to_string(S) + " Sk=" + std::to_string(L) +
+                       " + to_out + residual " + b + ".attn2";
+    ops.back().flop = (xo_pre ? 6.0 : 4.0) * h.M() * (double)C * C + 4.0 * h.B * (double)C * S * L;
     branch_done = true;
   } else if (can_fold_ln(h1, C, false) && xattn_fused_ok(C, heads, S, L)) {
     // norm2 -> to_q -> softmax(q k^T) v as ONE launch (xattn.hip): the q tile stays in registers

@@ -17,6 +17,10 @@
 //   phase 3  h2^T[64w .. +64][32] = Wo[64w ..][:] . a2^T + b_out + h1 : same loop as phase 1 over the LDS tile of a2.
 // Two workgroup barriers in all.  Weights stay in L2 (2 x C x C x 2 B for all workgroups).  Only C = 320 / 640 (5 / 10 heads of
 // 64): with 20 heads a workgroup would need 20 waves, and at M = 512 there would be 16 of them.
+// PRE (five heads only): the SELF-attention's output projection in front of it, in the same launch (unet.py:588):
+//   phase 0  h1^T[64w .. +64][32] = Wo1[64w ..][:] . a1^T + b1 + h0 : a1 (the self-attention's output) is the LDS tile, the result -
+//            rounded to fp16 like the tensor the separate launch stores - becomes the activation tile of phase 1 and never goes to HBM.
+// One more barrier; three launches (to_out, q-projection + attention, to_out) become one.
 #include "kernels.h"
 
 namespace sd {
@@ -38,6 +42,10 @@ struct XOArgs {
   half_t* out;
   int M, C, S, L, ldv;
   float ln_eps, scale_log2;
+  // PRE: x is a1 (the self-attention's output), h0 the block input (its residual), wo1_t / o1_bias the first to_out
+  const half_t* h0;
+  const half8* wo1_t;
+  const float* o1_bias;
 };
 
 __device__ __forceinline__ float xo_xor32_sumf(float v) {
@@ -63,38 +71,49 @@ __global__ __launch_bounds__(256) void xo_retile_kernel(const half_t* __restrict
   wt[idx] = *reinterpret_cast<const half8*>(w + (size_t)(nb * 32 + (lane & 31)) * K + k16 * 16 + (lane >> 5) * 8);
 }
 
-// acc[j] += W[nb0 + j] (32 rows) . src^T over all of K: weight fragments global -> VGPR in batches of BATCH K steps, one batch
-// ahead of the MFMAs; activation fragments from the LDS tile src [32][ROW].  STATS: row statistics of src on the side.
-template <int K16, int BATCH, bool STATS>
-__device__ __forceinline__ void xo_gemm(const half8* __restrict__ wt, int nb0, const half_t* src, int ROW, int lane, floatx16 (&acc)[2],
-                                        float& s1, float& s2) {
-  static_assert(K16 % BATCH == 0, "whole batches");
+// acc[j] += W[nb0 + j] (32 rows) . src^T over all of K: weight fragments global -> VGPR in batches of BATCH K steps, NBUF - 1
+// batches ahead of the MFMAs (xo_prefetch requests the first NBUF - 1 - it may run long before the activation tile is ready);
+// activation fragments from the LDS tile src [32][ROW].  STATS: row statistics of src on the side.
+template <int BATCH, int NBUF>
+struct XoW {
+  half8 w[NBUF][2][BATCH];   // [buffer][row block][step]
+};
+template <int K16, int BATCH, int NBUF>
+__device__ __forceinline__ void xo_prefetch(XoW<BATCH, NBUF>& r, const half8* __restrict__ wt, int nb0, int lane) {
+  const half8* w0 = wt + (size_t)nb0 * K16 * 64 + lane;
+  const half8* w1 = w0 + (size_t)K16 * 64;
+#pragma unroll
+  for (int p = 0; p < NBUF - 1; ++p)
+#pragma unroll
+    for (int i = 0; i < BATCH; ++i) {
+      r.w[p][0][i] = w0[(p * BATCH + i) * 64];
+      r.w[p][1][i] = w1[(p * BATCH + i) * 64];
+    }
+}
+template <int K16, int BATCH, int NBUF, bool STATS>
+__device__ __forceinline__ void xo_gemm(XoW<BATCH, NBUF>& r, const half8* __restrict__ wt, int nb0, const half_t* src, int ROW, int lane,
+                                        floatx16 (&acc)[2], float& s1, float& s2) {
+  static_assert(K16 % BATCH == 0 && K16 / BATCH >= NBUF - 1, "whole batches");
   constexpr int NB = K16 / BATCH;
   const int l31 = lane & 31, hi = lane >> 5;
   const half8* w0 = wt + (size_t)nb0 * K16 * 64 + lane;
   const half8* w1 = w0 + (size_t)K16 * 64;
   const half_t* srow = src + l31 * ROW + hi * 8;
-  half8 wb[2][2][BATCH];   // [buffer][row block][step]
-#pragma unroll
-  for (int i = 0; i < BATCH; ++i) {
-    wb[0][0][i] = w0[i * 64];
-    wb[0][1][i] = w1[i * 64];
-  }
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    const int cur = b & 1;
-    if (b + 1 < NB) {
+    const int cur = b % NBUF, nxt = (b + NBUF - 1) % NBUF;
+    if (b + NBUF - 1 < NB) {
 #pragma unroll
       for (int i = 0; i < BATCH; ++i) {
-        wb[cur ^ 1][0][i] = w0[((b + 1) * BATCH + i) * 64];
-        wb[cur ^ 1][1][i] = w1[((b + 1) * BATCH + i) * 64];
+        r.w[nxt][0][i] = w0[((b + NBUF - 1) * BATCH + i) * 64];
+        r.w[nxt][1][i] = w1[((b + NBUF - 1) * BATCH + i) * 64];
       }
     }
 #pragma unroll
     for (int i = 0; i < BATCH; ++i) {
       const half8 xf = *reinterpret_cast<const half8*>(srow + (b * BATCH + i) * 16);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[cur][0][i], xf, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[cur][1][i], xf, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r.w[cur][0][i], xf, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r.w[cur][1][i], xf, acc[1], 0, 0, 0);
       if constexpr (STATS) {
         const half2v one2 = {(half_t)1.f, (half_t)1.f};
 #pragma unroll
@@ -105,20 +124,21 @@ __device__ __forceinline__ void xo_gemm(const half8* __restrict__ wt, int nb0, c
         }
       }
     }
-    __builtin_amdgcn_sched_barrier(0);   // the next batch's loads stay one batch ahead, no further
+    __builtin_amdgcn_sched_barrier(0);   // the later batches' loads stay NBUF - 1 batches ahead, no further
   }
 }
 
-constexpr size_t xo_lds_bytes(int C) { return (size_t)2 * XO_TOK * (C + 8) * 2 + (size_t)3 * C * sizeof(float); }
+constexpr size_t xo_lds_bytes(int C) { return (size_t)2 * XO_TOK * (C + 8) * 2 + (size_t)4 * C * sizeof(float); }
 
-template <int NW>
+template <int NW, bool PRE>
 __global__ __launch_bounds__(NW * 64) void xattn_out_kernel(XOArgs a) {
   constexpr int C = NW * 64, ROW = C + 8, K16 = C / 16, NT = NW * 64;
-  constexpr int BATCH = NW <= 5 ? 5 : 4;
+  constexpr int BATCH = 4, NBUF = NW <= 5 ? 3 : 2;         // five heads: 256 VGPRs per wave, two batches ahead; ten: 168, one
+  static_assert(!PRE || NW <= 5, "the self-attention's to_out in front: five heads only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half_t* xs = reinterpret_cast<half_t*>(smem);            // [32][ROW]  h1 rows: LayerNorm source, residual
-  half_t* os = xs + XO_TOK * ROW;                          // [32][ROW]  a2 (all heads)
-  float* sconst = reinterpret_cast<float*>(os + XO_TOK * ROW);   // [C] q bias | [C] q colsum | [C] out bias
+  half_t* os = xs + XO_TOK * ROW;                          // [32][ROW]  a2 (all heads); PRE: a1 until phase 0 is over
+  float* sconst = reinterpret_cast<float*>(os + XO_TOK * ROW);   // [C] q bias | [C] q colsum | [C] out bias | [C] first out bias (PRE)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = head = 64-channel output block
@@ -126,15 +146,27 @@ __global__ __launch_bounds__(NW * 64) void xattn_out_kernel(XOArgs a) {
   const int m_blk = blockIdx.x * XO_TOK;
   const int b = m_blk / a.S;                               // S % 32 == 0: one sample per workgroup
 
-  // ---- the activation tile, the per-column constants (NT == C threads: 4 chunks / 1 column each) and the prompt's K fragments
-  // of this head: every load is requested before the first one is used ----
+  // ---- the activation tile (PRE: a1), the per-column constants (NT == C threads: 4 chunks / 1 column each), the first weight
+  // batches and the prompt's K fragments of this head: every load is requested before the first one is used ----
   half8 xv[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int idx = tid + NT * i, row = idx / (C / 8), c8 = idx - row * (C / 8);
     xv[i] = *reinterpret_cast<const half8*>(a.x + (size_t)(m_blk + row) * C + c8 * 8);
   }
+  XoW<BATCH, NBUF> wr;
+  xo_prefetch<K16, BATCH, NBUF>(wr, PRE ? a.wo1_t : a.wq_t, 2 * wave, lane);
   const float qb = a.q_bias[tid], qc = a.q_colsum[tid], ob = a.o_bias[tid];
+  float ob1 = 0.f;
+  half4 h0r[2][4];                                         // PRE: the residual of phase 0, this lane's 32 channels of its token
+  if constexpr (PRE) {
+    ob1 = a.o1_bias[tid];
+    const half_t* hrow = a.h0 + (size_t)(m_blk + l31) * C + wave * XO_D + 4 * hi;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) h0r[j][g] = *reinterpret_cast<const half4*>(hrow + j * 32 + 8 * g);
+  }
   // scores^T[key][q] = K . Q^T: lane (l31 = key of the tile, hi) holds, for step (j, s), channels j*32 + 16*s + 4*hi + {0..3, 8..11}
   // of its key - the order in which the q accumulators come out of phase 1 (xattn.hip); keys >= L are clamped and masked later
   half4 kq[3][2][2][2];
@@ -152,24 +184,51 @@ __global__ __launch_bounds__(NW * 64) void xattn_out_kernel(XOArgs a) {
         }
     }
   }
+  {
+    half_t* dst = PRE ? os : xs;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = tid + NT * i, row = idx / (C / 8), c8 = idx - row * (C / 8);
-    *reinterpret_cast<half8*>(xs + row * ROW + c8 * 8) = xv[i];
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + NT * i, row = idx / (C / 8), c8 = idx - row * (C / 8);
+      *reinterpret_cast<half8*>(dst + row * ROW + c8 * 8) = xv[i];
+    }
   }
   sconst[tid] = qb;
   sconst[C + tid] = qc;
   sconst[2 * C + tid] = ob;
-  __syncthreads();                                         // x tile and constants visible
+  if constexpr (PRE) sconst[3 * C + tid] = ob1;
+  __syncthreads();                                         // the tile and the constants are visible
+
+  floatx16 acc[2];
+  float ln_s1 = 0.f, ln_s2 = 0.f;
+  if constexpr (PRE) {
+    // ---- phase 0: h1^T[64 * wave ..][32] = Wo1 . a1^T + b1 + h0 -> the activation tile of phase 1 (fp16, as the tensor would be) ----
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    float d1 = 0.f, d2 = 0.f;
+    xo_gemm<K16, BATCH, NBUF, false>(wr, a.wo1_t, 2 * wave, os, ROW, lane, acc, d1, d2);
+    xo_prefetch<K16, BATCH, NBUF>(wr, a.wq_t, 2 * wave, lane);   // phase 1's first batches: in flight under the epilogue and the barrier
+    half_t* hrow = xs + l31 * ROW + wave * XO_D + 4 * hi;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const floatx4 b1 = *reinterpret_cast<const floatx4*>(sconst + 3 * C + wave * XO_D + j * 32 + 8 * g + 4 * hi);
+        half4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (half_t)((float)(half_t)(acc[j][4 * g + e] + b1[e]) + (float)h0r[j][g][e]);
+        *reinterpret_cast<half4*>(hrow + j * 32 + 8 * g) = o;
+      }
+    __syncthreads();                                       // h1 of every channel block is in the tile; nobody reads a1 any more
+  }
 
   // ---- phase 1: q^T of head `wave`, LayerNorm statistics of the token rows on the side ----
-  floatx16 acc[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  float ln_s1 = 0.f, ln_s2 = 0.f;
-  xo_gemm<K16, BATCH, true>(a.wq_t, 2 * wave, xs, ROW, lane, acc, ln_s1, ln_s2);
+  xo_gemm<K16, BATCH, NBUF, true>(wr, a.wq_t, 2 * wave, xs, ROW, lane, acc, ln_s1, ln_s2);
 
   // ---- V^T fragments of this head (O^T[d][q] = V^T . P^T): lane (l31 = channel of the tile, hi), step (kt, s2): keys
   // kt*32 + s2*16 + 4*hi + {0..3, 8..11}; columns [L, ldv) are zero by contract, columns >= ldv do not exist.  Five heads: requested
@@ -232,6 +291,8 @@ __global__ __launch_bounds__(NW * 64) void xattn_out_kernel(XOArgs a) {
         sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[j][s], sacc[kt], 0, 0, 0);
       }
   }
+  // the first batches of to_out's weights: five heads have the registers to keep them in flight under the softmax and P . V
+  if constexpr (NW <= 5) xo_prefetch<K16, BATCH, NBUF>(wr, a.wo_t, 2 * wave, lane);
   float mx = -3.0e38f;
 #pragma unroll
   for (int kt = 0; kt < 3; ++kt)
@@ -293,8 +354,9 @@ __global__ __launch_bounds__(NW * 64) void xattn_out_kernel(XOArgs a) {
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  float d1 = 0.f, d2 = 0.f;
-  xo_gemm<K16, BATCH, false>(a.wo_t, 2 * wave, os, ROW, lane, acc, d1, d2);
+  float e1 = 0.f, e2 = 0.f;
+  if constexpr (NW > 5) xo_prefetch<K16, BATCH, NBUF>(wr, a.wo_t, 2 * wave, lane);
+  xo_gemm<K16, BATCH, NBUF, false>(wr, a.wo_t, 2 * wave, os, ROW, lane, acc, e1, e2);
   {
     half_t* orow = a.out + (size_t)(m_blk + l31) * C + wave * XO_D;
     const half_t* rrow = xs + l31 * ROW + wave * XO_D;
@@ -315,11 +377,11 @@ __global__ __launch_bounds__(NW * 64) void xattn_out_kernel(XOArgs a) {
   }
 }
 
-template <int NW>
+template <int NW, bool PRE>
 void launch_nw(const XOArgs& a, hipStream_t s) {
   constexpr size_t lds = xo_lds_bytes(NW * 64);
   static_assert(lds <= 160 * 1024, "LDS");
-  auto k = xattn_out_kernel<NW>;
+  auto k = xattn_out_kernel<NW, PRE>;
   static DynLdsOnce once;
   once.set(k, lds);
   hipLaunchKernelGGL(k, dim3(a.M / XO_TOK), dim3(NW * 64), lds, s, a);
@@ -343,10 +405,14 @@ void launch_xattn_out(const XAttnOutDesc& d, hipStream_t s) {
   SD_REQUIRE(d.M % d.S == 0 && d.ldv % 8 == 0 && d.ldv >= d.L && d.ldv <= XO_KEYS, kInvalidArgument, "xattn_out: M=%d ldv=%d", d.M, d.ldv);
   if (d.impl == kAttnSplitEinsumV2 && d.S >= 512)   // the reference would silently drop the tail (attention.py:86)
     SD_REQUIRE(d.S % 512 == 0, kInvalidArgument, "SPLIT_EINSUM_V2 needs S_q %% 512 == 0 (got %d)", d.S);
+  const bool pre = d.wo1_t != nullptr;
+  SD_REQUIRE(!pre || (d.heads == 5 && d.h0 && d.o1_bias), kInvalidArgument, "xattn_out: the self-attention's to_out in front needs five heads, h0 and its bias");
   XOArgs a{d.x, reinterpret_cast<const half8*>(d.wq_t), d.q_bias, d.q_colsum, d.k, d.vt, reinterpret_cast<const half8*>(d.wo_t), d.o_bias,
-           d.out, d.M, d.C, d.S, d.L, d.ldv, d.ln_eps, 1.4426950408889634f / sqrtf((float)XO_D)};
-  if (d.heads == 5) launch_nw<5>(a, s);
-  else launch_nw<10>(a, s);
+           d.out, d.M, d.C, d.S, d.L, d.ldv, d.ln_eps, 1.4426950408889634f / sqrtf((float)XO_D), d.h0, reinterpret_cast<const half8*>(d.wo1_t),
+           d.o1_bias};
+  if (d.heads == 5 && pre) launch_nw<5, true>(a, s);
+  else if (d.heads == 5) launch_nw<5, false>(a, s);
+  else launch_nw<10, false>(a, s);
   SD_HIP(hipGetLastError());
 }
 

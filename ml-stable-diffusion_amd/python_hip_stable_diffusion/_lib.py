@@ -98,7 +98,7 @@ SYMBOLS = [
     ("sd_op_conv2d_groupnorm_conv3x3", _I, [_P, _P, _FP, _P, _FP, _FP, _P, _FP, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _I,
                                             C.POINTER(_I), _I, _FP]),
     ("sd_op_cross_attention_fused", _I, [_P, _FP, _FP, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _FP]),
-    ("sd_op_cross_attention_block", _I, [_P, _FP, _FP, _P, _P, _P, _P, _FP, _P, _I, _I, _I, _I, _F, _I, _I, _FP]),
+    ("sd_op_cross_attention_block", _I, [_P, _FP, _FP, _P, _P, _P, _P, _FP, _P, _P, _FP, _P, _I, _I, _I, _I, _F, _I, _I, _FP]),
     ("sd_op_geglu", _I, [_P, _P, _FP, _P, _I, _I, _I, _I, _FP]),
     ("sd_op_timestep_embedding", _I, [_FP, _FP, _I, _I, _I, _F]),
     ("sd_numpy_randn", _I, [C.c_uint32, C.POINTER(C.c_double), C.c_size_t]),
@@ -305,20 +305,25 @@ def conv2d_groupnorm_conv3x3(x, w, gn_weight, gn_bias, w2, bias2=None, res2=None
     return conv_out, out, entries.value, ms.value
 
 
-def cross_attention_block(x, ln_weight, ln_bias, wq, k, v, wo, bo, heads, eps=1e-5, fused=True, iters=1):
+def cross_attention_block(x, ln_weight, ln_bias, wq, k, v, wo, bo, heads, eps=1e-5, fused=True, iters=1, a1=None, wo1=None, bo1=None):
     """x + to_out(softmax(to_q(LayerNormANE(x)) k^T / 8) v) + bo - the cross-attention branch of a BasicTransformerBlock; fused=True
     runs it as ONE launch (5 or 10 heads of 64, Sq % 32 == 0), else as the q-projection + attention launch and the to_out GEMM.
-    x (B,C,1,Sq), k / v (B,C,1,Sk) f16, wq / wo (C,C) f16, bo (C) f32.  Returns (out, ms)."""
+    With a1 / wo1 / bo1 the self-attention's output projection comes first: the branch runs on h1 = x + to_out1(a1) + bo1 (one
+    launch: 5 heads only).  x, a1 (B,C,1,Sq), k / v (B,C,1,Sk) f16, wq / wo / wo1 (C,C) f16, bo / bo1 (C) f32.  Returns (out, ms)."""
     x, k, v, wq, wo = f16(x), f16(k), f16(v), f16(wq), f16(wo)
     B, Cn, _, Sq = x.shape
     Sk = k.shape[3]
     if Cn != heads * 64 or k.shape[1] != Cn or v.shape != k.shape or wq.shape != (Cn, Cn) or wo.shape != (Cn, Cn):
         raise ValueError("cross_attention_block: inconsistent shapes")
     ln_weight, ln_bias, bo = f32(ln_weight), f32(ln_bias), f32(bo)
+    if a1 is not None:
+        a1, wo1, bo1 = f16(a1), f16(wo1), f32(bo1)
+        if a1.shape != x.shape or wo1.shape != (Cn, Cn):
+            raise ValueError("cross_attention_block: inconsistent shapes of a1 / wo1")
     out = np.empty_like(x)
     ms = C.c_float(0)
-    check(lib().sd_op_cross_attention_block(ptr(x), fptr(ln_weight), fptr(ln_bias), ptr(wq), ptr(k), ptr(v), ptr(wo), fptr(bo), ptr(out),
-                                            B, heads, Sq, Sk, eps, int(fused), iters, C.byref(ms)))
+    check(lib().sd_op_cross_attention_block(ptr(x), fptr(ln_weight), fptr(ln_bias), ptr(wq), ptr(k), ptr(v), ptr(wo), fptr(bo), ptr(a1), ptr(wo1),
+                                            fptr(bo1), ptr(out), B, heads, Sq, Sk, eps, int(fused), iters, C.byref(ms)))
     return out, ms.value
 
 

@@ -521,6 +521,39 @@ def test_cross_attention_block_in_one_launch(case):
     assert np.array_equal(one, again)
 
 
+XPRE_CASES = [(2, 5, 4096, 77), (1, 5, 32, 77), (3, 5, 96, 40)]   # (B, heads, Sq, Sk)
+
+
+@pytest.mark.parametrize("case", XPRE_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_self_attention_out_projection_and_cross_attention_block_in_one_launch(case):
+    """attn1.to_out + residual -> norm2 -> to_q -> attention -> attn2.to_out + residual (unet.py:588-590) as ONE launch: h1 never
+    goes to HBM.  Against fp32 torch (h1 rounded to fp16 where the separate launch would store it) and the three-launch path."""
+    b, heads, sq, sk = case
+    c = heads * 64
+    rs = np.random.RandomState(7 * sq + sk + heads + b)
+    h0 = h16(rs.randn(b, c, 1, sq) * 1.5 + 0.3)
+    a1 = h16(rs.randn(b, c, 1, sq))
+    wo1 = h16(rs.randn(c, c) / np.sqrt(c))
+    bo1 = (0.1 * rs.randn(c)).astype(np.float32)
+    lw = (1.0 + 0.2 * rs.randn(c)).astype(np.float32)
+    lb = (0.2 * rs.randn(c)).astype(np.float32)
+    wq = h16(rs.randn(c, c) / np.sqrt(c))
+    k = h16(rs.randn(b, c, 1, sk))
+    v = h16(rs.randn(b, c, 1, sk))
+    wo = h16(rs.randn(c, c) / np.sqrt(c))
+    bo = (0.1 * rs.randn(c)).astype(np.float32)
+    h1 = torch.from_numpy(h0.astype(np.float32)) + F.conv2d(torch.from_numpy(a1.astype(np.float32)),
+                                                            torch.from_numpy(wo1.astype(np.float32))[:, :, None, None], torch.from_numpy(bo1))
+    ref = xblock_ref(h16(h1.numpy()), lw, lb, wq, k, v, wo, bo, heads, 1e-5)
+    kw = dict(a1=a1, wo1=wo1, bo1=bo1)
+    three, _ = _lib.cross_attention_block(h0, lw, lb, wq, k, v, wo, bo, heads, fused=False, **kw)
+    one, _ = _lib.cross_attention_block(h0, lw, lb, wq, k, v, wo, bo, heads, fused=True, **kw)
+    close(three, ref, f"to_out + cross-attention + to_out, three launches {case}")
+    close(one, ref, f"to_out + cross-attention + to_out, one launch {case}")
+    again, _ = _lib.cross_attention_block(h0, lw, lb, wq, k, v, wo, bo, heads, fused=True, iters=3, **kw)
+    assert np.array_equal(one, again)
+
+
 def test_cross_attention_block_refuses_other_head_counts():
     rs = np.random.RandomState(3)
     c = 20 * 64
