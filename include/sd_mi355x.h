@@ -298,6 +298,13 @@ int sd_op_conv2d_groupnorm_conv3x3(const void* x, const void* w, const float* bi
                                    const float* gn_bias, const void* w2, const float* bias2, const void* res2, void* conv_out, void* out,
                                    int B, int Cin, int H, int W, int Cout, int ksize, int N2, int groups, float eps, int silu, int fold,
                                    int tile, int staging2, int* entries, int iters, float* ms);
+/* The tail of a SpatialTransformer (unet.py:591 FeedForward.net.2 + residual, :561-563 proj_out + residual):
+ * out = res2 + proj_out(res1 + ff.net.2(g) + b1) + b2.  fused = 1: ONE launch (32 tokens x 5 waves per workgroup, C = 320,
+ * S % 32 == 0; the intermediate never goes to HBM), fused = 0: the two 1x1 GEMMs.  g (B, 4C, 1, S), res1 / res2 / out (B, C, 1, S) f16,
+ * w1 (C, 4C), w2 (C, C) f16, b1 / b2 (C) f32.  gn_sums (may be NULL): (B, groups, 2) f32 - the GroupNorm statistics (sum, sum of
+ * squares per sample and group) the launch left for a consuming GroupNorm, folded; NaN when it left none. */
+int sd_op_ffn_out_proj(const void* g, const void* w1, const float* b1, const void* res1, const void* w2, const float* b2, const void* res2,
+                       void* out, float* gn_sums, int B, int C, int S, int groups, int fused, int iters, float* ms);
 /* Cross-attention front half as one launch (unet.py:87-118 inside :586-591): out = softmax(to_q(LayerNormANE(x)) k^T / 8) v
  * per head, head dim 64, Sk <= 96 (the prompt), any Sq >= 1 (ragged last token tile).  V^T columns [Sk, round_up(Sk, 8)) must be
  * zero (this entry point zero-fills them; the masked probabilities there are 0 but 0 * inf would be NaN).  x (B, heads*64, 1, Sq), k / v (B, heads*64, 1, Sk) f16 BC1S,

@@ -948,6 +948,92 @@ int sd_op_cross_attention_block(const void* x, const float* ln_weight, const flo
   });
 }
 
+int sd_op_ffn_out_proj(const void* g, const void* w1, const float* b1, const void* res1, const void* w2, const float* b2, const void* res2,
+                       void* out, float* gn_sums, int B, int C, int S, int groups, int fused, int iters, float* ms) {
+  return guarded([&] {
+    SD_REQUIRE(g && w1 && b1 && res1 && w2 && b2 && res2 && out, kInvalidArgument, "NULL argument");
+    const int K1 = 4 * C, M = B * S;
+    SD_REQUIRE(B > 0 && C % 64 == 0 && S > 0, kInvalidArgument, "ffn_out_proj: B=%d C=%d S=%d", B, C, S);
+    SD_REQUIRE(!fused || ffn_proj_ok(C, K1, M, S), kUnsupported, "ffn_out_proj: the one-launch form takes C = 320 and S %% 32 == 0 (C=%d S=%d)", C, S);
+    SD_REQUIRE(!gn_sums || (groups >= 1 && C % groups == 0), kInvalidArgument, "ffn_out_proj: groups %d", groups);
+    Scratch sc;
+    auto to_tokens = [&](const void* p, int ch) {   // (B, ch, 1, S) -> [B * S][ch]
+      const half_t* h = reinterpret_cast<const half_t*>(p);
+      std::vector<half_t> t((size_t)M * ch);
+      for (int b = 0; b < B; ++b)
+        for (int c = 0; c < ch; ++c)
+          for (int s = 0; s < S; ++s) t[((size_t)b * S + s) * ch + c] = h[((size_t)b * ch + c) * S + s];
+      return t;
+    };
+    std::vector<half_t> gt = to_tokens(g, K1), r1 = to_tokens(res1, C), r2 = to_tokens(res2, C);
+    half_t* dg = sc.dev<half_t>(gt.size(), gt.data());
+    half_t* dr1 = sc.dev<half_t>(r1.size(), r1.data());
+    half_t* dr2 = sc.dev<half_t>(r2.size(), r2.data());
+    half_t* dw1 = sc.dev<half_t>((size_t)C * K1, reinterpret_cast<const half_t*>(w1));
+    half_t* dw2 = sc.dev<half_t>((size_t)C * C, reinterpret_cast<const half_t*>(w2));
+    float* db1 = sc.dev<float>(C, b1);
+    float* db2 = sc.dev<float>(C, b2);
+    half_t* dh3 = sc.dev<half_t>((size_t)M * C);
+    half_t* o = sc.dev<half_t>((size_t)M * C);
+    const size_t pf = gn_sums ? groupnorm_scratch_floats(B, S, groups) : 0;
+    float* partial = gn_sums ? sc.dev<float>(pf) : nullptr;
+    if (partial) {   // poison: only what the producer wrote may be folded
+      std::vector<float> poison(pf, 1.0e30f);
+      SD_HIP(hipMemcpy(partial, poison.data(), pf * sizeof(float), hipMemcpyHostToDevice));
+    }
+    int n_entries = 0;
+    if (fused) {
+      half_t* w1_t = sc.dev<half_t>((size_t)C * K1);
+      half_t* w2_t = sc.dev<half_t>((size_t)C * C);
+      launch_xattn_out_retile_nk(dw1, w1_t, C, K1, sc.stream);
+      launch_xattn_out_retile_nk(dw2, w2_t, C, C, sc.stream);
+      FfnProjDesc d;
+      d.g = dg; d.w1_t = w1_t; d.b1 = db1; d.res1 = dr1; d.w2_t = w2_t; d.b2 = db2; d.res2 = dr2; d.out = o;
+      d.gn_partial = partial; d.gn_groups = groups; d.M = M; d.C = C; d.K1 = K1; d.S = S;
+      sc.timed(iters, ms, [&] { n_entries = launch_ffn_proj(d, sc.stream); });
+    } else {
+      auto gemm_res = [&](const half_t* in, int cin, const half_t* w, const float* bias, const half_t* res, half_t* dst) {
+        ConvDesc cd;
+        cd.x0 = in; cd.C0 = cin; cd.w = w; cd.bias = bias; cd.res = res; cd.out = dst;
+        cd.B = B; cd.Hi = 1; cd.Wi = S; cd.Ho = 1; cd.Wo = S; cd.N = C;
+        SD_REQUIRE(conv_fast_path_ok(cd), kInvalidArgument, "ffn_out_proj: off the MFMA path");
+        return cd;
+      };
+      ConvDesc c1 = gemm_res(dg, K1, dw1, db1, dr1, dh3);
+      ConvDesc c2 = gemm_res(dh3, C, dw2, db2, dr2, o);
+      c2.gn_partial = partial;
+      c2.gn_groups = groups;
+      ConvWorkspace ws;
+      ws.partial_bytes = std::max(conv_workspace_bytes(c1), conv_workspace_bytes(c2));
+      if (ws.partial_bytes) ws.partial = reinterpret_cast<float*>(sc.dev<char>(ws.partial_bytes));
+      sc.timed(iters, ms, [&] {
+        launch_conv(c1, ws, sc.stream);
+        n_entries = launch_conv(c2, ws, sc.stream);
+      });
+    }
+    std::vector<half_t> ot((size_t)M * C);
+    SD_HIP(hipMemcpy(ot.data(), o, ot.size() * 2, hipMemcpyDeviceToHost));
+    half_t* oh = reinterpret_cast<half_t*>(out);
+    for (int b = 0; b < B; ++b)
+      for (int c = 0; c < C; ++c)
+        for (int s = 0; s < S; ++s) oh[((size_t)b * C + c) * S + s] = ot[((size_t)b * S + s) * C + c];
+    if (gn_sums) {   // the producer's entries folded on the host: (sum, sumsq) per (sample, group); -1 entries: none written
+      std::vector<float> hp(pf);
+      SD_HIP(hipMemcpy(hp.data(), partial, pf * sizeof(float), hipMemcpyDeviceToHost));
+      for (int b = 0; b < B; ++b)
+        for (int gi = 0; gi < groups; ++gi) {
+          double s1 = 0.0, s2 = 0.0;
+          for (int e = 0; e < n_entries; ++e) {
+            s1 += hp[(((size_t)b * groups + gi) * kGnMaxSlabs + e) * 2];
+            s2 += hp[(((size_t)b * groups + gi) * kGnMaxSlabs + e) * 2 + 1];
+          }
+          gn_sums[((size_t)b * groups + gi) * 2] = n_entries ? (float)s1 : NAN;
+          gn_sums[((size_t)b * groups + gi) * 2 + 1] = n_entries ? (float)s2 : NAN;
+        }
+    }
+  });
+}
+
 int sd_op_geglu(const void* x, const void* w, const float* bias, void* out, int M, int C, int N2, int iters, float* ms) {
   return guarded([&] {
     SD_REQUIRE(x && w && out && N2 % 2 == 0, kInvalidArgument, "bad GEGLU arguments");

@@ -213,6 +213,27 @@ struct XAttnOutDesc {
 bool xattn_out_ok(int C, int heads, int S, int L);
 void launch_xattn_out_retile(const half_t* w, half_t* wt, int C, hipStream_t s);   // [C][C] row-major -> fragment-major
 void launch_xattn_out(const XAttnOutDesc& d, hipStream_t s);
+// The tail of a SpatialTransformer in one launch (xattn_out.hip ffn_proj_kernel): out = res2 + proj_out(res1 + ff.net.2(g) + b1) + b2
+// (unet.py:591 FeedForward.net.2 + residual, :561-563 proj_out + residual); C = 320 only.  g [M][K1 = 4C] the GEGLU product,
+// w1_t (C x K1) / w2_t (C x C) fragment-major (launch_xattn_out_retile_nk), res1 = the block's h2, res2 = the transformer's input,
+// out [M][C].  gn_partial / gn_groups as ConvDesc: GroupNorm statistics of the output for its consumer; returns the entries per
+// (sample, group) written (S / 32, or 0).
+struct FfnProjDesc {
+  const half_t* g = nullptr;
+  const half_t* w1_t = nullptr;
+  const float* b1 = nullptr;
+  const half_t* res1 = nullptr;
+  const half_t* w2_t = nullptr;
+  const float* b2 = nullptr;
+  const half_t* res2 = nullptr;
+  half_t* out = nullptr;
+  float* gn_partial = nullptr;
+  int gn_groups = 0;
+  int M = 0, C = 0, K1 = 0, S = 0;   // S: tokens per sample
+};
+bool ffn_proj_ok(int C, int K1, int M, int S);
+int launch_ffn_proj(const FfnProjDesc& d, hipStream_t s);
+void launch_xattn_out_retile_nk(const half_t* w, half_t* wt, int N, int K, hipStream_t s);   // [N][K] row-major -> fragment-major
 
 // ---------------------------------------------------------------------------------------------
 // K6/K7: norms (norm.hip)

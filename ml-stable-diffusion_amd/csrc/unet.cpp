@@ -666,7 +666,8 @@ Tensor UNet::attention(std::vector<Op>& ops, const Tensor& q, const half_t* k, c
 }
 
 // unet.py:586-591 (+ CrossAttention :87-118, FeedForward/GEGLU :594-617)
-Tensor UNet::transformer_block(std::vector<Op>& ops, const std::string& b, const Tensor& h, int heads) {
+Tensor UNet::transformer_block(std::vector<Op>& ops, const std::string& b, const Tensor& h, int heads, const std::string* proj_out,
+                               const Tensor* tres, bool* tail_done) {
   const int C = h.C, S = h.H * h.W, L = cfg_.context_len;
   // --- self attention.  MFMA-tileable widths: norm1 is folded into ONE fused q|k|v GEMM whose V
   // columns leave token-transposed (attention's V^T operand); otherwise LN + stacked q|k + V^T GEMMs.
@@ -698,11 +699,12 @@ Tensor UNet::transformer_block(std::vector<Op>& ops, const std::string& b, const
   Tensor q = qk;
   q.C = C;   // logical width of q; rows are 2C apart
   Tensor a1 = attention(ops, q, qk.p + C, vtp, heads, S, S, 2 * C, ldv, 2 * C, vt_perm, q_pre);
-  // the cross-attention branch - norm2 -> to_q -> attention -> to_out -> + h1 - as ONE launch (xattn_out.hip: 32 tokens x all heads
-  // per workgroup).  SD_XATTN_OUT (with SD_TUNE): 1 = at the 5-head level, 2 = at the 10-head level too (measured slower there:
-  // 64 workgroups of ten waves), 3 = 5-head level with the self-attention's to_out + residual in front, in the same launch (h1 then
-  // never goes to HBM); measured in LAB_NOTES.md r5
-  static const int xo_mode = tune_env_int("SD_XATTN_OUT", 0);
+  // attn1.to_out + residual -> norm2 -> to_q -> cross-attention -> attn2.to_out + residual as ONE launch at the 5-head level
+  // (xattn_out.hip: 32 tokens x all heads per workgroup; h1 never goes to HBM): three launches of 11.6 + 15.3 + 11.6 us become one of
+  // 23.7, step 4.493 -> 4.443 ms (profiles/r05_xattn_out_stage2_ab.log).  SD_XATTN_OUT (with SD_TUNE) for the A/B: 0 = the three
+  // launches, 1 = only the cross-attention branch in one launch (-0.024 ms), 2 = that at the 10-head level too (64 workgroups of ten
+  // waves: +0.04 ms), 3 = the default
+  static const int xo_mode = tune_env_int("SD_XATTN_OUT", 3);
   const bool xo_branch = xo_mode != 0 && !f32_ && can_fold_ln(h, C, false) && xattn_fused_ok(C, heads, S, L) && xattn_out_ok(C, heads, S, L) &&
                          (heads == 5 || xo_mode == 2);
   const bool xo_pre = xo_branch && xo_mode == 3 && heads == 5;
@@ -809,6 +811,48 @@ Tensor UNet::transformer_block(std::vector<Op>& ops, const std::string& b, const
     Tensor n3 = layer_norm(ops, b + ".norm3", h2);
     g = conv(ops, b + ".ff.net.0.proj", n3, nullptr, 8 * C, 1, 1, 1, true, nullptr, nullptr, kOutGeglu);
   }
+  // the tail of the SpatialTransformer - ff.net.2 + residual -> proj_out + residual - as ONE launch at the 320-channel level
+  // (ffn_proj_kernel: the intermediate never goes to HBM, the output's GroupNorm statistics for the next resnet come out of it);
+  // SD_FFN_PROJ (with SD_TUNE) for the A/B, measured in LAB_NOTES.md r5
+  static const int fp_mode = tune_env_int("SD_FFN_PROJ", 0);
+  if (proj_out && tres && tail_done && fp_mode != 0 && !f32_ && g.C == 4 * C && ffn_proj_ok(C, 4 * C, h.M(), S)) {
+    const half_t* w1 = upload_conv_weight(b + ".ff.net.2", C, 4 * C, 1, false);
+    half_t* w1_t = arena_.alloc_n<half_t>((size_t)C * 4 * C);
+    launch_xattn_out_retile_nk(w1, w1_t, C, 4 * C, stream_);
+    const half_t* w2 = upload_conv_weight(*proj_out, C, C, 1, false);
+    half_t* w2_t = arena_.alloc_n<half_t>((size_t)C * C);
+    launch_xattn_out_retile_nk(w2, w2_t, C, C, stream_);
+    Tensor out = new_tensor(h.B, h.H, h.W, C);
+    FfnProjDesc d;
+    d.g = g.p;
+    d.w1_t = w1_t;
+    d.b1 = upload_vec(b + ".ff.net.2.bias", C);
+    d.res1 = h2.p;
+    d.w2_t = w2_t;
+    d.b2 = upload_vec(*proj_out + ".bias", C);
+    d.res2 = tres->p;
+    d.out = out.p;
+    d.M = h.M();
+    d.C = C;
+    d.K1 = 4 * C;
+    d.S = S;
+    auto hook = std::make_shared<GnHook>();   // a GroupNorm built later over this tensor may ask for its statistics (as conv_w)
+    out.gn = hook;
+    hook->ops_pos = (int)ops.size();
+    hook->ops_list = &ops;
+    ops.push_back([d, hook](hipStream_t s) {
+      FfnProjDesc dd = d;
+      dd.gn_partial = hook->partial;
+      dd.gn_groups = hook->groups;
+      hook->produced(launch_ffn_proj(dd, s));
+    });
+    char buf[256];
+    snprintf(buf, sizeof(buf), "gemm1x1 %d->%d @%dx%d M=%d K=%d %s.ff.net.2 + residual + proj_out + residual", 4 * C, C, h.H, h.W, h.M(), 4 * C, b.c_str());
+    ops.back().label = buf;
+    ops.back().flop = 2.0 * h.M() * (double)C * (4 * C) + 2.0 * h.M() * (double)C * C;
+    *tail_done = true;
+    return out;
+  }
   return conv(ops, b + ".ff.net.2", g, nullptr, C, 1, 1, 1, true, nullptr, h2.p);
 }
 
@@ -874,7 +918,14 @@ Tensor UNet::transformer(std::vector<Op>& ops, const std::string& p, const Tenso
     Tensor t0 = group_norm(ops, p + ".norm", x, nullptr, 1e-6f, false);
     h = conv(ops, p + ".proj_in", t0, nullptr, x.C, 1, 1, 1, true, nullptr, nullptr);
   }
-  for (int d = 0; d < depth; ++d) h = transformer_block(ops, p + ".transformer_blocks." + std::to_string(d), h, heads);
+  bool tail_done = false;
+  const std::string proj_name = p + ".proj_out";
+  for (int d = 0; d < depth; ++d) {
+    const bool last = d == depth - 1;
+    h = transformer_block(ops, p + ".transformer_blocks." + std::to_string(d), h, heads, last ? &proj_name : nullptr, last ? &x : nullptr,
+                          last ? &tail_done : nullptr);
+  }
+  if (tail_done) return h;
   return conv(ops, p + ".proj_out", h, nullptr, x.C, 1, 1, 1, true, nullptr, x.p);
 }
 

@@ -138,7 +138,11 @@ class UNet {
   Tensor resnet(std::vector<Op>& ops, const std::string& p, const Tensor& x, const Tensor* x2, int cout,
                 bool has_temb = true);
   Tensor transformer(std::vector<Op>& ops, const std::string& p, const Tensor& x, int heads, int depth);
-  Tensor transformer_block(std::vector<Op>& ops, const std::string& b, const Tensor& h, int heads);
+  // proj_out / tres (last block of a SpatialTransformer only): the transformer's proj_out and its residual - where the tail
+  // ff.net.2 + residual -> proj_out + residual runs as ONE launch (xattn_out.hip ffn_proj_kernel) *tail_done is set and the returned
+  // tensor is the transformer's output
+  Tensor transformer_block(std::vector<Op>& ops, const std::string& b, const Tensor& h, int heads, const std::string* proj_out = nullptr,
+                           const Tensor* tres = nullptr, bool* tail_done = nullptr);
   Tensor vae_attention(std::vector<Op>& ops, const std::string& p, const Tensor& h);
   Tensor attention(std::vector<Op>& ops, const Tensor& q, const half_t* k, const half_t* vt, int heads, int Sq,
                    int Sk, int ldk, int ldv, int ldq, bool vt_perm = false, bool q_prescaled = false);

@@ -387,6 +387,160 @@ void launch_nw(const XOArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k, dim3(a.M / XO_TOK), dim3(NW * 64), lds, s, a);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The tail of a SpatialTransformer as ONE launch (unet.py:591 FeedForward.net.2 + residual, then :561-563 proj_out + residual):
+//     h3  = h2 + ff.net.2(g) + b          g = the GEGLU product [M][4C]
+//     out = x  + proj_out(h3) + b_p       x = the transformer's input
+// Same workgroup shape as above (32 tokens x C / 64 waves, wave w = output-channel block w of both GEMMs, weights global -> VGPR
+// in fragment order): phase A walks K = 4C over the LDS tile of g, its result - fp16 like the tensor the separate launch stores -
+// is the LDS tile phase B multiplies; h3 never goes to HBM.  The output leaves through an LDS tile: coalesced 16-B stores, and
+// - when the consumer is a GroupNorm (the next resnet's norm1, unet.py:472) - its (sum, sumsq) partial per (sample, group) of
+// this 32-token tile, in the format of the conv epilogues (entry = tile index inside the sample; fixed-order sums, no atomics).
+// ---------------------------------------------------------------------------------------------
+struct FPArgs {
+  const half_t* g;
+  const half8* w1_t;
+  const float* b1;
+  const half_t* res1;
+  const half8* w2_t;
+  const float* b2;
+  const half_t* res2;
+  half_t* out;
+  float* gn_partial;
+  int M, S, gn_G;
+};
+
+template <int NW>
+constexpr size_t fp_lds_bytes() {
+  return (size_t)XO_TOK * (4 * NW * 64 + 8) * 2 + (size_t)XO_TOK * (NW * 64 + 8) * 2 + (size_t)4 * NW * 64 * sizeof(float);
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void ffn_proj_kernel(FPArgs a) {
+  constexpr int C = NW * 64, K1 = 4 * C, ROWG = K1 + 8, ROW = C + 8, NT = NW * 64;
+  constexpr int BATCH = 4, NBUF = 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* gs = reinterpret_cast<half_t*>(smem);            // [32][ROWG]  g rows; behind phase A: the output tile [32][ROW]
+  half_t* ts = gs + XO_TOK * ROWG;                         // [32][ROW]   h3
+  float* sconst = reinterpret_cast<float*>(ts + XO_TOK * ROW);   // [C] b1 | [C] b2 | [C] column sums | [C] column sums of squares
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int m_blk = blockIdx.x * XO_TOK;
+
+  // ---- everything this workgroup reads before phase A is requested up front: weight batches, the g tile (16 chunks per thread),
+  // both residual slices of this lane, the constants ----
+  XoW<BATCH, NBUF> wr;
+  xo_prefetch<K1 / 16, BATCH, NBUF>(wr, a.w1_t, 2 * wave, lane);
+  constexpr int GCH = XO_TOK * (K1 / 8) / NT;              // = 16
+  half8 gv[GCH];
+#pragma unroll
+  for (int i = 0; i < GCH; ++i) {
+    const int idx = tid + NT * i, row = idx / (K1 / 8), c8 = idx - row * (K1 / 8);
+    gv[i] = *reinterpret_cast<const half8*>(a.g + (size_t)(m_blk + row) * K1 + c8 * 8);
+  }
+  const float cb1 = a.b1[tid], cb2 = a.b2[tid];
+  half4 r1[2][4], r2[2][4];
+  {
+    const size_t off = (size_t)(m_blk + l31) * C + wave * XO_D + 4 * hi;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        r1[j][q] = *reinterpret_cast<const half4*>(a.res1 + off + j * 32 + 8 * q);
+        r2[j][q] = *reinterpret_cast<const half4*>(a.res2 + off + j * 32 + 8 * q);
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < GCH; ++i) {
+    const int idx = tid + NT * i, row = idx / (K1 / 8), c8 = idx - row * (K1 / 8);
+    *reinterpret_cast<half8*>(gs + row * ROWG + c8 * 8) = gv[i];
+  }
+  sconst[tid] = cb1;
+  sconst[C + tid] = cb2;
+  __syncthreads();                                         // the g tile and the constants are visible
+
+  // ---- phase A: h3^T[64 * wave ..][32] = W1 . g^T + b1 + h2 -> LDS tile (fp16, as the tensor would be) ----
+  floatx16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  float d1 = 0.f, d2 = 0.f;
+  xo_gemm<K1 / 16, BATCH, NBUF, false>(wr, a.w1_t, 2 * wave, gs, ROWG, lane, acc, d1, d2);
+  xo_prefetch<C / 16, BATCH, NBUF>(wr, a.w2_t, 2 * wave, lane);   // phase B's first batches: in flight under the epilogue and the barrier
+  {
+    half_t* trow = ts + l31 * ROW + wave * XO_D + 4 * hi;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const floatx4 bb = *reinterpret_cast<const floatx4*>(sconst + wave * XO_D + j * 32 + 8 * q + 4 * hi);
+        half4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (half_t)((float)(half_t)(acc[j][4 * q + e] + bb[e]) + (float)r1[j][q][e]);
+        *reinterpret_cast<half4*>(trow + j * 32 + 8 * q) = o;
+      }
+  }
+  __syncthreads();                                         // h3 of every channel block is in the tile; nobody reads g any more
+
+  // ---- phase B: out^T[64 * wave ..][32] = Wp . h3^T + b_p + x -> LDS tile (over the g tile) ----
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  xo_gemm<C / 16, BATCH, NBUF, false>(wr, a.w2_t, 2 * wave, ts, ROW, lane, acc, d1, d2);
+  half_t* ot = gs;                                         // [32][ROW]
+  {
+    half_t* orow = ot + l31 * ROW + wave * XO_D + 4 * hi;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const floatx4 bb = *reinterpret_cast<const floatx4*>(sconst + C + wave * XO_D + j * 32 + 8 * q + 4 * hi);
+        half4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (half_t)((float)(half_t)(acc[j][4 * q + e] + bb[e]) + (float)r2[j][q][e]);
+        *reinterpret_cast<half4*>(orow + j * 32 + 8 * q) = o;
+      }
+  }
+  __syncthreads();                                         // the output tile is complete
+  // coalesced stores: NT == C threads, 4 chunks of 16 B each
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + NT * i, row = idx / (C / 8), c8 = idx - row * (C / 8);
+    *reinterpret_cast<half8*>(a.out + (size_t)(m_blk + row) * C + c8 * 8) = *reinterpret_cast<const half8*>(ot + row * ROW + c8 * 8);
+  }
+  if (a.gn_partial == nullptr) return;                     // (block-uniform)
+  // GroupNorm statistics of the stored (fp16-rounded) values: thread = channel, fixed-order sums over the 32 tokens, then
+  // thread = group folds its channels
+  {
+    float s = 0.f, q = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < XO_TOK; ++r) {
+      const float f = (float)ot[r * ROW + tid];
+      s += f;
+      q = fmaf(f, f, q);
+    }
+    sconst[2 * C + tid] = s;
+    sconst[3 * C + tid] = q;
+  }
+  __syncthreads();
+  if (tid < a.gn_G) {
+    const int cpg = C / a.gn_G;
+    float s = 0.f, q = 0.f;
+    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+      s += sconst[2 * C + c];
+      q += sconst[3 * C + c];
+    }
+    const int b = m_blk / a.S, tile = (m_blk - b * a.S) / XO_TOK;
+    float* dst = a.gn_partial + (((size_t)b * a.gn_G + tid) * kGnMaxSlabs + tile) * 2;
+    dst[0] = s;
+    dst[1] = q;
+  }
+}
+
 }  // namespace
 
 bool xattn_out_ok(int C, int heads, int S, int L) {
@@ -413,6 +567,34 @@ void launch_xattn_out(const XAttnOutDesc& d, hipStream_t s) {
   if (d.heads == 5 && pre) launch_nw<5, true>(a, s);
   else if (d.heads == 5) launch_nw<5, false>(a, s);
   else launch_nw<10, false>(a, s);
+  SD_HIP(hipGetLastError());
+}
+
+bool ffn_proj_ok(int C, int K1, int M, int S) {
+  return C == 320 && K1 == 4 * C && M >= XO_TOK && M % S == 0 && S % XO_TOK == 0;
+}
+
+int launch_ffn_proj(const FfnProjDesc& d, hipStream_t s) {
+  SD_REQUIRE(ffn_proj_ok(d.C, d.K1, d.M, d.S) && d.g && d.w1_t && d.b1 && d.res1 && d.w2_t && d.b2 && d.res2 && d.out, kInvalidArgument,
+             "ffn_proj: C=%d K1=%d M=%d S=%d", d.C, d.K1, d.M, d.S);
+  const int tiles = d.S / XO_TOK;
+  const bool stats = d.gn_partial != nullptr && d.gn_groups >= 1 && d.gn_groups <= 64 && d.C % d.gn_groups == 0 && tiles <= 128;
+  FPArgs a{d.g, reinterpret_cast<const half8*>(d.w1_t), d.b1, d.res1, reinterpret_cast<const half8*>(d.w2_t), d.b2, d.res2, d.out,
+           stats ? d.gn_partial : nullptr, d.M, d.S, d.gn_groups};
+  constexpr size_t lds = fp_lds_bytes<5>();
+  static_assert(lds <= 160 * 1024, "LDS");
+  auto k = ffn_proj_kernel<5>;
+  static DynLdsOnce once;
+  once.set(k, lds);
+  hipLaunchKernelGGL(k, dim3(d.M / XO_TOK), dim3(5 * 64), lds, s, a);
+  SD_HIP(hipGetLastError());
+  return stats ? tiles : 0;
+}
+
+void launch_xattn_out_retile_nk(const half_t* w, half_t* wt, int N, int K, hipStream_t s) {
+  SD_REQUIRE(N % 32 == 0 && K % 16 == 0, kInvalidArgument, "fragment-major retile: N=%d K=%d", N, K);
+  const int n = N * K / 8;
+  hipLaunchKernelGGL(xo_retile_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, reinterpret_cast<half8*>(wt), N, K);
   SD_HIP(hipGetLastError());
 }
 

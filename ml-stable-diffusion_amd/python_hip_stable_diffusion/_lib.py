@@ -98,6 +98,7 @@ SYMBOLS = [
     ("sd_op_conv2d_groupnorm_conv3x3", _I, [_P, _P, _FP, _P, _FP, _FP, _P, _FP, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _I,
                                             C.POINTER(_I), _I, _FP]),
     ("sd_op_cross_attention_fused", _I, [_P, _FP, _FP, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _FP]),
+    ("sd_op_ffn_out_proj", _I, [_P, _P, _FP, _P, _P, _FP, _P, _P, _FP, _I, _I, _I, _I, _I, _I, _FP]),
     ("sd_op_cross_attention_block", _I, [_P, _FP, _FP, _P, _P, _P, _P, _FP, _P, _P, _FP, _P, _I, _I, _I, _I, _F, _I, _I, _FP]),
     ("sd_op_geglu", _I, [_P, _P, _FP, _P, _I, _I, _I, _I, _FP]),
     ("sd_op_timestep_embedding", _I, [_FP, _FP, _I, _I, _I, _F]),
@@ -325,6 +326,23 @@ def cross_attention_block(x, ln_weight, ln_bias, wq, k, v, wo, bo, heads, eps=1e
     check(lib().sd_op_cross_attention_block(ptr(x), fptr(ln_weight), fptr(ln_bias), ptr(wq), ptr(k), ptr(v), ptr(wo), fptr(bo), ptr(a1), ptr(wo1),
                                             fptr(bo1), ptr(out), B, heads, Sq, Sk, eps, int(fused), iters, C.byref(ms)))
     return out, ms.value
+
+
+def ffn_out_proj(g, w1, b1, res1, w2, b2, res2, groups=0, fused=True, iters=1):
+    """res2 + proj_out(res1 + ff.net.2(g) + b1) + b2 - the tail of a SpatialTransformer; fused=True runs it as ONE launch (C = 320,
+    S % 32 == 0).  g (B,4C,1,S), res1 / res2 (B,C,1,S) f16, w1 (C,4C), w2 (C,C) f16, b1 / b2 (C) f32.  groups > 0: also returns the
+    GroupNorm statistics the launch left for its consumer, folded: (B, groups, 2) = (sum, sum of squares).  Returns (out, gn_sums or None, ms)."""
+    g, res1, res2, w1, w2 = f16(g), f16(res1), f16(res2), f16(w1), f16(w2)
+    B, Cn, _, S = res1.shape
+    if g.shape != (B, 4 * Cn, 1, S) or res2.shape != res1.shape or w1.shape != (Cn, 4 * Cn) or w2.shape != (Cn, Cn):
+        raise ValueError("ffn_out_proj: inconsistent shapes")
+    b1, b2 = f32(b1), f32(b2)
+    out = np.empty_like(res1)
+    sums = np.empty((B, groups, 2), np.float32) if groups > 0 else None
+    ms = C.c_float(0)
+    check(lib().sd_op_ffn_out_proj(ptr(g), ptr(w1), fptr(b1), ptr(res1), ptr(w2), fptr(b2), ptr(res2), ptr(out), fptr(sums), B, Cn, S, groups,
+                                   int(fused), iters, C.byref(ms)))
+    return out, sums, ms.value
 
 
 def cross_attention_fused(x, ln_weight, ln_bias, wq, k, v, heads, eps=1e-5, nst=0, iters=1):

@@ -563,3 +563,44 @@ def test_cross_attention_block_refuses_other_head_counts():
     g = np.ones(c, np.float32)
     with pytest.raises(NotImplementedError):     # 20 heads: a workgroup would need 20 waves
         _lib.cross_attention_block(z, g, g, w, kk, kk, w, g, 20, fused=True)
+
+
+# ---------------------------------------------------------------- the tail of a SpatialTransformer as ONE launch
+FFP_CASES = [(2, 4096), (1, 32), (3, 96), (2, 576)]   # (B, S) at C = 320
+
+
+@pytest.mark.parametrize("case", FFP_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_ffn_out_and_proj_out_in_one_launch(case):
+    """ff.net.2 + residual -> proj_out + residual (unet.py:591, :561-563) as ONE launch (xattn_out.hip ffn_proj_kernel) against fp32
+    torch (the intermediate rounded to fp16 where the separate launch would store it) and against the two GEMM launches; the
+    GroupNorm statistics it leaves for the next resnet's norm1 against the sums of its own fp16 output."""
+    b, s_ = case
+    c = 320
+    rs = np.random.RandomState(11 * s_ + b)
+    g = h16(rs.randn(b, 4 * c, 1, s_))
+    w1 = h16(rs.randn(c, 4 * c) / np.sqrt(4 * c))
+    b1 = (0.1 * rs.randn(c)).astype(np.float32)
+    res1 = h16(rs.randn(b, c, 1, s_))
+    w2 = h16(rs.randn(c, c) / np.sqrt(c))
+    b2 = (0.1 * rs.randn(c)).astype(np.float32)
+    res2 = h16(rs.randn(b, c, 1, s_))
+    t = lambda a: torch.from_numpy(np.asarray(a, np.float32))
+    h3 = t(res1) + F.conv2d(t(g), t(w1)[:, :, None, None], t(b1))
+    ref = (t(res2) + F.conv2d(t(h16(h3.numpy())), t(w2)[:, :, None, None], t(b2))).numpy()
+    two, sums_two, _ = _lib.ffn_out_proj(g, w1, b1, res1, w2, b2, res2, groups=32, fused=False)
+    one, sums, _ = _lib.ffn_out_proj(g, w1, b1, res1, w2, b2, res2, groups=32, fused=True)
+    close(two, ref, f"ff.net.2 + proj_out, two launches {case}")
+    close(one, ref, f"ff.net.2 + proj_out, one launch {case}")
+    o32 = one.astype(np.float64).reshape(b, 32, c // 32, s_)
+    want = np.stack([o32.sum(axis=(2, 3)), (o32 ** 2).sum(axis=(2, 3))], axis=-1)
+    assert np.isfinite(sums).all()
+    assert np.abs(sums - want).max() <= 2e-4 * np.abs(want).max() + 1e-3, np.abs(sums - want).max()
+    again, sums2, _ = _lib.ffn_out_proj(g, w1, b1, res1, w2, b2, res2, groups=32, fused=True, iters=3)
+    assert np.array_equal(one, again) and np.array_equal(sums, sums2)
+
+
+def test_ffn_out_proj_refuses_other_widths():
+    z = lambda *sh: np.zeros(sh, np.float16)
+    with pytest.raises(NotImplementedError):
+        _lib.ffn_out_proj(z(1, 2560, 1, 32), z(640, 2560), np.zeros(640, np.float32), z(1, 640, 1, 32), z(640, 640), np.zeros(640, np.float32),
+                          z(1, 640, 1, 32), fused=True)
