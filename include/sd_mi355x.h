@@ -335,13 +335,15 @@ int sd_numpy_randn(uint32_t seed, double* out, size_t n);
  * (Philox4x32-10, NvRandomSource.swift:25-80; `offset` = number of arrays drawn before).  Host-side. */
 int sd_torch_randn(uint32_t seed, double* out, size_t n);
 int sd_philox_randn(uint64_t seed, uint32_t offset, double* out, size_t n);
-/* Box calibration for bench.py (no reference counterpart: measurement infrastructure).  out7[0] = device copy GB/s (1 GiB,
- * read + written bytes), out7[1] = dense v_mfma_f32_32x32x16_f16 register loop TFLOP/s, out7[2] = us per launch of a captured
- * graph of 323 empty launches (the step's launch count), out7[3] = us per launch of a 323-launch chain of short dependent
- * kernels on cold operands, out7[4] = us per launch of a 323-launch chain in which every workgroup reads 16 KB that a workgroup
- * on ANOTHER XCD wrote in the previous launch (8 MB handed over per launch), out7[5] / out7[6] = ns per dependent load from
- * never-touched HBM lines / from a 2-MB table resident in the caches.  Allocates and frees 2 GiB of device memory; synchronous. */
-int sd_calibrate(int device, float* out7);
+/* Box calibration for bench.py (no reference counterpart: measurement infrastructure).  out8[0] = device copy GB/s (1 GiB,
+ * read + written bytes), out8[1] = dense v_mfma_f32_32x32x16_f16 register loop TFLOP/s, out8[2] = us per launch of a captured
+ * graph of 323 empty launches (the step's launch count), out8[3] = us per launch of a 323-launch chain of short dependent
+ * kernels on cold operands, out8[4] = us per launch of a 323-launch chain in which every workgroup reads 16 KB that a workgroup
+ * on ANOTHER XCD wrote in the previous launch (8 MB handed over per launch), out8[5] / out8[6] = ns per dependent load from
+ * never-touched HBM lines / from a 2-MB table resident in the caches, out8[7] = us per launch of a 323-launch chain of SMALL
+ * grids (64 workgroups: 4 MB read, a reduction behind one barrier, 4 MB written - the shape of the launches that a slow box of the
+ * pool runs 1.3-2 x slower).  Allocates and frees 2 GiB of device memory; synchronous. */
+int sd_calibrate(int device, float* out8);
 /* MFMA fragment layout self-check used by the build/smoke tests (returns 0 when the hardware
  * layout matches what the kernels assume). */
 int sd_selftest_mfma(void);

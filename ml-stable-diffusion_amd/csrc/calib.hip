@@ -72,6 +72,29 @@ __global__ __launch_bounds__(256) void calib_handover_kernel(const floatx4* __re
   }
 }
 
+// A SMALL grid with a reduction in the middle (the shape of the single-launch GroupNorm, of the 16x16-level attention, of conv_in /
+// conv_out: 64 workgroups of 256 threads): every thread reads 16 x 16 B the previous launch wrote, the workgroup reduces through
+// LDS behind one barrier, every thread writes 16 x 16 B.  Session E of round 5 (profiles/r05_ffn_proj_ab_slow_box.log) met a box that
+// runs the step 20 % slower with all seven figures above unchanged: on it every launch of MANY workgroups took its usual time and
+// the launches of 64-160 workgroups 1.3-2.0 x as long.
+__global__ __launch_bounds__(256) void calib_small_grid_kernel(const floatx4* __restrict__ prev, floatx4* __restrict__ next) {
+  __shared__ float red[4];
+  const size_t base = (size_t)blockIdx.x * 16 * 256 + threadIdx.x;
+  floatx4 v[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] = prev[base + (size_t)k * 256];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float t = ((red[0] + red[1]) + (red[2] + red[3])) * 1.0e-9f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) next[base + (size_t)k * 256] = v[k] * 0.5f + floatx4{t, t, t, t};
+}
+
 // the table holds, at element i * stride, the index of the next element; one lane walks it
 __global__ void calib_chase_init_kernel(unsigned* tab, unsigned n, unsigned stride) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -106,7 +129,7 @@ float time_graph(hipStream_t st, hipGraphExec_t g, int reps) {
 
 }  // namespace
 
-// out[0..6] = copy_gbs, mfma_tflops, empty_launch_us, chain_us, handover_us, latency_ns (HBM), latency_l2_ns
+// out[0..7] = copy_gbs, mfma_tflops, empty_launch_us, chain_us, handover_us, latency_ns (HBM), latency_l2_ns, small_grid_us
 void run_calibration(int device, float* out) {
   SD_HIP(hipSetDevice(device));
   hipStream_t st;
@@ -188,6 +211,16 @@ void run_calibration(int device, float* out) {
         hipLaunchKernelGGL(calib_handover_kernel, dim3(512), dim3(256), 0, st, (i & 1) ? b1 : b0, (i & 1) ? b0 : b1);
     });
     out[4] = time_graph(st, ge, 10) * 1e3f / (float)kLaunches;
+    (void)hipGraphExecDestroy(ge);
+  }
+  {   // (g) small-grid chain: 64 workgroups, 4 MB in / 4 MB out per launch, ping-pong between the starts of src and dst
+    floatx4* b0 = src;
+    floatx4* b1 = dst;
+    hipGraphExec_t ge = capture([&] {
+      for (int i = 0; i < kLaunches; ++i)
+        hipLaunchKernelGGL(calib_small_grid_kernel, dim3(64), dim3(256), 0, st, (i & 1) ? b1 : b0, (i & 1) ? b0 : b1);
+    });
+    out[7] = time_graph(st, ge, 10) * 1e3f / (float)kLaunches;
     (void)hipGraphExecDestroy(ge);
   }
   {   // (f) dependent-load latency: never-touched lines of the 1-GiB table, then a 2-MB table that was just walked

@@ -813,8 +813,9 @@ Tensor UNet::transformer_block(std::vector<Op>& ops, const std::string& b, const
   }
   // the tail of the SpatialTransformer - ff.net.2 + residual -> proj_out + residual - as ONE launch at the 320-channel level
   // (ffn_proj_kernel: the intermediate never goes to HBM, the output's GroupNorm statistics for the next resnet come out of it);
-  // SD_FFN_PROJ (with SD_TUNE) for the A/B, measured in LAB_NOTES.md r5
-  static const int fp_mode = tune_env_int("SD_FFN_PROJ", 0);
+  // five launches less per step, 5.402 -> 5.392 ms on the (slow) box it was measured on (profiles/r05_ffn_proj_ab_slow_box.log);
+  // SD_FFN_PROJ=0 (with SD_TUNE): the two GEMM launches (A/B)
+  static const int fp_mode = tune_env_int("SD_FFN_PROJ", 1);
   if (proj_out && tres && tail_done && fp_mode != 0 && !f32_ && g.C == 4 * C && ffn_proj_ok(C, 4 * C, h.M(), S)) {
     const half_t* w1 = upload_conv_weight(b + ".ff.net.2", C, 4 * C, 1, false);
     half_t* w1_t = arena_.alloc_n<half_t>((size_t)C * 4 * C);

@@ -12,7 +12,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 files = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_*.log")) + glob.glob(os.path.join(ROOT, "profiles", "r05_*bench*.json")))
-KEYS = ["copy_gbs", "mfma_tflops", "empty_launch_us", "chain_us", "handover_us", "latency_hbm_ns", "latency_cache_ns"]
+KEYS = ["copy_gbs", "mfma_tflops", "empty_launch_us", "chain_us", "handover_us", "latency_hbm_ns", "latency_cache_ns", "small_grid_us"]
 rows = []
 for f in files:
     name = os.path.basename(f)
@@ -31,6 +31,7 @@ for f in files:
         m = re.match(r"ab\[SD_TUNE=1 \] ms/step, it/s: ([\d.]+) ([\d.]+) calib (.*?) sclk", line)
         if m:
             v = [float(x) if x != "None" else None for x in m.group(3).split()]
+            v = (v + [None] * len(KEYS))[:len(KEYS)]   # records older than a figure have none
             per.append((float(m.group(1)), v))
     if per:
         ms = sum(p[0] for p in per) / len(per)
@@ -60,4 +61,22 @@ if spread < 1.05:
           "copy / MFMA / empty-launch / cold-chain figures identical to 1 % - csrc/calib.hip - which is why the hand-over chain and the "
           "dependent-load latencies were added.)")
 else:
-    print("Figures whose ratio follows the step-time ratio are the candidates for bench.py's CALIB_WEIGHTS.")
+    slow = rows[-1]
+    track = []
+    for i, k in enumerate(KEYS):
+        if slow[2][i] is None or ref[2][i] is None:
+            continue
+        time_like = k.endswith("_us") or k.endswith("_ns")
+        r = slow[2][i] / ref[2][i] if time_like else ref[2][i] / slow[2][i]
+        if r >= 1.0 + 0.5 * (spread - 1.0):
+            track.append(f"{k} x{r:.3f}")
+    if track:
+        print("Figures that follow the slowest session's step time (candidates for bench.py's CALIB_WEIGHTS): " + ", ".join(track) + ".")
+    else:
+        print("NONE of the figures measured on the slowest session moved with its step time (all within a few per cent of the reference): "
+              "copy, dense MFMA, empty and cold launch chains, cross-XCD hand-over and dependent-load latencies do not see what makes that "
+              "box slow.  Its per-op profile (profiles/r05_ffn_proj_ab_slow_box.log against r05_xattn_out_stage2_ab.log) does: launches of "
+              "many workgroups (64x64-level convs, the 4096-token attention, weight-streaming convs) take their usual time, launches of "
+              "64-160 workgroups (single-launch GroupNorm x1.84, conv_in / conv_out x1.9-2.0, 16x16-level attention x1.68, 1280->1280 GEMMs "
+              "at M = 512 x1.28) take 1.3-2.0 x as long - hence the eighth figure, small_grid_us (calib.hip), which no session has yet "
+              "measured on both kinds of box.  bench.py's CALIB_WEIGHTS stays empty and `value_normalised` null until one has.")

@@ -29,7 +29,7 @@ for step in "$@"; do
     ab:*)
       kv=${step#ab:}; fl=""
       case "$kv" in *@*) fl=${kv#*@}; kv=${kv%%@*} ;; esac      # "ab:ENV=VAL@--prompts-per-gpu 8": extra bench flags behind @
-      r=$(env ${kv//,/ } timeout 300 python bench.py --cpu-steps 0 --repeats 5 $fl 2>/dev/null | tail -n 1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); g=(d.get('gpu_state') or {}).get('after_timed_region') or {}; c=d.get('calibration') or {}; print(d['ms_per_step'], d['value'], 'calib', c.get('copy_gbs'), c.get('mfma_tflops'), c.get('empty_launch_us'), c.get('chain_us'), c.get('handover_us'), c.get('latency_hbm_ns'), c.get('latency_cache_ns'), 'sclk', g.get('sclk clock speed:'), 'W', g.get('Current Socket Graphics Package Power (W)'))" 2>&1)
+      r=$(env ${kv//,/ } timeout 300 python bench.py --cpu-steps 0 --repeats 5 $fl 2>/dev/null | tail -n 1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); g=(d.get('gpu_state') or {}).get('after_timed_region') or {}; c=d.get('calibration') or {}; print(d['ms_per_step'], d['value'], 'calib', c.get('copy_gbs'), c.get('mfma_tflops'), c.get('empty_launch_us'), c.get('chain_us'), c.get('handover_us'), c.get('latency_hbm_ns'), c.get('latency_cache_ns'), c.get('small_grid_us'), 'sclk', g.get('sclk clock speed:'), 'W', g.get('Current Socket Graphics Package Power (W)'))" 2>&1)
       note "ab[$kv $fl] ms/step, it/s: $r" ;;
     profile)
       timeout 300 python tools/op_profile.py $OUT/op_profile_$TAG.json 2 ORIGINAL > $OUT/op_profile_$TAG.txt 2>&1; note "profile rc=$?"; head -n 28 $OUT/op_profile_$TAG.txt | cut -c1-150 ;;
@@ -64,6 +64,9 @@ for step in "$@"; do
       kv=${step#eprofile:}
       env ${kv//,/ } timeout 300 python tools/op_profile.py $OUT/op_profile_${TAG}_$i.json 2 ORIGINAL > $OUT/op_profile_${TAG}_$i.txt 2>&1; note "profile[$kv] rc=$? $(sed -n 2p $OUT/op_profile_${TAG}_$i.txt)"
       grep -E "conv3x3|groupnorm" $OUT/op_profile_${TAG}_$i.txt | head -n 30 | cut -c1-140 ;;
+    sh:*)   # a shell command inside the session (e.g. copy the PMC file where bench.py looks for it)
+      cmd=${step#sh:}
+      bash -c "$cmd"; note "sh[$cmd] rc=$?" ;;
     tune:*)   # end-to-end plan tuner: "tune:<candidates.json> [model] [latent]" -> gpurun_out/tuned_e2e_<tag>.inc
       ar=${step#tune:}
       SD_TUNE=1 timeout 1200 python tools/tune_e2e.py ${ar%% *} $OUT/tuned_e2e_$TAG.inc $OUT/tune_e2e_report_$TAG.json $( [ "$ar" != "${ar#* }" ] && echo ${ar#* } ) > $OUT/tune_e2e_$TAG.log 2>&1; note "tune_e2e rc=$?"
