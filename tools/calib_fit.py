@@ -46,8 +46,11 @@ print(f"{'session':58s} {'ms/step':>8s} {'x ref':>6s} | " + " ".join(f"{k:>16s}"
 for name, ms, v in rows:
     cells = []
     for i, k in enumerate(KEYS):
-        if v[i] is None or ref[2][i] is None:
+        if v[i] is None:
             cells.append(f"{'-':>16s}")
+            continue
+        if ref[2][i] is None:                                  # measured here, not on the reference session
+            cells.append(f"{v[i]:9.3f}       ")
             continue
         time_like = k.endswith("_us") or k.endswith("_ns")
         r = v[i] / ref[2][i] if time_like else ref[2][i] / v[i]
