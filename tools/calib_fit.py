@@ -81,5 +81,5 @@ else:
               "box slow.  Its per-op profile (profiles/r05_ffn_proj_ab_slow_box.log against r05_xattn_out_stage2_ab.log) does: launches of "
               "many workgroups (64x64-level convs, the 4096-token attention, weight-streaming convs) take their usual time, launches of "
               "64-160 workgroups (single-launch GroupNorm x1.84, conv_in / conv_out x1.9-2.0, 16x16-level attention x1.68, 1280->1280 GEMMs "
-              "at M = 512 x1.28) take 1.3-2.0 x as long - hence the eighth figure, small_grid_us (calib.hip), which no session has yet "
-              "measured on both kinds of box.  bench.py's CALIB_WEIGHTS stays empty and `value_normalised` null until one has.")
+              "at M = 512 x1.28) take 1.3-2.0 x as long.  The eighth figure, small_grid_us (calib.hip), was added for that reason and reads the "
+              "same on both kinds of box too.  bench.py's CALIB_WEIGHTS stays empty and `value_normalised` null.")
