@@ -283,7 +283,7 @@ def main():
 # profiles/r05_calibration_fit.txt from the sessions' records).  Empty weights = no figure has been shown to separate the boxes yet:
 # `value_normalised` is then null - a made-up normalisation would be worse than none.
 CALIB_REF = {"copy_gbs": 4750.0, "mfma_tflops": 2030.0, "empty_launch_us": 1.55, "chain_us": 3.62, "handover_us": 6.52,
-             "latency_hbm_ns": 360.0, "latency_cache_ns": 72.0}   # (small_grid_us: no reference yet - added after session E met a slow box)
+             "latency_hbm_ns": 360.0, "latency_cache_ns": 72.0, "small_grid_us": 3.04}
 CALIB_WEIGHTS = {}
 
 
