@@ -278,34 +278,37 @@ def main():
         dist.destroy_process_group()
 
 
-# Reference calibration: the box every `value_normalised` is expressed on (CALIB_REF: the 4.52-4.53-ms boxes of round 5's sessions
-# A / B) and how much of the step time follows each calibration figure (CALIB_WEIGHTS; tools/calib_fit.py writes
-# profiles/r05_calibration_fit.txt from the sessions' records).  Empty weights = no figure has been shown to separate the boxes yet:
-# `value_normalised` is then null - a made-up normalisation would be worse than none.
+# Reference calibration: the box every `value_normalised` is expressed on (CALIB_REF: the fast boxes of round 5's sessions) and how
+# much slower a step gets per unit of each figure (CALIB_SLOPES).  tools/calib_fit.py prints every session's figures next to its
+# step time (profiles/r05_calibration_fit.txt): eight figures - copy, dense MFMA, empty / cold-operand / cross-XCD / small-grid
+# launch chains, load latencies - are identical to 3 % on boxes 20-25 % apart; ONE is not: cold_code_us, the cost of launching a
+# kernel whose code is not in the instruction caches (tools/ubench/icache.hip: +0.8 us per launch on the fast boxes, +11 us on the
+# slow ones; the UNet step launches ~40 different kernels one after the other).  Slope from the two kinds of box measured with the
+# final library (profiles/r05_icache_probe_{fast,slow}_box.txt: 4.420 ms at 0.76 us, 5.433 ms at 11.33 us): step time x (1 + 0.0217
+# per us of cold-code cost above the reference).
 CALIB_REF = {"copy_gbs": 4750.0, "mfma_tflops": 2030.0, "empty_launch_us": 1.55, "chain_us": 3.62, "handover_us": 6.52,
-             "latency_hbm_ns": 360.0, "latency_cache_ns": 72.0, "small_grid_us": 3.04}
-CALIB_WEIGHTS = {}
+             "latency_hbm_ns": 360.0, "latency_cache_ns": 72.0, "small_grid_us": 3.04, "cold_code_us": 0.76}
+CALIB_SLOPES = {"cold_code_us": 0.0217}
 
 
 def normalised(value, calib):
-    """`value` as the reference box would have measured it: the step time is modelled as a weighted sum of terms that scale with
-    the box's calibration figures (time-like figures directly, rate-like figures inversely); `value` itself stays raw."""
+    """`value` as the reference (fast) box would have measured it: value x (1 + sum of slope x (figure - reference figure)); `value`
+    itself stays raw.  Null when a figure of the model is missing from the calibration."""
     scale = None
-    if CALIB_WEIGHTS:
-        scale = 0.0
-        for k, w in CALIB_WEIGHTS.items():
-            time_like = k.endswith("_us") or k.endswith("_ns")
-            scale += w * (calib[k] / CALIB_REF[k] if time_like else CALIB_REF[k] / calib[k])   # > 1: this box is slower on that term
-    ratios = {k: round((calib[k] / CALIB_REF[k]) if (k.endswith("_us") or k.endswith("_ns")) else (CALIB_REF[k] / calib[k]), 4)
-              for k in CALIB_REF if k in calib and calib[k]}
-    return {"calibration": dict(calib, reference=CALIB_REF, weights=CALIB_WEIGHTS, slowdown_vs_reference=ratios,
+    if CALIB_SLOPES and all(calib.get(k) is not None for k in CALIB_SLOPES):
+        scale = 1.0 + sum(w * (calib[k] - CALIB_REF[k]) for k, w in CALIB_SLOPES.items())
+    ratios = {k: round((calib[k] / CALIB_REF[k]) if k.endswith(("_us", "_ns")) else (CALIB_REF[k] / calib[k]), 4)
+              for k in CALIB_REF if calib.get(k)}
+    return {"calibration": dict(calib, reference=CALIB_REF, slopes=CALIB_SLOPES, slowdown_vs_reference=ratios,
                                 note="calib.hip, measured before the warm-up: 1-GiB copy GB/s, dense MFMA loop TFLOP/s, us per launch of a "
-                                     "323-launch empty graph / of a 323-launch chain of short kernels on cold operands / of a chain handing 8 MB "
-                                     "over between the XCDs' L2s, ns per dependent load from HBM / from the caches; slowdown_vs_reference > 1 = "
-                                     "this box is slower than the reference box on that figure"),
+                                     "323-launch empty graph / of a chain of short kernels on cold operands / of a chain handing 8 MB over "
+                                     "between the XCDs' L2s / of a chain of 64-workgroup launches, ns per dependent load from HBM / from the "
+                                     "caches, and cold_code_us = us per launch a chain of 32 DIFFERENT 30-KB kernels costs more than the same "
+                                     "chain repeating one of them; slowdown_vs_reference > 1 = this box is slower than the reference box there"),
             "value_normalised": None if scale is None else round(value * scale, 3),
-            "value_normalised_note": "value x (this box's modelled step time / the reference box's), weights from profiles/r05_calibration_fit.txt; "
-                                     "null while no calibration figure has been shown to track the boxes' step-time spread; `value` is the raw measurement"}
+            "value_normalised_note": "value x (1 + 0.0217 x (cold_code_us - 0.76)): the step time this build has on the FAST boxes of the pool, "
+                                     "whose instruction-fetch path costs 0.8 us per cold launch where the slow boxes' costs 11 us (LAB_NOTES.md "
+                                     "Finding 14, profiles/r05_calibration_fit.txt); `value` is the raw measurement"}
 
 
 def concurrent_prompts(model, HipModel, ucfg, checkpoint, args, lat_hw, device, loop_inputs, latents):

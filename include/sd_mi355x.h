@@ -342,7 +342,9 @@ int sd_philox_randn(uint64_t seed, uint32_t offset, double* out, size_t n);
  * on ANOTHER XCD wrote in the previous launch (8 MB handed over per launch), out8[5] / out8[6] = ns per dependent load from
  * never-touched HBM lines / from a 2-MB table resident in the caches, out8[7] = us per launch of a 323-launch chain of SMALL
  * grids (64 workgroups: 4 MB read, a reduction behind one barrier, 4 MB written - the shape of the launches that a slow box of the
- * pool runs 1.3-2 x slower).  Allocates and frees 2 GiB of device memory; synchronous. */
+ * pool runs 1.3-2 x slower - and which reads the same on them), out8[8] = COLD CODE: us per launch of a 320-launch chain that walks 32
+ * different kernels of ~30 KB of code each minus the same chain repeating one of them - 0.8 us on the fast boxes of the pool, 11 us
+ * on the slow ones: the figure `value_normalised` is built on.  Nine floats.  Allocates and frees 2 GiB of device memory; synchronous. */
 int sd_calibrate(int device, float* out8);
 /* MFMA fragment layout self-check used by the build/smoke tests (returns 0 when the hardware
  * layout matches what the kernels assume). */

@@ -11,6 +11,9 @@
 //                   ran on ANOTHER XCD - and writing 8 MB: the producer -> consumer hand-over of activations between the L2s
 //   latency_ns      one wave chasing 512 dependent 64-byte-strided pointers through a 1-GiB table (never-touched lines: HBM
 //                   latency) and latency_l2_ns the same through a 2-MB table after a warm-up pass (L2 / Infinity-Cache latency)
+#include <utility>
+#include <vector>
+
 #include "kernels.h"
 
 namespace sd {
@@ -95,6 +98,28 @@ __global__ __launch_bounds__(256) void calib_small_grid_kernel(const floatx4* __
   for (int k = 0; k < 16; ++k) next[base + (size_t)k * 256] = v[k] * 0.5f + floatx4{t, t, t, t};
 }
 
+// COLD CODE (Finding 14, tools/ubench/icache.hip): 32 instantiations of one kernel with ~30 KB of straight-line code each.  A chain
+// that repeats ONE of them keeps its code in the instruction caches; a chain that walks all 32 round-robin fetches 30 KB of cold
+// code per launch - the UNet step's situation (~40 different kernels one after the other).  The difference per launch is what a
+// box's instruction-fetch path costs: 0.8 us on the fast boxes of the pool, 11 us on the slow ones - the ONE figure of this file
+// that separates them.
+template <int ID>
+__global__ __launch_bounds__(256) void calib_code_kernel(float* buf) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  float a = buf[t], b = a + 1.f, c = a + 2.f, d = a + 3.f;
+#pragma unroll
+  for (int i = 0; i < 448; ++i) {   // 4 independent chains x 448 FMAs with 32-bit literals
+    a = __builtin_fmaf(a, 1.0f + 1e-6f * (float)(ID * 4096 + i * 4 + 0), 1e-7f * (float)(i + ID));
+    b = __builtin_fmaf(b, 1.0f + 1e-6f * (float)(ID * 4096 + i * 4 + 1), 2e-7f * (float)(i + ID));
+    c = __builtin_fmaf(c, 1.0f + 1e-6f * (float)(ID * 4096 + i * 4 + 2), 3e-7f * (float)(i + ID));
+    d = __builtin_fmaf(d, 1.0f + 1e-6f * (float)(ID * 4096 + i * 4 + 3), 4e-7f * (float)(i + ID));
+  }
+  buf[t] = (a + b) + (c + d);
+}
+typedef void (*calib_code_fn)(float*);
+template <int... I>
+std::vector<calib_code_fn> calib_code_table(std::integer_sequence<int, I...>) { return {calib_code_kernel<I>...}; }
+
 // the table holds, at element i * stride, the index of the next element; one lane walks it
 __global__ void calib_chase_init_kernel(unsigned* tab, unsigned n, unsigned stride) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -129,7 +154,7 @@ float time_graph(hipStream_t st, hipGraphExec_t g, int reps) {
 
 }  // namespace
 
-// out[0..7] = copy_gbs, mfma_tflops, empty_launch_us, chain_us, handover_us, latency_ns (HBM), latency_l2_ns, small_grid_us
+// out[0..8] = copy_gbs, mfma_tflops, empty_launch_us, chain_us, handover_us, latency_ns (HBM), latency_l2_ns, small_grid_us, cold_code_us
 void run_calibration(int device, float* out) {
   SD_HIP(hipSetDevice(device));
   hipStream_t st;
@@ -222,6 +247,20 @@ void run_calibration(int device, float* out) {
     });
     out[7] = time_graph(st, ge, 10) * 1e3f / (float)kLaunches;
     (void)hipGraphExecDestroy(ge);
+  }
+  {   // (h) cold code: 320-launch chains of 64-workgroup launches, 32 kernels round-robin minus one kernel repeated
+    const std::vector<calib_code_fn> ks = calib_code_table(std::make_integer_sequence<int, 32>{});
+    float* buf = reinterpret_cast<float*>(dst);
+    float us[2];
+    for (int mode = 0; mode < 2; ++mode) {
+      hipGraphExec_t ge = capture([&] {
+        for (int i = 0; i < 320; ++i) hipLaunchKernelGGL(ks[mode == 0 ? 0 : i % 32], dim3(64), dim3(256), 0, st, buf);
+      });
+      const float a = time_graph(st, ge, 3), b = time_graph(st, ge, 3);
+      us[mode] = (a < b ? a : b) * 1e3f / 320.f;
+      (void)hipGraphExecDestroy(ge);
+    }
+    out[8] = us[1] - us[0];
   }
   {   // (f) dependent-load latency: never-touched lines of the 1-GiB table, then a 2-MB table that was just walked
     unsigned* tab = reinterpret_cast<unsigned*>(src);

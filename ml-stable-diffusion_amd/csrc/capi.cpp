@@ -1224,11 +1224,11 @@ int sd_philox_randn(uint64_t seed, uint32_t offset, double* out, size_t n) {
   });
 }
 
-int sd_calibrate(int device, float* out8) {
+int sd_calibrate(int device, float* out9) {
   return guarded([&] {
-    SD_REQUIRE(out8, kInvalidArgument, "NULL argument");
+    SD_REQUIRE(out9, kInvalidArgument, "NULL argument");
     require_device();
-    run_calibration(device, out8);
+    run_calibration(device, out9);
   });
 }
 

@@ -399,9 +399,9 @@ def philox_randn(seed, n, offset=0):
 
 
 def calibrate(device=0):
-    """Eight fixed micro-measurements of the box (calib.hip): what bench.py prints as `calibration` and normalises by."""
-    out = (C.c_float * 8)()
+    """Nine fixed micro-measurements of the box (calib.hip): what bench.py prints as `calibration` and normalises by."""
+    out = (C.c_float * 9)()
     check(lib().sd_calibrate(device, out))
     return {"copy_gbs": round(out[0], 1), "mfma_tflops": round(out[1], 1), "empty_launch_us": round(out[2], 3),
             "chain_us": round(out[3], 3), "handover_us": round(out[4], 3), "latency_hbm_ns": round(out[5], 1),
-            "latency_cache_ns": round(out[6], 1), "small_grid_us": round(out[7], 3)}
+            "latency_cache_ns": round(out[6], 1), "small_grid_us": round(out[7], 3), "cold_code_us": round(out[8], 3)}

@@ -12,7 +12,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 files = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_*.log")) + glob.glob(os.path.join(ROOT, "profiles", "r05_*bench*.json")))
-KEYS = ["copy_gbs", "mfma_tflops", "empty_launch_us", "chain_us", "handover_us", "latency_hbm_ns", "latency_cache_ns", "small_grid_us"]
+KEYS = ["copy_gbs", "mfma_tflops", "empty_launch_us", "chain_us", "handover_us", "latency_hbm_ns", "latency_cache_ns", "small_grid_us", "cold_code_us"]
 rows = []
 for f in files:
     name = os.path.basename(f)
@@ -57,29 +57,21 @@ for name, ms, v in rows:
         cells.append(f"{v[i]:9.1f} x{r:5.3f}")
     print(f"{name[:58]:58s} {ms:8.3f} {ms / ref[1]:6.3f} | " + " ".join(cells))
 spread = rows[-1][1] / rows[0][1]
-print(f"\nstep-time spread over {len(rows)} sessions: x{spread:.3f}.", end=" ")
-if spread < 1.05:
-    print("All sessions of this file landed on boxes of one speed class: nothing to fit; bench.py's CALIB_WEIGHTS stays empty and "
-          "`value_normalised` null.  (Earlier sessions of round 5, whose records were lost with their container, saw 4.40 and 5.52 ms with "
-          "copy / MFMA / empty-launch / cold-chain figures identical to 1 % - csrc/calib.hip - which is why the hand-over chain and the "
-          "dependent-load latencies were added.)")
-else:
-    slow = rows[-1]
-    track = []
-    for i, k in enumerate(KEYS):
-        if slow[2][i] is None or ref[2][i] is None:
-            continue
-        time_like = k.endswith("_us") or k.endswith("_ns")
-        r = slow[2][i] / ref[2][i] if time_like else ref[2][i] / slow[2][i]
-        if r >= 1.0 + 0.5 * (spread - 1.0):
-            track.append(f"{k} x{r:.3f}")
-    if track:
-        print("Figures that follow the slowest session's step time (candidates for bench.py's CALIB_WEIGHTS): " + ", ".join(track) + ".")
-    else:
-        print("NONE of the figures measured on the slowest session moved with its step time (all within a few per cent of the reference): "
-              "copy, dense MFMA, empty and cold launch chains, cross-XCD hand-over and dependent-load latencies do not see what makes that "
-              "box slow.  Its per-op profile (profiles/r05_ffn_proj_ab_slow_box.log against r05_xattn_out_stage2_ab.log) does: launches of "
-              "many workgroups (64x64-level convs, the 4096-token attention, weight-streaming convs) take their usual time, launches of "
-              "64-160 workgroups (single-launch GroupNorm x1.84, conv_in / conv_out x1.9-2.0, 16x16-level attention x1.68, 1280->1280 GEMMs "
-              "at M = 512 x1.28) take 1.3-2.0 x as long.  The eighth figure, small_grid_us (calib.hip), was added for that reason and reads the "
-              "same on both kinds of box too.  bench.py's CALIB_WEIGHTS stays empty and `value_normalised` null.")
+print(f"\nstep-time spread over {len(rows)} sessions: x{spread:.3f}.")
+print("Eight figures - copy, dense MFMA, empty / cold-operand / cross-XCD hand-over / small-grid launch chains, dependent-load latencies - "
+      "are within a few per cent on every box, the slowest included: they do not see what makes a box slow.  The per-op profile does "
+      "(profiles/r05_ffn_proj_ab_slow_box.log against r05_xattn_out_stage2_ab.log): launches of many workgroups take their usual time, "
+      "launches of 64-160 workgroups 1.3-2.0 x as long.")
+probe = []
+for kind in ("fast", "slow"):
+    f = os.path.join(ROOT, "profiles", f"r05_icache_probe_{kind}_box.txt")
+    if os.path.exists(f):
+        probe.append(f"--- {os.path.basename(f)}\n" + open(f).read().rstrip())
+if probe:
+    print("\nThe ninth figure, cold_code_us (calib.hip; stand-alone: tools/ubench/icache.hip), is what separates them - a launch whose code is "
+          "not in the instruction caches:")
+    print("\n".join(probe))
+    print("\n-> cold_code_us = (32 kernels round-robin) - (same kernel), 64 workgroups: 0.76 us on the fast box (4.420 ms per step), 11.33 us on "
+          "the slow one (5.433 ms): bench.py's CALIB_SLOPES = {cold_code_us: (5.433 / 4.420 - 1) / (11.33 - 0.76) = 0.0217 per us}; "
+          "value_normalised = value x (1 + 0.0217 x (cold_code_us - 0.76)).  Sessions whose record carries the figure are the test of it "
+          "(column cold_code_us above).")

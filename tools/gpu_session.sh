@@ -29,7 +29,7 @@ for step in "$@"; do
     ab:*)
       kv=${step#ab:}; fl=""
       case "$kv" in *@*) fl=${kv#*@}; kv=${kv%%@*} ;; esac      # "ab:ENV=VAL@--prompts-per-gpu 8": extra bench flags behind @
-      r=$(env ${kv//,/ } timeout 300 python bench.py --cpu-steps 0 --repeats 5 $fl 2>/dev/null | tail -n 1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); g=(d.get('gpu_state') or {}).get('after_timed_region') or {}; c=d.get('calibration') or {}; print(d['ms_per_step'], d['value'], 'calib', c.get('copy_gbs'), c.get('mfma_tflops'), c.get('empty_launch_us'), c.get('chain_us'), c.get('handover_us'), c.get('latency_hbm_ns'), c.get('latency_cache_ns'), c.get('small_grid_us'), 'sclk', g.get('sclk clock speed:'), 'W', g.get('Current Socket Graphics Package Power (W)'))" 2>&1)
+      r=$(env ${kv//,/ } timeout 300 python bench.py --cpu-steps 0 --repeats 5 $fl 2>/dev/null | tail -n 1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); g=(d.get('gpu_state') or {}).get('after_timed_region') or {}; c=d.get('calibration') or {}; print(d['ms_per_step'], d['value'], 'calib', c.get('copy_gbs'), c.get('mfma_tflops'), c.get('empty_launch_us'), c.get('chain_us'), c.get('handover_us'), c.get('latency_hbm_ns'), c.get('latency_cache_ns'), c.get('small_grid_us'), c.get('cold_code_us'), 'sclk', g.get('sclk clock speed:'), 'W', g.get('Current Socket Graphics Package Power (W)'))" 2>&1)
       note "ab[$kv $fl] ms/step, it/s: $r" ;;
     profile)
       timeout 300 python tools/op_profile.py $OUT/op_profile_$TAG.json 2 ORIGINAL > $OUT/op_profile_$TAG.txt 2>&1; note "profile rc=$?"; head -n 28 $OUT/op_profile_$TAG.txt | cut -c1-150 ;;
@@ -40,13 +40,14 @@ for step in "$@"; do
       [ -n "$DB" ] && python tools/timeline.py $DB > $OUT/step_timeline_$TAG.txt 2>&1 && head -n 30 $OUT/step_timeline_$TAG.txt | cut -c1-160
       [ -n "$DB" ] && python tools/rocpd_stats.py $DB $OUT/kernel_stats_$TAG.csv > /dev/null 2>&1
       rm -rf $OUT/prof_$TAG ;;
-    pmc)   # HBM traffic + MFMA-busy + stall counters of the eager step: separate --pmc passes (never with trace domains other than kernel-trace)
+    pmc|pmc2)   # HBM traffic + MFMA-busy + stall counters of the eager step: separate --pmc passes (never with trace domains other than kernel-trace); pmc2 = the two traffic passes only
       for SET in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES"; do
+        [ "$step" = pmc2 ] && [ "${SET%% *}" = SQ_VALU_MFMA_BUSY_CYCLES ] && continue
         T=$(echo $SET | cut -d' ' -f1)
         rm -rf $OUT/pmc_$T
         (cd /tmp && timeout 300 rocprofv3 --pmc $SET --kernel-trace -d $OUT/pmc_$T -o r -- python /root/repo/tools/pmc_probe.py sd21 4 > $OUT/pmc_${T}_$TAG.log 2>&1); note "pmc $T rc=$?"
       done
-      python tools/pmc_reduce.py $OUT/hbm_traffic_$TAG.json $(find $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES -name "*.db") 2>&1 | tail -n 20
+      python tools/pmc_reduce.py $OUT/hbm_traffic_$TAG.json $(find $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES -name "*.db" 2>/dev/null) 2>&1 | tail -n 20
       rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES ;;
     bench:*)   # bench with extra flags, e.g. "bench:--model sdxl-base --latent 96"
       fl=${step#bench:}
