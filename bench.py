@@ -283,12 +283,15 @@ def main():
 # step time (profiles/r05_calibration_fit.txt): eight figures - copy, dense MFMA, empty / cold-operand / cross-XCD / small-grid
 # launch chains, load latencies - are identical to 3 % on boxes 20-25 % apart; ONE is not: cold_code_us, the cost of launching a
 # kernel whose code is not in the instruction caches (tools/ubench/icache.hip: +0.8 us per launch on the fast boxes, +11 us on the
-# slow ones; the UNet step launches ~40 different kernels one after the other).  Slope from the two kinds of box measured with the
-# final library (profiles/r05_icache_probe_{fast,slow}_box.txt: 4.420 ms at 0.76 us, 5.433 ms at 11.33 us): step time x (1 + 0.0217
-# per us of cold-code cost above the reference).
+# slow ones; the UNet step launches ~40 different kernels one after the other).  Slope from the two kinds of box measured with THIS
+# library (profiles/r05_final_bench_fast_box{,_2}.json: 4.226 / 4.246 ms at 0.77 / 0.75 us; r05_final_bench_slow_box_calib_build.json:
+# 5.386 ms at 11.29 us): step time x (1 + 0.0258 per us of cold-code cost above the reference).  The slope belongs to a build (it is
+# its number of cold launches x their code size): the previous build's pair (4.420 / 5.433 ms, r05_icache_probe_*) gives 0.0217, and
+# with that slope - the one in force when the slow-box line above was taken - its value_normalised read 228.1 against 235.5 / 236.7
+# on the fast boxes (3.4 % apart); with this one 236.1.
 CALIB_REF = {"copy_gbs": 4750.0, "mfma_tflops": 2030.0, "empty_launch_us": 1.55, "chain_us": 3.62, "handover_us": 6.52,
              "latency_hbm_ns": 360.0, "latency_cache_ns": 72.0, "small_grid_us": 3.04, "cold_code_us": 0.76}
-CALIB_SLOPES = {"cold_code_us": 0.0217}
+CALIB_SLOPES = {"cold_code_us": 0.0258}
 
 
 def normalised(value, calib):
@@ -306,7 +309,7 @@ def normalised(value, calib):
                                      "caches, and cold_code_us = us per launch a chain of 32 DIFFERENT 30-KB kernels costs more than the same "
                                      "chain repeating one of them; slowdown_vs_reference > 1 = this box is slower than the reference box there"),
             "value_normalised": None if scale is None else round(value * scale, 3),
-            "value_normalised_note": "value x (1 + 0.0217 x (cold_code_us - 0.76)): the step time this build has on the FAST boxes of the pool, "
+            "value_normalised_note": "value x (1 + 0.0258 x (cold_code_us - 0.76)): the step time this build has on the FAST boxes of the pool, "
                                      "whose instruction-fetch path costs 0.8 us per cold launch where the slow boxes' costs 11 us (LAB_NOTES.md "
                                      "Finding 14, profiles/r05_calibration_fit.txt); `value` is the raw measurement"}
 

@@ -72,6 +72,6 @@ if probe:
           "not in the instruction caches:")
     print("\n".join(probe))
     print("\n-> cold_code_us = (32 kernels round-robin) - (same kernel), 64 workgroups: 0.76 us on the fast box (4.420 ms per step), 11.33 us on "
-          "the slow one (5.433 ms): bench.py's CALIB_SLOPES = {cold_code_us: (5.433 / 4.420 - 1) / (11.33 - 0.76) = 0.0217 per us}; "
-          "value_normalised = value x (1 + 0.0217 x (cold_code_us - 0.76)).  Sessions whose record carries the figure are the test of it "
-          "(column cold_code_us above).")
+          "the slow one (5.433 ms): (5.433 / 4.420 - 1) / (11.33 - 0.76) = 0.0217 per us for that build; the committed library (column "
+          "cold_code_us above: 4.226 / 4.246 ms at 0.77 / 0.75 us, 5.386 ms at 11.29 us) gives 0.0258, bench.py's CALIB_SLOPES; "
+          "value_normalised = value x (1 + 0.0258 x (cold_code_us - 0.76)).")
