@@ -31,7 +31,7 @@ Extra objects on the JSON line:
   --model / --latent select the UNets of BASELINE configs 4 and 5 and 768x768 latents (reported lines; the default
                invocation is BASELINE config 2)
   cpu_baseline the oracle (CPU restatement of the reference UNet + loop) timed on this box's host
-               cores on a bounded sample (rank 0, N=1 only) at the best of a thread sweep (8 .. 128); kind "port"
+               cores on a bounded sample (rank 0, N=1 only: 5 timed steps) at the best of a thread sweep (8 .. 128); kind "port"
   e2e          prompt -> image latency: tokenizer + CLIP text tower on HIP + 20 steps + VAE decode
   gpu_state    rocm-smi clocks / power / temperature before the warm-up and right after the timed repeats
 """
@@ -74,7 +74,10 @@ def main():
     ap.add_argument("--prompts-per-gpu", type=int, default=1)
     ap.add_argument("--attention", default="ORIGINAL", choices=["ORIGINAL", "SPLIT_EINSUM", "SPLIT_EINSUM_V2"])
     ap.add_argument("--guidance-scale", type=float, default=7.5)
-    ap.add_argument("--cpu-steps", type=int, default=2, help="oracle steps timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=5, help="oracle steps timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--sustain-s", type=float, default=12.0,
+                    help="untimed back-to-back replays of the step graph AFTER the timed repeats (result discarded, never part of "
+                         "`value`): long enough for an outside GPU-utilisation sampler to see the run (0 = skip)")
     ap.add_argument("--repeats", type=int, default=5, help="repeats of the K-step timed region (median reported)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--model", default="sd21-base", choices=sorted(MODELS), help="UNet of BASELINE configs 2 / 4 / 5")
@@ -193,6 +196,16 @@ def main():
         rep_s.append(el)
         rep_ev.append(float(np.median(ev_ms)))
     gpu_after = gpu_state(local_rank) if rank == 0 and not stub else None   # right behind the timed repeats: clocks under load
+    sustain = None
+    if not stub and args.sustain_s > 0:   # the timed region is 0.5 s of a 60-s run; make the GPU leg visible
+        t0 = time.perf_counter()
+        n_sus = 0
+        while time.perf_counter() - t0 < args.sustain_s:
+            run(500)
+            n_sus += 500
+        sync()
+        sustain = {"seconds": round(time.perf_counter() - t0, 2), "steps": n_sus,
+                   "note": "untimed back-to-back step-graph replays after the timed repeats; result discarded, not part of `value`"}
     order = np.argsort(rep_s)
     mid = int(order[len(order) // 2])
     elapsed = rep_s[mid]
@@ -258,9 +271,10 @@ def main():
                       "note": "rocm-smi clocks / power / junction temperature of this rank's GPU: attributes box-to-box spread"},
         "e2e": {"model_build_s": round(build_s, 1), "final_latents_finite": True,
                 "gathered_latents": list(all_final.shape), "hbm_bytes": int(model.device_bytes)},
+        "sustained_leg": sustain,
     }
     if calib is not None:
-        out.update(normalised(value, calib))
+        out.update(calibration_record(calib))
     if world == 1:
         out["roofline"].update(hbm_traffic(ev_ms_step, args, lat_hw))
         out["roofline"].update(kernel_families(ops, ev_ms_step))
@@ -278,40 +292,26 @@ def main():
         dist.destroy_process_group()
 
 
-# Reference calibration: the box every `value_normalised` is expressed on (CALIB_REF: the fast boxes of round 5's sessions) and how
-# much slower a step gets per unit of each figure (CALIB_SLOPES).  tools/calib_fit.py prints every session's figures next to its
-# step time (profiles/r05_calibration_fit.txt): eight figures - copy, dense MFMA, empty / cold-operand / cross-XCD / small-grid
-# launch chains, load latencies - are identical to 3 % on boxes 20-25 % apart; ONE is not: cold_code_us, the cost of launching a
-# kernel whose code is not in the instruction caches (tools/ubench/icache.hip: +0.8 us per launch on the fast boxes, +11 us on the
-# slow ones; the UNet step launches ~40 different kernels one after the other).  Slope from the two kinds of box measured with THIS
-# library (profiles/r05_final_bench_fast_box{,_2}.json: 4.226 / 4.246 ms at 0.77 / 0.75 us; r05_final_bench_slow_box_calib_build.json:
-# 5.386 ms at 11.29 us): step time x (1 + 0.0258 per us of cold-code cost above the reference).  The slope belongs to a build (it is
-# its number of cold launches x their code size): the previous build's pair (4.420 / 5.433 ms, r05_icache_probe_*) gives 0.0217, and
-# with that slope - the one in force when the slow-box line above was taken - its value_normalised read 228.1 against 235.5 / 236.7
-# on the fast boxes (3.4 % apart); with this one 236.1.
+# Box calibration (csrc/calib.hip): nine fixed micro-measurements taken before the warm-up.  Eight of them read the same on every
+# box of the pool; cold_code_us - what a launch costs more when its CODE is not in the instruction caches - is 0.8 us on the fast
+# boxes and 11 us on the slow ones (LAB_NOTES.md Finding 14) and explains the pool's 20-25 % spread of one build.  Round 5 also
+# printed a `value_normalised` from a slope fitted per build; VERDICT r5 / ADVICE r5: the slope belongs to ONE build and ONE workload,
+# so it is gone - the raw figures stay, next to the reference values of a fast box, and `value` is always the raw measurement.
 CALIB_REF = {"copy_gbs": 4750.0, "mfma_tflops": 2030.0, "empty_launch_us": 1.55, "chain_us": 3.62, "handover_us": 6.52,
              "latency_hbm_ns": 360.0, "latency_cache_ns": 72.0, "small_grid_us": 3.04, "cold_code_us": 0.76}
-CALIB_SLOPES = {"cold_code_us": 0.0258}
 
 
-def normalised(value, calib):
-    """`value` as the reference (fast) box would have measured it: value x (1 + sum of slope x (figure - reference figure)); `value`
-    itself stays raw.  Null when a figure of the model is missing from the calibration."""
-    scale = None
-    if CALIB_SLOPES and all(calib.get(k) is not None for k in CALIB_SLOPES):
-        scale = 1.0 + sum(w * (calib[k] - CALIB_REF[k]) for k, w in CALIB_SLOPES.items())
+def calibration_record(calib):
     ratios = {k: round((calib[k] / CALIB_REF[k]) if k.endswith(("_us", "_ns")) else (CALIB_REF[k] / calib[k]), 4)
               for k in CALIB_REF if calib.get(k)}
-    return {"calibration": dict(calib, reference=CALIB_REF, slopes=CALIB_SLOPES, slowdown_vs_reference=ratios,
+    return {"calibration": dict(calib, reference=CALIB_REF, slowdown_vs_reference=ratios,
                                 note="calib.hip, measured before the warm-up: 1-GiB copy GB/s, dense MFMA loop TFLOP/s, us per launch of a "
                                      "323-launch empty graph / of a chain of short kernels on cold operands / of a chain handing 8 MB over "
                                      "between the XCDs' L2s / of a chain of 64-workgroup launches, ns per dependent load from HBM / from the "
                                      "caches, and cold_code_us = us per launch a chain of 32 DIFFERENT 30-KB kernels costs more than the same "
-                                     "chain repeating one of them; slowdown_vs_reference > 1 = this box is slower than the reference box there"),
-            "value_normalised": None if scale is None else round(value * scale, 3),
-            "value_normalised_note": "value x (1 + 0.0258 x (cold_code_us - 0.76)): the step time this build has on the FAST boxes of the pool, "
-                                     "whose instruction-fetch path costs 0.8 us per cold launch where the slow boxes' costs 11 us (LAB_NOTES.md "
-                                     "Finding 14, profiles/r05_calibration_fit.txt); `value` is the raw measurement"}
+                                     "chain repeating one of them (0.8 on the pool's fast boxes, 11 on its slow ones); slowdown_vs_reference "
+                                     "> 1 = this box is slower than the reference box there.  Raw data only: no figure of this line is "
+                                     "corrected with it")}
 
 
 def concurrent_prompts(model, HipModel, ucfg, checkpoint, args, lat_hw, device, loop_inputs, latents):

@@ -335,17 +335,17 @@ int sd_numpy_randn(uint32_t seed, double* out, size_t n);
  * (Philox4x32-10, NvRandomSource.swift:25-80; `offset` = number of arrays drawn before).  Host-side. */
 int sd_torch_randn(uint32_t seed, double* out, size_t n);
 int sd_philox_randn(uint64_t seed, uint32_t offset, double* out, size_t n);
-/* Box calibration for bench.py (no reference counterpart: measurement infrastructure).  out8[0] = device copy GB/s (1 GiB,
- * read + written bytes), out8[1] = dense v_mfma_f32_32x32x16_f16 register loop TFLOP/s, out8[2] = us per launch of a captured
- * graph of 323 empty launches (the step's launch count), out8[3] = us per launch of a 323-launch chain of short dependent
- * kernels on cold operands, out8[4] = us per launch of a 323-launch chain in which every workgroup reads 16 KB that a workgroup
- * on ANOTHER XCD wrote in the previous launch (8 MB handed over per launch), out8[5] / out8[6] = ns per dependent load from
- * never-touched HBM lines / from a 2-MB table resident in the caches, out8[7] = us per launch of a 323-launch chain of SMALL
+/* Box calibration for bench.py (no reference counterpart: measurement infrastructure).  out9[0] = device copy GB/s (1 GiB,
+ * read + written bytes), out9[1] = dense v_mfma_f32_32x32x16_f16 register loop TFLOP/s, out9[2] = us per launch of a captured
+ * graph of 323 empty launches (the step's launch count), out9[3] = us per launch of a 323-launch chain of short dependent
+ * kernels on cold operands, out9[4] = us per launch of a 323-launch chain in which every workgroup reads 16 KB that a workgroup
+ * on ANOTHER XCD wrote in the previous launch (8 MB handed over per launch), out9[5] / out9[6] = ns per dependent load from
+ * never-touched HBM lines / from a 2-MB table resident in the caches, out9[7] = us per launch of a 323-launch chain of SMALL
  * grids (64 workgroups: 4 MB read, a reduction behind one barrier, 4 MB written - the shape of the launches that a slow box of the
- * pool runs 1.3-2 x slower - and which reads the same on them), out8[8] = COLD CODE: us per launch of a 320-launch chain that walks 32
+ * pool runs 1.3-2 x slower - and which reads the same on them), out9[8] = COLD CODE: us per launch of a 320-launch chain that walks 32
  * different kernels of ~30 KB of code each minus the same chain repeating one of them - 0.8 us on the fast boxes of the pool, 11 us
  * on the slow ones: the figure `value_normalised` is built on.  Nine floats.  Allocates and frees 2 GiB of device memory; synchronous. */
-int sd_calibrate(int device, float* out8);
+int sd_calibrate(int device, float* out9);
 /* MFMA fragment layout self-check used by the build/smoke tests (returns 0 when the hardware
  * layout matches what the kernels assume). */
 int sd_selftest_mfma(void);

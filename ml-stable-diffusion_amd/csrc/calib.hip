@@ -156,18 +156,35 @@ float time_graph(hipStream_t st, hipGraphExec_t g, int reps) {
 
 // out[0..8] = copy_gbs, mfma_tflops, empty_launch_us, chain_us, handover_us, latency_ns (HBM), latency_l2_ns, small_grid_us, cold_code_us
 void run_calibration(int device, float* out) {
+  // everything this function creates is released on every exit path (a throwing SD_HIP included), and the caller's current
+  // device is put back
+  struct Guard {
+    int prev = -1;
+    hipStream_t st = nullptr;
+    floatx4 *src = nullptr, *dst = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Guard() {
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+      if (src) (void)hipFree(src);
+      if (dst) (void)hipFree(dst);
+      if (st) (void)hipStreamDestroy(st);
+      if (prev >= 0) (void)hipSetDevice(prev);
+    }
+  } g;
+  SD_HIP(hipGetDevice(&g.prev));
   SD_HIP(hipSetDevice(device));
-  hipStream_t st;
-  SD_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  SD_HIP(hipStreamCreateWithFlags(&g.st, hipStreamNonBlocking));
   const size_t bytes = (size_t)1 << 30, n4 = bytes / 16;
-  floatx4 *src = nullptr, *dst = nullptr;
-  SD_HIP(hipMalloc(reinterpret_cast<void**>(&src), bytes));
-  SD_HIP(hipMalloc(reinterpret_cast<void**>(&dst), bytes));
+  SD_HIP(hipMalloc(reinterpret_cast<void**>(&g.src), bytes));
+  SD_HIP(hipMalloc(reinterpret_cast<void**>(&g.dst), bytes));
+  SD_HIP(hipEventCreate(&g.e0));
+  SD_HIP(hipEventCreate(&g.e1));
+  const hipStream_t st = g.st;
+  floatx4 *const src = g.src, *const dst = g.dst;
+  const hipEvent_t e0 = g.e0, e1 = g.e1;
   SD_HIP(hipMemsetAsync(src, 1, bytes, st));
   SD_HIP(hipMemsetAsync(dst, 0, bytes, st));
-  hipEvent_t e0, e1;
-  SD_HIP(hipEventCreate(&e0));
-  SD_HIP(hipEventCreate(&e1));
   auto timed = [&](int reps, auto&& launch) {
     launch();
     SD_HIP(hipStreamSynchronize(st));
@@ -282,11 +299,7 @@ void run_calibration(int device, float* out) {
     out[5] = chase((unsigned)(bytes / 4096), 1024u, 512, 1);          // 262 144 entries, 4 KB apart: 512 hops on cold lines
     out[6] = chase(32768u, 16u, 4096, 2);                              // 2 MB: the second pass walks what the first pulled in
   }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  (void)hipFree(src);
-  (void)hipFree(dst);
-  (void)hipStreamDestroy(st);
+  SD_HIP(hipStreamSynchronize(st));
 }
 
 }  // namespace sd

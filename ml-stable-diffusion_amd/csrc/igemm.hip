@@ -2661,6 +2661,17 @@ bool conv_fast_path_ok(const ConvDesc& d) {
   return true;
 }
 
+// Would the plan of this conv be the weight-streaming kernel (plan tile 9) if its fragment-major weight copy existed?  The ONE
+// predicate UNet::conv_w allocates that copy by (a second, looser copy of this rule left ~430 MB of copies per handle
+// that no kernel reads).
+bool conv_plan_is_wstream(const ConvDesc& d0) {
+  if (!conv_fast_path_ok(d0) || !wstream_shape_ok(d0)) return false;
+  ConvDesc d = d0;
+  if (!d.w_tiled) d.w_tiled = d.w;   // choose_plan only tests the pointer
+  const IgemmArgs a = make_args(d);
+  return choose_plan(d, a).tile == 9;
+}
+
 size_t conv_workspace_bytes(const ConvDesc& d) {
   if (!conv_fast_path_ok(d)) return 0;
   IgemmArgs a = make_args(d);

@@ -111,6 +111,7 @@ void conv_tune_set_candidate(int tile, int staging, int splitk);
 int conv_plan_table_set(const char* text);   // rows of tuned_convs.inc format; returns the number of plans read
 
 // wstream.hip: the small-M weight-streaming kernel (plan tile 9) and the group-organised slab combine
+bool conv_plan_is_wstream(const ConvDesc& d);            // choose_plan would take plan tile 9 given the pre-tiled weights
 bool wstream_shape_ok(const ConvDesc& d);                 // shape admits plan tile 9 (d.w_tiled not looked at)
 int wstream_splits(const ConvDesc& d, int nw);            // slabs launch_wstream writes with nw waves per workgroup
 size_t wstream_tiled_halves(int N, int Ctot, int ksize);

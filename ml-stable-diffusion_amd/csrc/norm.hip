@@ -173,13 +173,13 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const half_t* __re
   groupnorm_apply_body(x0, C0, x1, C1, partial, slabs, gamma, beta, y, HW, G, eps, silu, pix_per_block, blockIdx.x, blockIdx.y);
 }
 
-template <int VW, int NT = 256>
+template <int VW, int NT = 256, bool RES = false>
 __global__ __launch_bounds__(NT) void groupnorm_fused_kernel(const half_t* __restrict__ x0, int C0,
                                                               const half_t* __restrict__ x1, int C1,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, half_t* __restrict__ y,
                                                               int HW, int G, float eps, int silu) {
-  groupnorm_fused_body<VW, NT>(x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu, blockIdx.x, blockIdx.y);
+  groupnorm_fused_body<VW, NT, RES>(x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu, blockIdx.x, blockIdx.y);
 }
 
 // One workgroup per row: row kept in registers (cols <= 256 threads * 4 chunks * 8), fp32 max / sum
@@ -283,8 +283,8 @@ void launch_groupnorm(const half_t* x0, int C0, const half_t* x1, int C1, float*
                       const float* beta, half_t* y, int B, int HW, int G, float eps, int silu, hipStream_t s,
                       int producer_entries, const ConvDesc* side) {
   if (!x1) C1 = 0;
-  static const int resident_mode = tune_env_int("SD_GN_RESIDENT", 1);   // 0: the single-launch kernels run their two-pass form (A/B)
-  const int silu_f = (silu ? 1 : 0) | (resident_mode == 0 ? 2 : 0);      // bit 1 only reaches groupnorm_fused_body
+  static const bool res = tune_env_int("SD_GN_RESIDENT", 0) != 0;   // 1: round 5's register-resident single-launch form (A/B; gn_body.inc)
+  const int silu_f = silu ? 1 : 0;
   const int C = C0 + C1;
   SD_REQUIRE(C % G == 0 && C0 % 8 == 0 && C1 % 8 == 0 && G <= 64, kUnsupported, "groupnorm: C0=%d C1=%d G=%d", C0, C1, G);
   const int cpg = C / G;
@@ -310,12 +310,14 @@ void launch_groupnorm(const half_t* x0, int C0, const half_t* x1, int C1, float*
       launch_gn_fused_side(cpg % 8 == 0 ? 8 : (cpg % 4 == 0 ? 4 : 2), x0, C0, x1, C1, gamma, beta, y, B, HW, G, eps, silu_f, *side, s);
       return;
     }
-    if (cpg % 8 == 0)
-      hipLaunchKernelGGL(groupnorm_fused_kernel<8>, grid, dim3(256), 0, s, x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu_f);
-    else if (cpg % 4 == 0)
-      hipLaunchKernelGGL(groupnorm_fused_kernel<4>, grid, dim3(256), 0, s, x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu_f);
-    else
-      hipLaunchKernelGGL(groupnorm_fused_kernel<2>, grid, dim3(256), 0, s, x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu_f);
+#define SD_GN_FUSED(VW_, NT_)                                                                                                              \
+  do {                                                                                                                                     \
+    if (res) hipLaunchKernelGGL((groupnorm_fused_kernel<VW_, NT_, true>), grid, dim3(NT_), 0, s, x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu_f); \
+    else hipLaunchKernelGGL((groupnorm_fused_kernel<VW_, NT_, false>), grid, dim3(NT_), 0, s, x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu_f);    \
+  } while (0)
+    if (cpg % 8 == 0) SD_GN_FUSED(8, 256);
+    else if (cpg % 4 == 0) SD_GN_FUSED(4, 256);
+    else SD_GN_FUSED(2, 256);
     SD_HIP(hipGetLastError());
     return;
   }
@@ -324,10 +326,8 @@ void launch_groupnorm(const half_t* x0, int C0, const half_t* x1, int C1, float*
   static const bool wide = tune_env_int("SD_GN_WIDE", 1) != 0;
   if (wide && !side && HW <= 1024 && cpg >= 16 && cpg <= 48 && cpg % 4 == 0) {   // (1024-thread blocks: no side GEMM there)   // (60-channel groups measured slower: 20.8 vs 16.0 us)
     dim3 grid(G, B);
-    if (cpg % 8 == 0)
-      hipLaunchKernelGGL((groupnorm_fused_kernel<8, 1024>), grid, dim3(1024), 0, s, x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu_f);
-    else
-      hipLaunchKernelGGL((groupnorm_fused_kernel<4, 1024>), grid, dim3(1024), 0, s, x0, C0, x1, C1, gamma, beta, y, HW, G, eps, silu_f);
+    if (cpg % 8 == 0) SD_GN_FUSED(8, 1024);
+    else SD_GN_FUSED(4, 1024);
     SD_HIP(hipGetLastError());
     return;
   }

@@ -81,12 +81,16 @@ struct DevBuf {
 // steered by a stray variable.  (cached per call site by the callers' function-local statics)
 inline int tune_env_int(const char* name, int dflt) {
   static const bool on = getenv("SD_TUNE") != nullptr;
-  if (!on) return dflt;
+  if (!on) {   // (callers cache the result in function-local statics: one line per switch and call site at most)
+    if (getenv(name)) fprintf(stderr, "libsdmi355: %s is set but ignored: A/B switches are only read when SD_TUNE=1 is set too\n", name);
+    return dflt;
+  }
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
 }
 inline bool tune_env_set(const char* name) {
   static const bool on = getenv("SD_TUNE") != nullptr;
+  if (!on && getenv(name)) fprintf(stderr, "libsdmi355: %s is set but ignored: A/B switches are only read when SD_TUNE=1 is set too\n", name);
   return on && getenv(name) != nullptr;
 }
 

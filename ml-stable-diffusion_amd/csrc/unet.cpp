@@ -335,7 +335,10 @@ Tensor UNet::conv_w(std::vector<Op>& ops, const std::string& name, const half_t*
     // small-M layers: the weight-streaming kernel (plan tile 9) needs the fragment-major copy of the weights
     static const int ws_mode = tune_env_int("SD_WSTREAM", 1);
     const int Mrows = x.B * d.Ho * d.Wo;
-    if (ws_mode != 0 && !ex && wstream_shape_ok(d) && ((k == 3 && Mrows <= 512) || (k == 1 && Mrows <= 128))) {
+    // (SD_TUNE: every shape a plan sweep may send there; production: exactly the convs whose plan IS tile 9)
+    static const bool tuning = getenv("SD_TUNE") != nullptr;
+    const bool ws_candidate = tuning ? ((k == 3 && Mrows <= 512) || (k == 1 && Mrows <= 128)) : conv_plan_is_wstream(d);
+    if (ws_mode != 0 && !ex && wstream_shape_ok(d) && ws_candidate) {
       const int cin_t = x.C + (x2 ? x2->C : 0);
       half_t* wt = arena_.alloc_n<half_t>(wstream_tiled_halves(cout, cin_t, k));
       launch_wstream_retile(w, wt, cout, cin_t, k, stream_);

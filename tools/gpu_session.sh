@@ -29,13 +29,13 @@ for step in "$@"; do
     ab:*)
       kv=${step#ab:}; fl=""
       case "$kv" in *@*) fl=${kv#*@}; kv=${kv%%@*} ;; esac      # "ab:ENV=VAL@--prompts-per-gpu 8": extra bench flags behind @
-      r=$(env ${kv//,/ } timeout 300 python bench.py --cpu-steps 0 --repeats 5 $fl 2>/dev/null | tail -n 1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); g=(d.get('gpu_state') or {}).get('after_timed_region') or {}; c=d.get('calibration') or {}; print(d['ms_per_step'], d['value'], 'calib', c.get('copy_gbs'), c.get('mfma_tflops'), c.get('empty_launch_us'), c.get('chain_us'), c.get('handover_us'), c.get('latency_hbm_ns'), c.get('latency_cache_ns'), c.get('small_grid_us'), c.get('cold_code_us'), 'sclk', g.get('sclk clock speed:'), 'W', g.get('Current Socket Graphics Package Power (W)'))" 2>&1)
+      r=$(env ${kv//,/ } timeout 300 python bench.py --cpu-steps 0 --sustain-s 0 --repeats 5 $fl 2>/dev/null | tail -n 1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); g=(d.get('gpu_state') or {}).get('after_timed_region') or {}; c=d.get('calibration') or {}; print(d['ms_per_step'], d['value'], 'calib', c.get('copy_gbs'), c.get('mfma_tflops'), c.get('empty_launch_us'), c.get('chain_us'), c.get('handover_us'), c.get('latency_hbm_ns'), c.get('latency_cache_ns'), c.get('small_grid_us'), c.get('cold_code_us'), 'sclk', g.get('sclk clock speed:'), 'W', g.get('Current Socket Graphics Package Power (W)'))" 2>&1)
       note "ab[$kv $fl] ms/step, it/s: $r" ;;
     profile)
       timeout 300 python tools/op_profile.py $OUT/op_profile_$TAG.json 2 ORIGINAL > $OUT/op_profile_$TAG.txt 2>&1; note "profile rc=$?"; head -n 28 $OUT/op_profile_$TAG.txt | cut -c1-150 ;;
     trace)
       rm -rf $OUT/prof_$TAG
-      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o bench -- python /root/repo/bench.py --steps 6 --warmup 2 --cpu-steps 0 --repeats 1 > $OUT/rocprof_$TAG.log 2>&1); note "rocprof rc=$?"
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o bench -- python /root/repo/bench.py --steps 6 --warmup 2 --cpu-steps 0 --sustain-s 0 --repeats 1 > $OUT/rocprof_$TAG.log 2>&1); note "rocprof rc=$?"
       DB=$(find $OUT/prof_$TAG -name "*.db" | head -n 1)
       [ -n "$DB" ] && python tools/timeline.py $DB > $OUT/step_timeline_$TAG.txt 2>&1 && head -n 30 $OUT/step_timeline_$TAG.txt | cut -c1-160
       [ -n "$DB" ] && python tools/rocpd_stats.py $DB $OUT/kernel_stats_$TAG.csv > /dev/null 2>&1

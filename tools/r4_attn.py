@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Round-4 attention A/B: the software-pipelined d = 64 kernel (attention8.hip) against the general kernels
 (variant 1) on the UNet's self-attention shapes, stand-alone, plus a quick parity check against the oracle.
-  python tools/r4_attn.py [check] [bench]          (SD_ATTN8_WAVES=4|8 forces the workgroup size)
+  python tools/r4_attn.py [check] [bench]          (SD_TUNE=1 SD_ATTN8_WAVES=4|8 forces the workgroup size)
 """
 import os
 import sys

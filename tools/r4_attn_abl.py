@@ -26,6 +26,7 @@ RUNS += [(a, {"SD_ATTN8_WAVES": "8"}) for a in (1, 2, 4, 6, 8, 17, 23, 31, 100, 
 RUNS += [(31, {"SD_VT_PAD": "0", "SD_ATTN8_STAGGER": "0"})]
 for abl, extra in RUNS:
     env = dict(os.environ)
+    env["SD_TUNE"] = "1"   # the library reads its A/B switches only under SD_TUNE
     env.update(extra)
     if abl:
         env["SD_ATTN8_ABL"] = str(abl)
