@@ -325,6 +325,12 @@ int sd_op_cross_attention_block(const void* x, const float* ln_weight, const flo
                                 int Sq, int Sk, float eps, int fused, int iters, float* ms);
 /* GEGLU feed-forward first half (unet.py:609-617): x (M, C) f16, w (8C', C) f16, bias (8C'/.. ) */
 int sd_op_geglu(const void* x, const void* w, const float* bias, void* out, int M, int C, int N2, int iters, float* ms);
+/* The same projection with the LayerNorm in front of it folded into the GEMM, as the UNet runs it (unet.py:583-591 norm3 ->
+ * :609-617; host-side fold of UNet::fold_layernorm): x (M, C) f16 UN-normalised, ln_weight / ln_bias (C) f32 or both NULL,
+ * w (N2, C) f16, bias (N2) f32 or NULL -> out (M, N2 / 2) f16.  kernel: 0 = the library's plan, 1 = the tiled GEMM kernels,
+ * 2 = the weight-stationary kernel (wsgemm.hip: C = 320, N2 % 256 == 0, M >= 2048; other shapes -> SD_ERR_INVALID_ARGUMENT). */
+int sd_op_geglu_ln(const void* x, const float* ln_weight, const float* ln_bias, const void* w, const float* bias, void* out, int M, int C,
+                   int N2, float eps, int kernel, int iters, float* ms);
 /* unet.py:703-728 */
 int sd_op_timestep_embedding(const float* t, float* out, int n, int dim, int flip_sin_to_cos, float freq_shift);
 /* numpy legacy stream: np.random.seed(seed); np.random.randn(n) (pipeline.py:331,:726;

@@ -1,0 +1,380 @@
+// Large-M 1x1 GEMM with the WEIGHTS going global -> VGPR (unet.py:594-617 GEGLU / ff.net.2, :62-118 to_out).
+//
+// LAB_NOTES Finding 5: the tiled kernels of igemm.hip stop at 430-850 TFLOP/s because BOTH operands of a 128 x 128 x 64 step go
+// through the L2 -> LDS fill of one CU (32 KB for 2.1 MFLOP = 64 FLOP per byte), while hipBLASLt reaches 1.0-1.26 PFLOP/s on the
+// same shapes.  xattn_out.hip showed the way round it inside this library: weight fragments straight into registers in MFMA order
+// from a pre-tiled copy, no LDS fill and no ring barrier on the weight side.  This kernel is that idea as a general GEMM:
+//   * workgroup = NW waves, tile BM x (32 NW): wave w owns 32 output columns over all BM rows (BM / 32 accumulator blocks), so
+//     nobody shares a weight fragment and the weights of a workgroup cross L2 -> CU exactly once;
+//   * weights: per 64-deep K stage a wave requests its four 1-KB fragments (fully coalesced 16 B per lane) PB - 1 stages ahead
+//     into a register ring - plain loads, counted by the compiler, nothing to synchronise;
+//   * activations: the only operand in LDS.  Every thread carries 16-byte chunks of the BM x 64 stage through registers (requested
+//     two stages ahead, written one stage ahead: the split issue-early / write-late form) into a two-slot ring with the bank
+//     swizzle of igemm.hip; ONE barrier per stage; 256 FLOP per byte filled at BM = 128;
+//   * LayerNorm fold: the loader threads see every activation chunk exactly once on its way to LDS and keep (sum, sumsq) of it -
+//     the row statistics cost eight v_dot2 per stage and thread, no extra pass;
+//   * epilogue through an LDS tile, whole rows out (bias, LayerNorm fold, residual, or value * gelu(gate) for GEGLU rows in the
+//     lane order of wsgemm.hip).
+// One workgroup of 8 waves per CU (2 per SIMD), like the 256 x 256 8-phase template of the CDNA guide; plain HIP, no inline asm.
+#include "kernels.h"
+
+#include <type_traits>
+
+namespace sd {
+
+namespace {
+
+constexpr int BV_BK = 64;
+
+struct BvArgs {
+  const half_t* x;        // [M][K]
+  const half_t* wt;       // pre-tiled: [N / 32 strips][K / 16][64 lanes][8 halves]  (launch_bvgemm_retile)
+  const float* bias;      // [N] device row order, or null
+  const float* colsum;    // [N] LayerNorm fold, or null
+  const half_t* res;      // [M][ldo] or null (plain mode)
+  half_t* out;            // [M][ldo]
+  int M, N, K, nk, ldo;
+  int mtiles, ntiles;
+  float ln_eps;
+};
+
+__device__ __forceinline__ float bv_gelu_erf(float x) {   // igemm.hip gelu_erf (Abramowitz-Stegun 7.1.26)
+  const float z = x * 0.70710678118654752f;
+  const float az = fabsf(z);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
+  float p = 1.061405429f;
+  p = fmaf(p, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-az * az * 1.4426950408889634f);
+  const float erf_abs = fmaf(-p * t, e, 1.0f);
+  return 0.5f * x * (1.0f + copysignf(erf_abs, z));
+}
+
+// MFMA row n of strip `strip` (the accumulator register of lane half hi = (n >> 2) & 1 that holds it is r = 4 (n >> 3) + (n & 3))
+// -> row of the device weight matrix.  Plain: a lane ends up with the 16 consecutive output channels 32 strip + 16 hi + r.
+// GEGLU: wsgemm.hip's order - registers 0-3 | 8-11 the values, 4-7 | 12-15 the gates of the 8 consecutive channels
+// 16 strip + 8 hi + {0..3 | 4..7}; device rows are 32 values | 32 gates per 64 (UNet::upload_conv_weight).
+__host__ __device__ inline int bv_row(int strip, int n, bool geglu) {
+  const int hi = (n >> 2) & 1, grp = n >> 3, e = n & 3;
+  if (!geglu) return strip * 32 + 16 * hi + 4 * grp + e;
+  const int ch = strip * 16 + 8 * hi + 4 * (grp >> 1) + e;
+  return (ch >> 5) * 64 + (grp & 1) * 32 + (ch & 31);
+}
+
+__global__ __launch_bounds__(256) void bvgemm_retile_kernel(const half_t* __restrict__ w, half_t* __restrict__ wt, int N, int K, int geglu) {
+  const int ks16 = K / 16;
+  const size_t total = (size_t)(N / 32) * ks16 * 64;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(idx & 63);
+    const size_t r = idx >> 6;
+    const int ks = (int)(r % ks16), strip = (int)(r / ks16);
+    const int row = bv_row(strip, lane & 31, geglu != 0);
+    *reinterpret_cast<half8*>(wt + idx * 8) = *reinterpret_cast<const half8*>(w + (size_t)row * K + ks * 16 + (lane >> 5) * 8);
+  }
+}
+
+template <int BM, int NW, bool GEGLU>
+struct BvLds {
+  static constexpr int OCOLS = GEGLU ? NW * 16 : NW * 32;     // output columns of the workgroup
+  static constexpr int OROW = OCOLS + 8;                      // staged row stride in halves
+  static constexpr int SLOT = BM * BV_BK * 2;                 // one activation stage
+  static constexpr int STAGE = BM * OROW * 2;                 // the epilogue's tile (re-uses the ring)
+  static constexpr int MAIN = (2 * SLOT > STAGE) ? 2 * SLOT : STAGE;
+  static constexpr int STAT_OFF = MAIN;                       // [BM][2] floats
+  static constexpr int BYTES = STAT_OFF + BM * 2 * 4;
+};
+
+template <int BM, int NW, bool GEGLU, bool LNF>
+__global__ __launch_bounds__(NW * 64, BM == 64 ? 4 : 2) void bvgemm_kernel(BvArgs a) {   // (BM = 64: two workgroups per CU, 128 VGPRs)
+  using L = BvLds<BM, NW, GEGLU>;
+  constexpr int NT = NW * 64;
+  constexpr int TM = BM / 32;                                  // accumulator blocks per wave
+  constexpr int CPT = BM * 8 / NT;                             // 16-byte activation chunks per thread and stage
+  constexpr int PB = 4;                                        // weight stages in the register ring (requests run PB - 1 ahead)
+  static_assert(BM * 8 % NT == 0 && CPT >= 1, "whole chunks per thread");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  int bid = blockIdx.x;
+  {   // XCD-contiguous walk: the n-tiles of a row block run on ONE XCD, its L2 serves the activations to all of them
+    const int nwg = gridDim.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = ((xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  }
+  const int nt = bid % a.ntiles, mt = bid / a.ntiles;
+  const int m0 = mt * BM;
+  const int strip = nt * NW + wave;
+  const int nk = a.nk, ks16 = a.K >> 4;
+
+  // ---- loader coordinates: chunk j of this thread = (row, 16-byte column) of every stage ----
+  const half_t* asrc[CPT];
+  int adst[CPT];
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) {
+    const int c = tid + j * NT;
+    const int row = c >> 3, ch = c & 7;
+    const int mr = min(m0 + row, a.M - 1);                     // rows past the end re-read the last row (never stored)
+    asrc[j] = a.x + (size_t)mr * a.K + ch * 8;
+    adst[j] = row * 128 + ((ch ^ ((row >> 1) & 7)) * 16);
+  }
+  const half_t* wsrc = a.wt + ((size_t)strip * ks16 * 64 + lane) * 8;
+
+  half8 areg[2][CPT], breg[PB][4];
+  float ls1[CPT], ls2[CPT];
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) ls1[j] = ls2[j] = 0.f;
+  auto load_a = [&](half8 (&dst)[CPT], int s) {
+    const int sc = min(s, nk - 1);                             // (past the end: a redundant re-read, never used)
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) dst[j] = *reinterpret_cast<const half8*>(asrc[j] + sc * BV_BK);
+  };
+  auto load_b = [&](half8 (&dst)[4], int s) {
+    const int sc = min(s, nk - 1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q] = *reinterpret_cast<const half8*>(wsrc + (size_t)(sc * 4 + q) * 512);
+  };
+  auto write_a = [&](const half8 (&src)[CPT], int slot, bool live) {   // live (block-uniform): a stage of the K range, not the clamped tail
+    char* base = smem + slot * L::SLOT;
+    const half2v one2 = {(half_t)1.f, (half_t)1.f};
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+      *reinterpret_cast<half8*>(base + adst[j]) = src[j];
+      if (LNF && live) {                                       // the chunk's share of its row's statistics, on the way through
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const half2v p2 = {src[j][2 * e], src[j][2 * e + 1]};
+          ls2[j] = __builtin_amdgcn_fdot2(p2, p2, ls2[j], false);
+          ls1[j] = __builtin_amdgcn_fdot2(p2, one2, ls1[j], false);
+        }
+      }
+    }
+  };
+
+  const int fsw = (l31 >> 1) & 7;
+  int foff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) foff[q] = l31 * 128 + (((q * 2 + hi) ^ fsw) * 16);
+
+  floatx16 acc[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  // fragment reads run one 16-deep step ahead of the MFMAs that use them (left to itself hipcc issues each pair of reads right
+  // in front of its MFMAs: the LDS latency then sits between every two MFMAs of a wave)
+  auto compute = [&](const half8 (&bq)[4], int slot) {
+    const char* at = smem + slot * L::SLOT;
+    half8 xf[2][TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) xf[0][i] = *reinterpret_cast<const half8*>(at + i * 4096 + foff[0]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q + 1 < 4) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) xf[(q + 1) & 1][i] = *reinterpret_cast<const half8*>(at + i * 4096 + foff[q + 1]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq[q], xf[q & 1][i], acc[i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // ---- prologue: two activation stages and PB - 1 weight stages in flight, stage 0 written ----
+  load_a(areg[0], 0);
+#pragma unroll
+  for (int p = 0; p < PB - 1; ++p) load_b(breg[p], p);
+  load_a(areg[1], 1);
+  write_a(areg[0], 0, true);
+  __syncthreads();
+
+  // stage s: request A(s + 2) and B(s + PB - 1), write A(s + 1), multiply stage s, barrier.  Ring indices are static: four
+  // stages per trip.
+  auto stage = [&](int s, auto ai_c, auto bi_c) {
+    constexpr int AI = decltype(ai_c)::value, BI = decltype(bi_c)::value;   // s % 2, s % PB
+    load_b(breg[(BI + PB - 1) % PB], s + PB - 1);
+    write_a(areg[(AI + 1) % 2], (AI + 1) % 2, s + 1 < nk);
+    load_a(areg[AI], s + 2);   // (after write_a of the OTHER register set; this set's stage s went to LDS one stage ago)
+    compute(breg[BI], AI);
+    __syncthreads();
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  int s = 0;
+  for (; s + 4 <= nk; s += 4) {
+    stage(s, I0{}, I0{});
+    stage(s + 1, I1{}, I1{});
+    stage(s + 2, I0{}, I2{});
+    stage(s + 3, I1{}, I3{});
+  }
+  if (s < nk) stage(s, I0{}, I0{});
+  if (s + 1 < nk) stage(s + 1, I1{}, I1{});
+  if (s + 2 < nk) stage(s + 2, I0{}, I2{});
+
+  // ---- LayerNorm statistics: the 8 chunk owners of a row are 8 consecutive lanes ----
+  float* stat = reinterpret_cast<float*>(smem + L::STAT_OFF);
+  if constexpr (LNF) {
+    // (write_a counted stages 0 .. nk - 1 of every chunk; the clamped re-read behind the last stage is written, not counted)
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+      float s1 = ls1[j], s2 = ls2[j];
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+      }
+      const int c = tid + j * NT;
+      if ((c & 7) == 0) {
+        const float inv_k = 1.0f / (float)a.K;
+        const float mean = s1 * inv_k;
+        const float var = fmaxf(s2 * inv_k - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + a.ln_eps);
+        stat[(c >> 3) * 2] = rstd;
+        stat[(c >> 3) * 2 + 1] = -rstd * mean;
+      }
+    }
+  }
+
+  // ---- epilogue: constants of the lane's 16 accumulator rows, tile -> LDS, whole rows -> global ----
+  half_t* sg = reinterpret_cast<half_t*>(smem);
+  float cb[16], cs[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = bv_row(strip, (r & 3) + 8 * (r >> 2) + 4 * hi, GEGLU);
+    cb[r] = a.bias ? a.bias[row] : 0.f;
+    cs[r] = LNF ? a.colsum[row] : 0.f;
+  }
+  if constexpr (LNF) __syncthreads();                          // statistics visible (the ring is free since the last stage's barrier)
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int row = i * 32 + l31;
+    float la = 1.f, lb = 0.f;
+    if constexpr (LNF) {
+      la = stat[row * 2];
+      lb = stat[row * 2 + 1];
+    }
+    if constexpr (GEGLU) {
+      half8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int rv = (e < 4) ? e : 8 + (e - 4), rg = rv + 4;
+        float v, g;
+        if constexpr (LNF) {
+          v = fmaf(acc[i][rv], la, fmaf(lb, cs[rv], cb[rv]));
+          g = fmaf(acc[i][rg], la, fmaf(lb, cs[rg], cb[rg]));
+        } else {
+          v = acc[i][rv] + cb[rv];
+          g = acc[i][rg] + cb[rg];
+        }
+        o[e] = (half_t)(v * bv_gelu_erf(g));
+      }
+      *reinterpret_cast<half8*>(sg + row * L::OROW + wave * 16 + hi * 8) = o;
+    } else {
+      half8 o[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v;
+        if constexpr (LNF) v = fmaf(acc[i][r], la, fmaf(lb, cs[r], cb[r]));
+        else v = acc[i][r] + cb[r];
+        o[r >> 3][r & 7] = (half_t)v;
+      }
+      *reinterpret_cast<half8*>(sg + row * L::OROW + wave * 32 + hi * 16) = o[0];
+      *reinterpret_cast<half8*>(sg + row * L::OROW + wave * 32 + hi * 16 + 8) = o[1];
+    }
+  }
+  __syncthreads();
+  constexpr int CPR = L::OCOLS / 8;                            // 16-byte chunks per staged row
+  constexpr int ROUNDS = BM * CPR / NT;
+  static_assert(BM * CPR % NT == 0, "whole store rounds");
+  const size_t col0 = (size_t)nt * L::OCOLS;
+#pragma unroll 4
+  for (int it = 0; it < ROUNDS; ++it) {
+    const int id = tid + it * NT;
+    const int r = id / CPR, c = id - r * CPR;
+    half8 v = *reinterpret_cast<const half8*>(sg + r * L::OROW + c * 8);
+    if (m0 + r < a.M) {
+      const size_t off = (size_t)(m0 + r) * a.ldo + col0 + c * 8;
+      if (!GEGLU && a.res) {
+        const half8 rr = *reinterpret_cast<const half8*>(a.res + off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
+      }
+      *reinterpret_cast<half8*>(a.out + off) = v;
+    }
+  }
+}
+
+template <int BM, int NW, bool GEGLU, bool LNF>
+void launch_bv(const BvArgs& a, hipStream_t s) {
+  auto k = bvgemm_kernel<BM, NW, GEGLU, LNF>;
+  constexpr size_t lds = BvLds<BM, NW, GEGLU>::BYTES;
+  static DynLdsOnce once;
+  once.set(k, lds);
+  hipLaunchKernelGGL(k, dim3(a.mtiles * a.ntiles), dim3(NW * 64), lds, s, a);
+}
+
+}  // namespace
+
+// single-source 1x1 GEMM, K a multiple of 64 (>= 256), N a multiple of 256 weight rows, bias / LayerNorm fold / residual or GEGLU;
+// no timestep embedding, no fused q|k|v, no GroupNorm statistics of the output, no split-K.
+bool bvgemm_shape_ok(const ConvDesc& d) {
+  if (d.ksize != 1 || d.stride != 1 || d.up != 1 || d.x1 || d.C0 % 64 != 0 || d.C0 < 256) return false;
+  if (d.temb || d.out_t || d.gn_partial || d.gnf_partial || d.n_twins || d.debug) return false;
+  if (!(d.out_mode == kOutHalf || d.out_mode == kOutGeglu)) return false;
+  if (d.out_mode == kOutGeglu && d.res) return false;
+  if (d.N % 256 != 0) return false;
+  return (long)d.B * d.Ho * d.Wo >= 128;
+}
+
+size_t bvgemm_tiled_halves(int N, int K) { return (size_t)N * K; }
+
+void launch_bvgemm_retile(const half_t* w, half_t* wt, int N, int K, bool geglu, hipStream_t s) {
+  SD_REQUIRE(N % 32 == 0 && K % 16 == 0, kInvalidArgument, "bvgemm retile: N=%d K=%d", N, K);
+  const size_t total = (size_t)N * K / 8;
+  hipLaunchKernelGGL(bvgemm_retile_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, s, w, wt, N, K, geglu ? 1 : 0);
+  SD_HIP(hipGetLastError());
+}
+
+// bm: 128 or 64 rows per workgroup (0: by the size of the grid)
+void launch_bvgemm(const ConvDesc& d, int bm, hipStream_t s) {
+  SD_REQUIRE(bvgemm_shape_ok(d) && d.w_bv, kInvalidArgument, "bvgemm: shape not eligible (C0=%d N=%d mode=%d)", d.C0, d.N, d.out_mode);
+  BvArgs a{};
+  a.x = d.x0;
+  a.wt = d.w_bv;
+  a.bias = d.bias;
+  a.colsum = d.ln_colsum;
+  a.res = d.res;
+  a.out = d.out;
+  a.M = d.B * d.Ho * d.Wo;
+  a.N = d.N;
+  a.K = d.C0;
+  a.nk = a.K / BV_BK;
+  const bool geglu = d.out_mode == kOutGeglu;
+  a.ldo = geglu ? d.N / 2 : d.N;
+  a.ntiles = d.N / 256;
+  a.ln_eps = d.ln_eps;
+  if (bm != 64 && bm != 128) bm = ((long)cdiv(a.M, 128) * a.ntiles >= 200) ? 128 : 64;   // fill the CUs first
+  a.mtiles = cdiv(a.M, bm);
+  const bool lnf = d.ln_colsum != nullptr;
+#define SD_BV(BM_)                                                    \
+  do {                                                                \
+    if (geglu) {                                                      \
+      if (lnf) launch_bv<BM_, 8, true, true>(a, s);                   \
+      else launch_bv<BM_, 8, true, false>(a, s);                      \
+    } else {                                                          \
+      if (lnf) launch_bv<BM_, 8, false, true>(a, s);                  \
+      else launch_bv<BM_, 8, false, false>(a, s);                     \
+    }                                                                 \
+  } while (0)
+  if (bm == 128) SD_BV(128);
+  else SD_BV(64);
+#undef SD_BV
+  SD_HIP(hipGetLastError());
+}
+
+}  // namespace sd

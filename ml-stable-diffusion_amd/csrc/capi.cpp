@@ -467,6 +467,10 @@ int sd_op_conv2d(const void* x, const void* w, const float* bias, const void* re
     d.ksize = ksize; d.stride = stride; d.up = up; d.N = Cout;
     d.tile = tile % 10;          // tile / 10 selects the staging variant of the same tile (A/B testing)
     d.staging = tile / 10;
+    if (tile >= 110 && tile <= 112) {   // 110 / 111 / 112: plan tile 11 (bvgemm.hip) by grid size / 64 rows / 128 rows per workgroup
+      d.tile = 11;
+      d.staging = tile - 110;
+    }
     d.splitk = splitk;
     d.debug = force_generic >= 2 ? force_generic - 1 : 0;   // 2: loads only, 3: compute only (ablation)
     if (d.debug & 4) d.prof = sc.dev<long long>(8);
@@ -478,7 +482,13 @@ int sd_op_conv2d(const void* x, const void* w, const float* bias, const void* re
       launch_wstream_retile(d.w, wtd, Cout, Cin, ksize, sc.stream);
       d.w_tiled = wtd;
     }
-    if (fast) {
+    if (fast && d.tile == 11) {
+      SD_REQUIRE(bvgemm_shape_ok(d), kInvalidArgument, "conv2d: shape not eligible for plan tile 11 (bvgemm.hip)");
+      half_t* wtd = sc.dev<half_t>(bvgemm_tiled_halves(Cout, Cin));
+      launch_bvgemm_retile(d.w, wtd, Cout, Cin, false, sc.stream);
+      d.w_bv = wtd;
+    }
+    if (fast && d.tile != 11) {
       ws.partial_bytes = conv_workspace_bytes(d);
       if (ws.partial_bytes) ws.partial = reinterpret_cast<float*>(sc.dev<char>(ws.partial_bytes));
     }
@@ -1068,6 +1078,80 @@ int sd_op_geglu(const void* x, const void* w, const float* bias, void* out, int 
       else
         launch_conv_generic(d, 0, sc.stream);
     });
+    SD_HIP(hipMemcpy(out, dout, (size_t)M * half_n * 2, hipMemcpyDeviceToHost));
+  });
+}
+
+// GEGLU projection with the LayerNorm in front of it folded in (unet.py:583-591 norm3 -> :609-617 ff.net.0.proj), exactly as the
+// UNet builder folds it (UNet::fold_layernorm): x (M, C) f16 un-normalised rows, ln_weight / ln_bias (C) f32 or both NULL (plain
+// GEGLU), w (N2, C) f16 [values | gates], bias (N2) f32 or NULL -> out (M, N2 / 2) f16.  kernel: 0 = the plan the library picks,
+// 1 = the tiled igemm / gemm_pipe kernels, 2 = the weight-stationary kernel of wsgemm.hip (plan tile 10; refused for other shapes).
+int sd_op_geglu_ln(const void* x, const float* ln_weight, const float* ln_bias, const void* w, const float* bias, void* out, int M, int C,
+                   int N2, float eps, int kernel, int iters, float* ms) {
+  return guarded([&] {
+    const int abl = kernel / 10;   // kernel = 2 + 10 * n: ablation build n of the weight-stationary kernel (measurement tools only)
+    kernel %= 10;
+    SD_REQUIRE(x && w && out && N2 % 64 == 0 && (ln_weight == nullptr) == (ln_bias == nullptr) && kernel >= 0 && kernel <= 5 &&
+                   (abl == 0 || kernel == 2), kInvalidArgument, "bad GEGLU arguments");
+    Scratch sc;
+    const half_t* wh = reinterpret_cast<const half_t*>(w);
+    const int half_n = N2 / 2;
+    std::vector<half_t> wt((size_t)N2 * C);
+    std::vector<float> bt(N2, 0.f), cst(N2, 0.f);
+    for (int o = 0; o < N2; ++o) {
+      const bool gate = o >= half_n;
+      const int j = gate ? o - half_n : o;
+      const int dst = (j / 32) * 64 + (gate ? 32 : 0) + (j % 32);
+      double cs = 0.0, bb = bias ? (double)bias[o] : 0.0;
+      for (int c = 0; c < C; ++c) {
+        const float wv = (float)wh[(size_t)o * C + c];
+        const half_t h = ln_weight ? (half_t)(wv * ln_weight[c]) : wh[(size_t)o * C + c];
+        wt[(size_t)dst * C + c] = h;
+        cs += (double)(float)h;
+        if (ln_bias) bb += (double)wv * (double)ln_bias[c];
+      }
+      bt[dst] = (float)bb;
+      cst[dst] = (float)cs;
+    }
+    ConvDesc d;
+    d.x0 = sc.dev<half_t>((size_t)M * C, reinterpret_cast<const half_t*>(x));
+    d.C0 = C;
+    d.w = sc.dev<half_t>(wt.size(), wt.data());
+    d.bias = sc.dev<float>(N2, bt.data());
+    if (ln_weight) d.ln_colsum = sc.dev<float>(N2, cst.data());
+    d.ln_eps = eps;
+    half_t* dout = sc.dev<half_t>((size_t)M * half_n);
+    d.out = dout;
+    d.B = 1; d.Hi = 1; d.Wi = M; d.Ho = 1; d.Wo = M;
+    d.N = N2;
+    d.out_mode = kOutGeglu;
+    SD_REQUIRE(conv_fast_path_ok(d), kUnsupported, "GEGLU shape off the MFMA path (C=%d N2=%d)", C, N2);
+    if (kernel != 1 && kernel < 3 && wsgemm_shape_ok(d)) {
+      half_t* wtd = sc.dev<half_t>(wsgemm_tiled_halves(N2));
+      launch_wsgemm_retile(d.w, wtd, N2, sc.stream);
+      d.w_ws = wtd;
+    }
+    if (kernel == 2) d.tile = 10;
+    if (kernel >= 3) {   // 3 / 4 / 5: plan tile 11 (bvgemm.hip) by grid size / 64 / 128 rows per workgroup
+      SD_REQUIRE(bvgemm_shape_ok(d), kInvalidArgument, "GEGLU shape not eligible for plan tile 11 (bvgemm.hip)");
+      half_t* wtd = sc.dev<half_t>(bvgemm_tiled_halves(N2, C));
+      launch_bvgemm_retile(d.w, wtd, N2, C, true, sc.stream);
+      d.w_bv = wtd;
+      d.w_ws = nullptr;
+      d.tile = 11;
+      d.staging = kernel - 3;
+    }
+    d.debug = abl;
+    if (abl == 5) d.prof = sc.dev<long long>(64);
+    ConvWorkspace ws;
+    sc.timed(iters, ms, [&] { launch_conv(d, ws, sc.stream); });
+    if (d.prof) {   // workgroup (0, 0), thread 0: shader-clock stamps of its first pipeline iterations
+      long long t[64];
+      SD_HIP(hipMemcpy(t, d.prof, sizeof(t), hipMemcpyDeviceToHost));
+      for (int i = 0; i < 6; ++i)
+        fprintf(stderr, "[sd prof] wsgemm iteration %d: barrier wait %lld, DMA issue + store %lld, statistics %lld, MFMA || epilogue %lld cycles\n",
+                i + 1, t[i * 8 + 1] - t[i * 8], t[i * 8 + 2] - t[i * 8 + 1], t[i * 8 + 3] - t[i * 8 + 2], t[i * 8 + 4] - t[i * 8 + 3]);
+    }
     SD_HIP(hipMemcpy(out, dout, (size_t)M * half_n * 2, hipMemcpyDeviceToHost));
   });
 }

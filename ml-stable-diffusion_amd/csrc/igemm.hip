@@ -2808,6 +2808,21 @@ int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
              kInvalidArgument, "fused q|k|v: n_trans %d N %d HoWo %d ldT %d", d.n_trans, d.N, d.Ho * d.Wo, d.ldT);
   SD_REQUIRE(!d.vt_perm || (d.out_t && (d.Ho * d.Wo) % 16 == 0), kInvalidArgument, "permuted V^T needs the fused q|k|v epilogue and HoWo %% 16 == 0");
   SD_REQUIRE(d.q_cols == 0 || (d.out_t && d.q_cols % 4 == 0 && d.q_cols <= d.n_trans), kInvalidArgument, "pre-scaled queries need the fused q|k|v epilogue (q_cols %d)", d.q_cols);
+  {   // plan tile 10: the weight-stationary GEGLU kernel (wsgemm.hip) wherever its pre-tiled weights exist and nothing else was
+      // asked for (SD_WSGEMM=0 with SD_TUNE: the tiled kernels, A/B; a tuner candidate in force also keeps it off)
+    static const bool wsg_on = tune_env_int("SD_WSGEMM", 1) != 0;
+    const bool forced = d.tile == 10;
+    if (d.w_ws && wsgemm_shape_ok(d) && (forced || (wsg_on && d.tile == 0 && d.splitk == 0 && d.staging == 0 && g_tune.tile == 0))) {
+      launch_wsgemm(d, s);
+      return 0;
+    }
+    SD_REQUIRE(!forced, kInvalidArgument, "plan tile 10 (wsgemm.hip) needs the pre-tiled weights and an eligible GEGLU shape");
+  }
+  if (d.tile == 11) {   // plan tile 11: weights global -> VGPR (bvgemm.hip); staging 1 / 2 force 64 / 128 rows per workgroup
+    SD_REQUIRE(d.w_bv && bvgemm_shape_ok(d), kInvalidArgument, "plan tile 11 (bvgemm.hip) needs the pre-tiled weights and an eligible 1x1 shape");
+    launch_bvgemm(d, d.staging == 1 ? 64 : (d.staging == 2 ? 128 : 0), s);
+    return 0;
+  }
   IgemmArgs a = make_args(d);
   Plan p = choose_plan(d, a);
   bool halo = p.tile == 7;

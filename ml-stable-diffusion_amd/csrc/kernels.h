@@ -87,6 +87,12 @@ struct ConvDesc {
   int gnf_silu = 0;
   // weights in the fragment-major layout of wstream.hip (launch_wstream_retile), or null: plan tile 9 needs them
   const half_t* w_tiled = nullptr;
+  // weights in the fragment-major layout of wsgemm.hip (launch_wsgemm_retile), or null: the weight-stationary GEGLU kernel
+  // (plan tile 10) needs them; launch_conv takes that kernel whenever they are there and no other plan was forced
+  const half_t* w_ws = nullptr;
+  // weights in the fragment-major layout of bvgemm.hip (launch_bvgemm_retile; plain or GEGLU row order by out_mode), or null:
+  // plan tile 11 (weights global -> VGPR, large-M 1x1 GEMMs) needs them
+  const half_t* w_bv = nullptr;
   // n_twins > 0: the output leaves through fp32 slabs and reduce_twin_kernel, which also writes the GroupNorm twins
   // (needs Ho * Wo <= 256 and reduce_twin_ok; launch_conv forces the slab path whatever the plan's split-K)
   GnTwin twin[2];
@@ -120,6 +126,18 @@ int launch_wstream(const ConvDesc& d, float* partial, int nw, hipStream_t s);
 bool reduce_twin_ok(int HW, int N, int n_twins, const GnTwin* tw);
 void launch_reduce_twin(const float* partial, int S, int M, int N, int HW, const float* bias, const float* temb, int temb_stride,
                         const half_t* res, half_t* out, int n_twins, const GnTwin* tw, hipStream_t s);
+
+// wsgemm.hip (round 6): weight-stationary GEGLU projection of the 320-channel level (plan tile 10)
+bool wsgemm_shape_ok(const ConvDesc& d);
+size_t wsgemm_tiled_halves(int N);
+void launch_wsgemm_retile(const half_t* w, half_t* wt, int N, hipStream_t s);
+void launch_wsgemm(const ConvDesc& d, hipStream_t s);
+
+// bvgemm.hip (round 6): 1x1 GEMM with the weights global -> VGPR, activations alone in LDS (plan tile 11)
+bool bvgemm_shape_ok(const ConvDesc& d);
+size_t bvgemm_tiled_halves(int N, int K);
+void launch_bvgemm_retile(const half_t* w, half_t* wt, int N, int K, bool geglu, hipStream_t s);
+void launch_bvgemm(const ConvDesc& d, int bm, hipStream_t s);   // bm: 128 / 64 rows per workgroup, 0 = by the grid size
 
 // calib.hip: box calibration for bench.py - out[0..6] = copy GB/s, dense MFMA TFLOP/s, us per launch of a 323-launch empty
 // graph, us per launch of a 323-launch chain of short kernels on cold operands, us per launch of a 323-launch chain handing 8 MB

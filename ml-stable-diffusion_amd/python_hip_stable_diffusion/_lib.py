@@ -101,6 +101,7 @@ SYMBOLS = [
     ("sd_op_ffn_out_proj", _I, [_P, _P, _FP, _P, _P, _FP, _P, _P, _FP, _I, _I, _I, _I, _I, _I, _FP]),
     ("sd_op_cross_attention_block", _I, [_P, _FP, _FP, _P, _P, _P, _P, _FP, _P, _P, _FP, _P, _I, _I, _I, _I, _F, _I, _I, _FP]),
     ("sd_op_geglu", _I, [_P, _P, _FP, _P, _I, _I, _I, _I, _FP]),
+    ("sd_op_geglu_ln", _I, [_P, _FP, _FP, _P, _FP, _P, _I, _I, _I, C.c_float, _I, _I, _FP]),
     ("sd_op_timestep_embedding", _I, [_FP, _FP, _I, _I, _I, _F]),
     ("sd_numpy_randn", _I, [C.c_uint32, C.POINTER(C.c_double), C.c_size_t]),
     ("sd_torch_randn", _I, [C.c_uint32, C.POINTER(C.c_double), C.c_size_t]),
@@ -368,6 +369,22 @@ def geglu(x, w, bias=None, iters=1):
     out = np.empty((M, N2 // 2), np.float16)
     ms = C.c_float(0)
     check(lib().sd_op_geglu(ptr(x), ptr(w), fptr(bias), ptr(out), M, Cn, N2, iters, C.byref(ms)))
+    return out, ms.value
+
+
+def geglu_ln(x, w, bias=None, ln_weight=None, ln_bias=None, eps=1e-5, kernel=0, iters=1):
+    """GEGLU projection with the LayerNorm in front of it folded in (unet.py:583-591 -> :609-617).  kernel: 0 the library's plan,
+    1 the tiled GEMM kernels, 2 the weight-stationary kernel (wsgemm.hip)."""
+    x, w = f16(x), f16(w)
+    M, Cn = x.shape
+    N2 = w.shape[0]
+    bias = None if bias is None else f32(bias)
+    ln_weight = None if ln_weight is None else f32(ln_weight)
+    ln_bias = None if ln_bias is None else f32(ln_bias)
+    out = np.empty((M, N2 // 2), np.float16)
+    ms = C.c_float(0)
+    check(lib().sd_op_geglu_ln(ptr(x), fptr(ln_weight), fptr(ln_bias), ptr(w), fptr(bias), ptr(out), M, Cn, N2, eps, kernel, iters,
+                               C.byref(ms)))
     return out, ms.value
 
 

@@ -1,0 +1,157 @@
+"""Round-6 kernels through the C ABI against fp32 torch:
+  * the weight-stationary GEGLU projection of the 320-channel level (wsgemm.hip, plan tile 10): norm3 folded into
+    ff.net.0.proj, value * gelu(gate) (unet.py:583-591, :609-617) - against the fp32 reference AND against the tiled GEMM
+    kernels it replaces, ragged row counts, one / odd / even numbers of row tiles per workgroup, bit-reproducibility.
+Tolerances as tests/test_ops_gpu.py: PSNR >= 60 dB, max |err| <= 4e-3 * max|ref| + 1e-3 (fp16 I/O, fp32 accumulate)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import psnr
+from python_hip_stable_diffusion import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def h16(a):
+    return np.asarray(a, np.float32).astype(np.float16)
+
+
+def close(got, ref, what, min_psnr=60.0, rel=4e-3):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert np.isfinite(got).all(), what
+    p = psnr.compute_psnr(got, ref)
+    err = np.abs(got - ref).max()
+    bound = rel * np.abs(ref).max() + 1e-3
+    assert p >= min_psnr and err <= bound, f"{what}: PSNR {p:.1f} dB, max|err| {err:.3e} (bound {bound:.3e})"
+
+
+def geglu_ln_ref(x, w, bias, ln_w, ln_b, eps=1e-5):
+    xt = torch.from_numpy(x.astype(np.float32))
+    if ln_w is not None:
+        xt = F.layer_norm(xt, (xt.shape[1],), torch.from_numpy(ln_w), torch.from_numpy(ln_b), eps)   # unet.py:583-591 norm3
+    h = xt @ torch.from_numpy(w.astype(np.float32)).T
+    if bias is not None:
+        h = h + torch.from_numpy(bias)
+    val, gate = h.chunk(2, dim=1)                                                                   # unet.py:616-617
+    return (val * F.gelu(gate)).numpy()
+
+
+def make_case(m, n2, seed, ln=True, offset=0.0):
+    rs = np.random.RandomState(seed)
+    c = 320
+    x = h16(rs.randn(m, c) * (1.0 + rs.rand(m, 1)) + offset)        # rows of different scale: the fold's statistics matter
+    w = h16(rs.randn(n2, c) / np.sqrt(c))
+    bias = (0.1 * rs.randn(n2)).astype(np.float32)
+    ln_w = (1.0 + 0.2 * rs.randn(c)).astype(np.float32) if ln else None
+    ln_b = (0.1 * rs.randn(c)).astype(np.float32) if ln else None
+    return x, w, bias, ln_w, ln_b
+
+
+WSG_CASES = [  # (M, N2): row tiles of 64 over min(tiles, 256 / (N2 / 256)) workers
+    (8192, 2560),    # SD2.1-base / SD1.5 ff.net.0.proj of the 64x64 level at CFG batch 2: 128 tiles on 25 workers -> 6 | 5 per worker
+    (2048, 2560),    # 32 tiles: one or two per worker
+    (2048, 256),     # ONE column group: 32 workers, one tile each (no pipelining at all)
+    (4096, 512),     # two column groups, 64 tiles on 64 workers
+    (4100, 2560),    # ragged: the last tile has 4 live rows
+    (12288, 2560),   # 192 tiles on 24 workers: 8 per worker (even trip count)
+    (2112, 512),     # 33 tiles: odd, last tile whole
+]
+
+
+@pytest.mark.parametrize("m,n2", WSG_CASES, ids=lambda v: str(v))
+@pytest.mark.parametrize("ln", [True, False], ids=["ln-fold", "plain"])
+def test_wsgemm_geglu_matches_torch(m, n2, ln):
+    x, w, bias, ln_w, ln_b = make_case(m, n2, m + n2, ln)
+    out, _ = _lib.geglu_ln(x, w, bias, ln_w, ln_b, kernel=2)
+    close(out, geglu_ln_ref(x, w, bias, ln_w, ln_b), f"wsgemm geglu M={m} N2={n2} ln={ln}")
+
+
+def test_wsgemm_geglu_matches_the_tiled_kernels():
+    """Same arithmetic as the launches it replaces (fp16 operands, fp32 accumulate, one rounding): both within tolerance of
+    the fp32 reference and of each other; the statistics' summation order is the only difference."""
+    x, w, bias, ln_w, ln_b = make_case(8192, 2560, 7)
+    new, _ = _lib.geglu_ln(x, w, bias, ln_w, ln_b, kernel=2)
+    old, _ = _lib.geglu_ln(x, w, bias, ln_w, ln_b, kernel=1)
+    ref = geglu_ln_ref(x, w, bias, ln_w, ln_b)
+    close(new, ref, "wsgemm vs fp32")
+    close(old, ref, "tiled vs fp32")
+    close(new, old.astype(np.float32), "wsgemm vs tiled", min_psnr=66.0)
+    dflt, _ = _lib.geglu_ln(x, w, bias, ln_w, ln_b, kernel=0)
+    assert np.array_equal(dflt, new), "the library's own plan for this shape is the weight-stationary kernel"
+
+
+def test_wsgemm_geglu_rows_far_from_zero_mean():
+    """LayerNorm fold with a large common offset (mean 6, std ~1.5): E[x^2] - mean^2 in fp32 from fp16 inputs."""
+    x, w, bias, ln_w, ln_b = make_case(4096, 512, 11, offset=6.0)
+    out, _ = _lib.geglu_ln(x, w, bias, ln_w, ln_b, kernel=2)
+    close(out, geglu_ln_ref(x, w, bias, ln_w, ln_b), "wsgemm geglu offset rows")
+
+
+def test_wsgemm_geglu_bit_reproducible():
+    x, w, bias, ln_w, ln_b = make_case(8192, 2560, 3)
+    a, _ = _lib.geglu_ln(x, w, bias, ln_w, ln_b, kernel=2)
+    for _ in range(3):
+        b, _ = _lib.geglu_ln(x, w, bias, ln_w, ln_b, kernel=2)
+        assert np.array_equal(a, b)
+
+
+def test_wsgemm_refuses_other_shapes():
+    rs = np.random.RandomState(0)
+    x = h16(rs.randn(2048, 640))
+    w = h16(rs.randn(5120, 640) / 25.0)
+    with pytest.raises(ValueError):
+        _lib.geglu_ln(x, w, None, None, None, kernel=2)      # K = 640: not this kernel's shape
+    out, _ = _lib.geglu_ln(x, w, None, None, None, kernel=0)  # ... the library's plan still runs it on the tiled kernels
+    close(out, geglu_ln_ref(x, w, None, None, None), "tiled geglu K=640")
+
+
+# ---- bvgemm.hip (plan tile 11): weights global -> VGPR, activations alone in LDS --------------------------------------------
+def conv1x1_ref(x, w, bias, res):
+    y = F.conv2d(torch.from_numpy(x.astype(np.float32)), torch.from_numpy(w.astype(np.float32)), None if bias is None else torch.from_numpy(bias))
+    if res is not None:
+        y = y + torch.from_numpy(res.astype(np.float32))
+    return y
+
+
+BV_CASES = [  # (B, Cin, H, W, Cout)
+    (2, 1280, 16, 16, 1280),   # attn.to_out / proj_in of the 16x16 level (M = 512)
+    (2, 5120, 16, 16, 1280),   # ff.net.2 of the 16x16 level: 80 K stages
+    (2, 1280, 8, 8, 1280),     # M = 128: one row tile, half of it (BM = 128: exactly one)
+    (1, 256, 9, 15, 256),      # ragged M = 135: rows past the end, the smallest K / N (4 stages = the ring depth)
+    (3, 320, 20, 20, 512),     # M = 1200: last row tile ragged for both tile heights, 5 stages (tail of the 4-stage trip)
+    (2, 1280, 32, 32, 2560),   # M = 2048, ten column tiles
+    (2, 448, 16, 16, 256),     # 7 K stages: three-stage tail
+]
+
+
+@pytest.mark.parametrize("case", BV_CASES, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("tile", [110, 111, 112], ids=["auto", "bm64", "bm128"])
+@pytest.mark.parametrize("with_res", [True, False], ids=["res", "nores"])
+def test_bvgemm_matches_torch(case, tile, with_res):
+    b, cin, hh, ww, cout = case
+    rs = np.random.RandomState(sum(case) + tile)
+    x = h16(rs.randn(b, cin, hh, ww))
+    w = h16(rs.randn(cout, cin, 1, 1) / np.sqrt(cin))
+    bias = (0.1 * rs.randn(cout)).astype(np.float32)
+    res = h16(rs.randn(b, cout, hh, ww)) if with_res else None
+    out, _ = _lib.conv2d(x, w, bias, res, tile=tile)
+    close(out, conv1x1_ref(x, w, bias, res), f"bvgemm {case} tile {tile} res={with_res}")
+    again, _ = _lib.conv2d(x, w, bias, res, tile=tile)
+    assert np.array_equal(out, again), "bit-reproducible"
+
+
+@pytest.mark.parametrize("m,c,n2", [(512, 1280, 10240), (2048, 640, 5120), (8192, 320, 2560), (1000, 640, 512)], ids=lambda v: str(v))
+@pytest.mark.parametrize("kernel", [3, 4, 5], ids=["auto", "bm64", "bm128"])
+@pytest.mark.parametrize("ln", [True, False], ids=["ln-fold", "plain"])
+def test_bvgemm_geglu_matches_torch(m, c, n2, kernel, ln):
+    rs = np.random.RandomState(m + c + kernel)
+    x = h16(rs.randn(m, c) * (1.0 + rs.rand(m, 1)))
+    w = h16(rs.randn(n2, c) / np.sqrt(c))
+    bias = (0.1 * rs.randn(n2)).astype(np.float32)
+    ln_w = (1.0 + 0.2 * rs.randn(c)).astype(np.float32) if ln else None
+    ln_b = (0.1 * rs.randn(c)).astype(np.float32) if ln else None
+    out, _ = _lib.geglu_ln(x, w, bias, ln_w, ln_b, kernel=kernel)
+    close(out, geglu_ln_ref(x, w, bias, ln_w, ln_b), f"bvgemm geglu M={m} C={c} N2={n2} kernel={kernel} ln={ln}")
