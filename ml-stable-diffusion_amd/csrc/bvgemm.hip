@@ -75,9 +75,9 @@ __global__ __launch_bounds__(256) void bvgemm_retile_kernel(const half_t* __rest
   }
 }
 
-template <int BM, int NW, bool GEGLU>
+template <int BM, int NW, int TN, bool GEGLU>
 struct BvLds {
-  static constexpr int OCOLS = GEGLU ? NW * 16 : NW * 32;     // output columns of the workgroup
+  static constexpr int OCOLS = (GEGLU ? 16 : 32) * NW * TN;   // output columns of the workgroup
   static constexpr int OROW = OCOLS + 8;                      // staged row stride in halves
   static constexpr int SLOT = BM * BV_BK * 2;                 // one activation stage
   static constexpr int STAGE = BM * OROW * 2;                 // the epilogue's tile (re-uses the ring)
@@ -86,13 +86,16 @@ struct BvLds {
   static constexpr int BYTES = STAT_OFF + BM * 2 * 4;
 };
 
-template <int BM, int NW, bool GEGLU, bool LNF>
-__global__ __launch_bounds__(NW * 64, BM == 64 ? 4 : 2) void bvgemm_kernel(BvArgs a) {   // (BM = 64: two workgroups per CU, 128 VGPRs)
-  using L = BvLds<BM, NW, GEGLU>;
+// TN: 32-column blocks per wave (1: wave tile BM x 32; 2: BM x 64 - every activation fragment read from LDS meets two weight
+// fragments, half the LDS traffic per MFMA, twice the accumulators); PB: weight stages in the register ring (requests run PB - 1
+// stages ahead).  Occupancy: 8 waves per CU in every configuration (one workgroup of 8, or two of 4).
+template <int BM, int NW, int TN, int PB, bool GEGLU, bool LNF>
+__global__ __launch_bounds__(NW * 64, (BM == 64 && TN == 1) ? 4 : 2) void bvgemm_kernel(BvArgs a) {
+  using L = BvLds<BM, NW, TN, GEGLU>;
   constexpr int NT = NW * 64;
-  constexpr int TM = BM / 32;                                  // accumulator blocks per wave
+  constexpr int TM = BM / 32;                                  // accumulator row blocks per wave
   constexpr int CPT = BM * 8 / NT;                             // 16-byte activation chunks per thread and stage
-  constexpr int PB = 4;                                        // weight stages in the register ring (requests run PB - 1 ahead)
+  constexpr int NBF = 4 * TN;                                  // weight fragments per wave and stage
   static_assert(BM * 8 % NT == 0 && CPT >= 1, "whole chunks per thread");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(NW * 64, BM == 64 ? 4 : 2) void bvgemm_kernel(BvArg
   }
   const int nt = bid % a.ntiles, mt = bid / a.ntiles;
   const int m0 = mt * BM;
-  const int strip = nt * NW + wave;
+  const int strip0 = (nt * NW + wave) * TN;                    // the wave's first 32-row weight strip
   const int nk = a.nk, ks16 = a.K >> 4;
 
   // ---- loader coordinates: chunk j of this thread = (row, 16-byte column) of every stage ----
@@ -120,23 +123,27 @@ __global__ __launch_bounds__(NW * 64, BM == 64 ? 4 : 2) void bvgemm_kernel(BvArg
     asrc[j] = a.x + (size_t)mr * a.K + ch * 8;
     adst[j] = row * 128 + ((ch ^ ((row >> 1) & 7)) * 16);
   }
-  const half_t* wsrc = a.wt + ((size_t)strip * ks16 * 64 + lane) * 8;
+  const half_t* wsrc = a.wt + ((size_t)strip0 * ks16 * 64 + lane) * 8;
+  const size_t wstrip = (size_t)ks16 * 512;                    // halves between two strips
 
-  half8 areg[2][CPT], breg[PB][4];
+  constexpr int AD = TN >= 2 ? 1 : 2;   // activation register sets: 2 = requested two stages ahead; 1 (the 256-VGPR wave tile): one
+  half8 areg[AD][CPT], breg[PB][NBF];
   float ls1[CPT], ls2[CPT];
 #pragma unroll
   for (int j = 0; j < CPT; ++j) ls1[j] = ls2[j] = 0.f;
-  auto load_a = [&](half8 (&dst)[CPT], int s) {
+  auto load_a = [&](half8 (&dst)[CPT], int s) __attribute__((always_inline)) {
     const int sc = min(s, nk - 1);                             // (past the end: a redundant re-read, never used)
 #pragma unroll
     for (int j = 0; j < CPT; ++j) dst[j] = *reinterpret_cast<const half8*>(asrc[j] + sc * BV_BK);
   };
-  auto load_b = [&](half8 (&dst)[4], int s) {
+  auto load_b = [&](half8 (&dst)[NBF], int s) __attribute__((always_inline)) {
     const int sc = min(s, nk - 1);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) dst[q] = *reinterpret_cast<const half8*>(wsrc + (size_t)(sc * 4 + q) * 512);
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dst[j * 4 + q] = *reinterpret_cast<const half8*>(wsrc + j * wstrip + (size_t)(sc * 4 + q) * 512);
   };
-  auto write_a = [&](const half8 (&src)[CPT], int slot, bool live) {   // live (block-uniform): a stage of the K range, not the clamped tail
+  auto write_a = [&](const half8 (&src)[CPT], int slot, bool live) __attribute__((always_inline)) {   // live (block-uniform): a stage of the K range, not the clamped tail
     char* base = smem + slot * L::SLOT;
     const half2v one2 = {(half_t)1.f, (half_t)1.f};
 #pragma unroll
@@ -158,15 +165,17 @@ __global__ __launch_bounds__(NW * 64, BM == 64 ? 4 : 2) void bvgemm_kernel(BvArg
 #pragma unroll
   for (int q = 0; q < 4; ++q) foff[q] = l31 * 128 + (((q * 2 + hi) ^ fsw) * 16);
 
-  floatx16 acc[TM];
+  floatx16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // fragment reads run one 16-deep step ahead of the MFMAs that use them (left to itself hipcc issues each pair of reads right
   // in front of its MFMAs: the LDS latency then sits between every two MFMAs of a wave)
-  auto compute = [&](const half8 (&bq)[4], int slot) {
+  auto compute = [&](const half8 (&bq)[NBF], int slot) __attribute__((always_inline)) {
     const char* at = smem + slot * L::SLOT;
     half8 xf[2][TM];
 #pragma unroll
@@ -178,43 +187,48 @@ __global__ __launch_bounds__(NW * 64, BM == 64 ? 4 : 2) void bvgemm_kernel(BvArg
         for (int i = 0; i < TM; ++i) xf[(q + 1) & 1][i] = *reinterpret_cast<const half8*>(at + i * 4096 + foff[q + 1]);
       }
 #pragma unroll
-      for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq[q], xf[q & 1][i], acc[i], 0, 0, 0);
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq[j * 4 + q], xf[q & 1][i], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
 
-  // ---- prologue: two activation stages and PB - 1 weight stages in flight, stage 0 written ----
+  // ---- prologue: the first activation stage(s) and PB - 1 weight stages in flight, stage 0 written ----
   load_a(areg[0], 0);
 #pragma unroll
   for (int p = 0; p < PB - 1; ++p) load_b(breg[p], p);
-  load_a(areg[1], 1);
+  if constexpr (AD == 2) load_a(areg[1], 1);
   write_a(areg[0], 0, true);
   __syncthreads();
 
-  // stage s: request A(s + 2) and B(s + PB - 1), write A(s + 1), multiply stage s, barrier.  Ring indices are static: four
-  // stages per trip.
-  auto stage = [&](int s, auto ai_c, auto bi_c) {
-    constexpr int AI = decltype(ai_c)::value, BI = decltype(bi_c)::value;   // s % 2, s % PB
+  // stage s: request B(s + PB - 1) and the next activation stage, multiply stage s, barrier; the activation stage s + 1 goes to
+  // the other LDS slot in front of (AD == 2: it was requested a stage ago) or behind (AD == 1) the MFMAs.  Ring indices are
+  // static: U stages per trip (U = lcm(2, PB)).
+  auto stage = [&](int s, auto si_c) __attribute__((always_inline)) {
+    constexpr int SI = decltype(si_c)::value;
+    constexpr int AI = SI % 2, BI = SI % PB;
     load_b(breg[(BI + PB - 1) % PB], s + PB - 1);
-    write_a(areg[(AI + 1) % 2], (AI + 1) % 2, s + 1 < nk);
-    load_a(areg[AI], s + 2);   // (after write_a of the OTHER register set; this set's stage s went to LDS one stage ago)
-    compute(breg[BI], AI);
+    if constexpr (AD == 2) {
+      write_a(areg[(AI + 1) % 2], (AI + 1) % 2, s + 1 < nk);
+      load_a(areg[AI], s + 2);   // (this set's stage s went to LDS one stage ago)
+      compute(breg[BI], AI);
+    } else {
+      load_a(areg[0], s + 1);
+      compute(breg[BI], AI);
+      write_a(areg[0], (AI + 1) % 2, s + 1 < nk);
+    }
     __syncthreads();
   };
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, 2>;
-  using I3 = std::integral_constant<int, 3>;
+  constexpr int U = (PB % 2 == 0) ? PB : 2 * PB;
+  auto trip = [&](int s, int count) __attribute__((always_inline)) {   // stages s .. s + count - 1 (count <= U, block-uniform)
+    [&]<int... I>(std::integer_sequence<int, I...>) {
+      ((I < count ? stage(s + I, std::integral_constant<int, I>{}) : void()), ...);
+    }(std::make_integer_sequence<int, U>{});
+  };
   int s = 0;
-  for (; s + 4 <= nk; s += 4) {
-    stage(s, I0{}, I0{});
-    stage(s + 1, I1{}, I1{});
-    stage(s + 2, I0{}, I2{});
-    stage(s + 3, I1{}, I3{});
-  }
-  if (s < nk) stage(s, I0{}, I0{});
-  if (s + 1 < nk) stage(s + 1, I1{}, I1{});
-  if (s + 2 < nk) stage(s + 2, I0{}, I2{});
+  for (; s + U <= nk; s += U) trip(s, U);
+  if (s < nk) trip(s, nk - s);
 
   // ---- LayerNorm statistics: the 8 chunk owners of a row are 8 consecutive lanes ----
   float* stat = reinterpret_cast<float*>(smem + L::STAT_OFF);
@@ -240,51 +254,54 @@ __global__ __launch_bounds__(NW * 64, BM == 64 ? 4 : 2) void bvgemm_kernel(BvArg
     }
   }
 
-  // ---- epilogue: constants of the lane's 16 accumulator rows, tile -> LDS, whole rows -> global ----
+  // ---- epilogue: per column block the constants of the lane's 16 accumulator rows, tile -> LDS, whole rows -> global ----
   half_t* sg = reinterpret_cast<half_t*>(smem);
-  float cb[16], cs[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = bv_row(strip, (r & 3) + 8 * (r >> 2) + 4 * hi, GEGLU);
-    cb[r] = a.bias ? a.bias[row] : 0.f;
-    cs[r] = LNF ? a.colsum[row] : 0.f;
-  }
   if constexpr (LNF) __syncthreads();                          // statistics visible (the ring is free since the last stage's barrier)
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int row = i * 32 + l31;
-    float la = 1.f, lb = 0.f;
-    if constexpr (LNF) {
-      la = stat[row * 2];
-      lb = stat[row * 2 + 1];
+  for (int j = 0; j < TN; ++j) {
+    float cb[16], cs[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = bv_row(strip0 + j, (r & 3) + 8 * (r >> 2) + 4 * hi, GEGLU);
+      cb[r] = a.bias ? a.bias[row] : 0.f;
+      cs[r] = LNF ? a.colsum[row] : 0.f;
     }
-    if constexpr (GEGLU) {
-      half8 o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int rv = (e < 4) ? e : 8 + (e - 4), rg = rv + 4;
-        float v, g;
-        if constexpr (LNF) {
-          v = fmaf(acc[i][rv], la, fmaf(lb, cs[rv], cb[rv]));
-          g = fmaf(acc[i][rg], la, fmaf(lb, cs[rg], cb[rg]));
-        } else {
-          v = acc[i][rv] + cb[rv];
-          g = acc[i][rg] + cb[rg];
+    for (int i = 0; i < TM; ++i) {
+      const int row = i * 32 + l31;
+      float la = 1.f, lb = 0.f;
+      if constexpr (LNF) {
+        la = stat[row * 2];
+        lb = stat[row * 2 + 1];
+      }
+      if constexpr (GEGLU) {
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int rv = (e < 4) ? e : 8 + (e - 4), rg = rv + 4;
+          float v, g;
+          if constexpr (LNF) {
+            v = fmaf(acc[i][j][rv], la, fmaf(lb, cs[rv], cb[rv]));
+            g = fmaf(acc[i][j][rg], la, fmaf(lb, cs[rg], cb[rg]));
+          } else {
+            v = acc[i][j][rv] + cb[rv];
+            g = acc[i][j][rg] + cb[rg];
+          }
+          o[e] = (half_t)(v * bv_gelu_erf(g));
         }
-        o[e] = (half_t)(v * bv_gelu_erf(g));
-      }
-      *reinterpret_cast<half8*>(sg + row * L::OROW + wave * 16 + hi * 8) = o;
-    } else {
-      half8 o[2];
+        *reinterpret_cast<half8*>(sg + row * L::OROW + (wave * TN + j) * 16 + hi * 8) = o;
+      } else {
+        half8 o[2];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v;
-        if constexpr (LNF) v = fmaf(acc[i][r], la, fmaf(lb, cs[r], cb[r]));
-        else v = acc[i][r] + cb[r];
-        o[r >> 3][r & 7] = (half_t)v;
+        for (int r = 0; r < 16; ++r) {
+          float v;
+          if constexpr (LNF) v = fmaf(acc[i][j][r], la, fmaf(lb, cs[r], cb[r]));
+          else v = acc[i][j][r] + cb[r];
+          o[r >> 3][r & 7] = (half_t)v;
+        }
+        *reinterpret_cast<half8*>(sg + row * L::OROW + (wave * TN + j) * 32 + hi * 16) = o[0];
+        *reinterpret_cast<half8*>(sg + row * L::OROW + (wave * TN + j) * 32 + hi * 16 + 8) = o[1];
       }
-      *reinterpret_cast<half8*>(sg + row * L::OROW + wave * 32 + hi * 16) = o[0];
-      *reinterpret_cast<half8*>(sg + row * L::OROW + wave * 32 + hi * 16 + 8) = o[1];
     }
   }
   __syncthreads();
@@ -309,10 +326,10 @@ __global__ __launch_bounds__(NW * 64, BM == 64 ? 4 : 2) void bvgemm_kernel(BvArg
   }
 }
 
-template <int BM, int NW, bool GEGLU, bool LNF>
+template <int BM, int NW, int TN, int PB, bool GEGLU, bool LNF>
 void launch_bv(const BvArgs& a, hipStream_t s) {
-  auto k = bvgemm_kernel<BM, NW, GEGLU, LNF>;
-  constexpr size_t lds = BvLds<BM, NW, GEGLU>::BYTES;
+  auto k = bvgemm_kernel<BM, NW, TN, PB, GEGLU, LNF>;
+  constexpr size_t lds = BvLds<BM, NW, TN, GEGLU>::BYTES;
   static DynLdsOnce once;
   once.set(k, lds);
   hipLaunchKernelGGL(k, dim3(a.mtiles * a.ntiles), dim3(NW * 64), lds, s, a);
@@ -320,14 +337,14 @@ void launch_bv(const BvArgs& a, hipStream_t s) {
 
 }  // namespace
 
-// single-source 1x1 GEMM, K a multiple of 64 (>= 256), N a multiple of 256 weight rows, bias / LayerNorm fold / residual or GEGLU;
+// single-source 1x1 GEMM, K a multiple of 64 (>= 256), N a multiple of 128 weight rows, bias / LayerNorm fold / residual or GEGLU;
 // no timestep embedding, no fused q|k|v, no GroupNorm statistics of the output, no split-K.
 bool bvgemm_shape_ok(const ConvDesc& d) {
   if (d.ksize != 1 || d.stride != 1 || d.up != 1 || d.x1 || d.C0 % 64 != 0 || d.C0 < 256) return false;
   if (d.temb || d.out_t || d.gn_partial || d.gnf_partial || d.n_twins || d.debug) return false;
   if (!(d.out_mode == kOutHalf || d.out_mode == kOutGeglu)) return false;
   if (d.out_mode == kOutGeglu && d.res) return false;
-  if (d.N % 256 != 0) return false;
+  if (d.N % 128 != 0) return false;
   return (long)d.B * d.Ho * d.Wo >= 128;
 }
 
@@ -340,9 +357,21 @@ void launch_bvgemm_retile(const half_t* w, half_t* wt, int N, int K, bool geglu,
   SD_HIP(hipGetLastError());
 }
 
-// bm: 128 or 64 rows per workgroup (0: by the size of the grid)
-void launch_bvgemm(const ConvDesc& d, int bm, hipStream_t s) {
+// variant: 1: 64 rows x 8 waves x 32 columns; 2: 128 rows x 8 waves x 32 columns; 3: 128 rows x 4 waves x 64 columns (two
+// workgroups per CU); 4: 128 rows x 4 waves x 32 columns (128-column tiles: the only form for N % 256 != 0); 0 = chosen here from
+// the stand-alone table profiles/r06_bvgemm_bench.txt
+int bvgemm_auto_variant(const ConvDesc& d) {
+  const long M = (long)d.B * d.Ho * d.Wo;
+  if (d.N % 256 != 0) return 4;
+  if (d.out_mode == kOutGeglu) return (d.C0 >= 1280 || M < 16384) ? 2 : 3;
+  if (M >= 16384) return 3;
+  return 1;
+}
+
+void launch_bvgemm(const ConvDesc& d, int variant, hipStream_t s) {
   SD_REQUIRE(bvgemm_shape_ok(d) && d.w_bv, kInvalidArgument, "bvgemm: shape not eligible (C0=%d N=%d mode=%d)", d.C0, d.N, d.out_mode);
+  if (variant < 1 || variant > 4) variant = bvgemm_auto_variant(d);
+  SD_REQUIRE(variant == 4 || d.N % 256 == 0, kInvalidArgument, "bvgemm variant %d needs N %% 256 == 0 (N=%d)", variant, d.N);
   BvArgs a{};
   a.x = d.x0;
   a.wt = d.w_bv;
@@ -356,25 +385,35 @@ void launch_bvgemm(const ConvDesc& d, int bm, hipStream_t s) {
   a.nk = a.K / BV_BK;
   const bool geglu = d.out_mode == kOutGeglu;
   a.ldo = geglu ? d.N / 2 : d.N;
-  a.ntiles = d.N / 256;
+  a.ntiles = d.N / (variant == 4 ? 128 : 256);
   a.ln_eps = d.ln_eps;
-  if (bm != 64 && bm != 128) bm = ((long)cdiv(a.M, 128) * a.ntiles >= 200) ? 128 : 64;   // fill the CUs first
+  const int bm = variant == 1 ? 64 : 128;
   a.mtiles = cdiv(a.M, bm);
   const bool lnf = d.ln_colsum != nullptr;
-#define SD_BV(BM_)                                                    \
+#define SD_BV(BM_, NW_, TN_, PB_)                                     \
   do {                                                                \
     if (geglu) {                                                      \
-      if (lnf) launch_bv<BM_, 8, true, true>(a, s);                   \
-      else launch_bv<BM_, 8, true, false>(a, s);                      \
+      if (lnf) launch_bv<BM_, NW_, TN_, PB_, true, true>(a, s);       \
+      else launch_bv<BM_, NW_, TN_, PB_, true, false>(a, s);          \
     } else {                                                          \
-      if (lnf) launch_bv<BM_, 8, false, true>(a, s);                  \
-      else launch_bv<BM_, 8, false, false>(a, s);                     \
+      if (lnf) launch_bv<BM_, NW_, TN_, PB_, false, true>(a, s);      \
+      else launch_bv<BM_, NW_, TN_, PB_, false, false>(a, s);         \
     }                                                                 \
   } while (0)
-  if (bm == 128) SD_BV(128);
-  else SD_BV(64);
+  if (variant == 1) SD_BV(64, 8, 1, 4);
+  else if (variant == 2) SD_BV(128, 8, 1, 4);
+  else if (variant == 3) SD_BV(128, 4, 2, 2);
+  else SD_BV(128, 4, 1, 4);
 #undef SD_BV
   SD_HIP(hipGetLastError());
+}
+
+// The library's own rule (launch_conv / UNet::conv_w): where the stand-alone table shows this kernel ahead of the tiled ones -
+// 8 192 rows and more, K of at least 640 (K = 320 GEGLU belongs to wsgemm.hip)
+bool bvgemm_wanted(const ConvDesc& d) {
+  if (!bvgemm_shape_ok(d)) return false;
+  const long M = (long)d.B * d.Ho * d.Wo;
+  return M >= 4096 && d.C0 >= 640;
 }
 
 }  // namespace sd

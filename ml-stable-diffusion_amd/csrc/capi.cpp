@@ -467,7 +467,7 @@ int sd_op_conv2d(const void* x, const void* w, const float* bias, const void* re
     d.ksize = ksize; d.stride = stride; d.up = up; d.N = Cout;
     d.tile = tile % 10;          // tile / 10 selects the staging variant of the same tile (A/B testing)
     d.staging = tile / 10;
-    if (tile >= 110 && tile <= 112) {   // 110 / 111 / 112: plan tile 11 (bvgemm.hip) by grid size / 64 rows / 128 rows per workgroup
+    if (tile >= 110 && tile <= 114) {   // 110 / 111 / 112 / 113: plan tile 11 (bvgemm.hip) by grid size / variants 1-3 (launch_bvgemm)
       d.tile = 11;
       d.staging = tile - 110;
     }
@@ -1091,7 +1091,7 @@ int sd_op_geglu_ln(const void* x, const float* ln_weight, const float* ln_bias, 
   return guarded([&] {
     const int abl = kernel / 10;   // kernel = 2 + 10 * n: ablation build n of the weight-stationary kernel (measurement tools only)
     kernel %= 10;
-    SD_REQUIRE(x && w && out && N2 % 64 == 0 && (ln_weight == nullptr) == (ln_bias == nullptr) && kernel >= 0 && kernel <= 5 &&
+    SD_REQUIRE(x && w && out && N2 % 64 == 0 && (ln_weight == nullptr) == (ln_bias == nullptr) && kernel >= 0 && kernel <= 7 &&
                    (abl == 0 || kernel == 2), kInvalidArgument, "bad GEGLU arguments");
     Scratch sc;
     const half_t* wh = reinterpret_cast<const half_t*>(w);
@@ -1132,7 +1132,7 @@ int sd_op_geglu_ln(const void* x, const float* ln_weight, const float* ln_bias, 
       d.w_ws = wtd;
     }
     if (kernel == 2) d.tile = 10;
-    if (kernel >= 3) {   // 3 / 4 / 5: plan tile 11 (bvgemm.hip) by grid size / 64 / 128 rows per workgroup
+    if (kernel >= 3) {   // 3 / 4 / 5 / 6: plan tile 11 (bvgemm.hip) by grid size / variants 1-3
       SD_REQUIRE(bvgemm_shape_ok(d), kInvalidArgument, "GEGLU shape not eligible for plan tile 11 (bvgemm.hip)");
       half_t* wtd = sc.dev<half_t>(bvgemm_tiled_halves(N2, C));
       launch_bvgemm_retile(d.w, wtd, N2, C, true, sc.stream);

@@ -2818,9 +2818,16 @@ int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
     }
     SD_REQUIRE(!forced, kInvalidArgument, "plan tile 10 (wsgemm.hip) needs the pre-tiled weights and an eligible GEGLU shape");
   }
-  if (d.tile == 11) {   // plan tile 11: weights global -> VGPR (bvgemm.hip); staging 1 / 2 force 64 / 128 rows per workgroup
+  {   // plan tile 11 on the library's own rule (SD_BVGEMM=0 with SD_TUNE: off, A/B)
+    static const bool bv_on = tune_env_int("SD_BVGEMM", 1) != 0;
+    if (bv_on && d.w_bv && d.tile == 0 && d.splitk == 0 && d.staging == 0 && g_tune.tile == 0 && bvgemm_wanted(d)) {
+      launch_bvgemm(d, 0, s);
+      return 0;
+    }
+  }
+  if (d.tile == 11) {   // plan tile 11: weights global -> VGPR (bvgemm.hip); staging 1 - 4 force a variant (launch_bvgemm)
     SD_REQUIRE(d.w_bv && bvgemm_shape_ok(d), kInvalidArgument, "plan tile 11 (bvgemm.hip) needs the pre-tiled weights and an eligible 1x1 shape");
-    launch_bvgemm(d, d.staging == 1 ? 64 : (d.staging == 2 ? 128 : 0), s);
+    launch_bvgemm(d, d.staging, s);
     return 0;
   }
   IgemmArgs a = make_args(d);

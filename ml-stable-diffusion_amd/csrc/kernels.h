@@ -137,7 +137,8 @@ void launch_wsgemm(const ConvDesc& d, hipStream_t s);
 bool bvgemm_shape_ok(const ConvDesc& d);
 size_t bvgemm_tiled_halves(int N, int K);
 void launch_bvgemm_retile(const half_t* w, half_t* wt, int N, int K, bool geglu, hipStream_t s);
-void launch_bvgemm(const ConvDesc& d, int bm, hipStream_t s);   // bm: 128 / 64 rows per workgroup, 0 = by the grid size
+void launch_bvgemm(const ConvDesc& d, int variant, hipStream_t s);   // variant 1-4 (bvgemm.hip), 0 = the library's choice
+bool bvgemm_wanted(const ConvDesc& d);                                // the library's rule for taking plan tile 11 on its own
 
 // calib.hip: box calibration for bench.py - out[0..6] = copy GB/s, dense MFMA TFLOP/s, us per launch of a 323-launch empty
 // graph, us per launch of a 323-launch chain of short kernels on cold operands, us per launch of a 323-launch chain handing 8 MB

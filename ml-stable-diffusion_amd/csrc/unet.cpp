@@ -352,6 +352,14 @@ Tensor UNet::conv_w(std::vector<Op>& ops, const std::string& name, const half_t*
         d.w_ws = wt;
       }
     }
+    {   // large-M 1x1 GEMMs: weights global -> VGPR (bvgemm.hip) reads its own fragment-major copy
+      static const bool bv_on = tune_env_int("SD_BVGEMM", 1) != 0;
+      if (bv_on && !d.w_ws && bvgemm_wanted(d)) {
+        half_t* wt = arena_.alloc_n<half_t>(bvgemm_tiled_halves(cout, x.C));
+        launch_bvgemm_retile(w, wt, cout, x.C, geglu, stream_);
+        d.w_bv = wt;
+      }
+    }
     if (hook) {
       hook->twin_capable = !ex && d.Ho * d.Wo <= 256;
       hook->desc = d;

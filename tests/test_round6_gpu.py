@@ -128,7 +128,7 @@ BV_CASES = [  # (B, Cin, H, W, Cout)
 
 
 @pytest.mark.parametrize("case", BV_CASES, ids=lambda c: "x".join(map(str, c)))
-@pytest.mark.parametrize("tile", [110, 111, 112], ids=["auto", "bm64", "bm128"])
+@pytest.mark.parametrize("tile", [110, 111, 112, 113, 114], ids=["auto", "64x8x32", "128x8x32", "128x4x64", "128x4x32"])
 @pytest.mark.parametrize("with_res", [True, False], ids=["res", "nores"])
 def test_bvgemm_matches_torch(case, tile, with_res):
     b, cin, hh, ww, cout = case
@@ -144,7 +144,7 @@ def test_bvgemm_matches_torch(case, tile, with_res):
 
 
 @pytest.mark.parametrize("m,c,n2", [(512, 1280, 10240), (2048, 640, 5120), (8192, 320, 2560), (1000, 640, 512)], ids=lambda v: str(v))
-@pytest.mark.parametrize("kernel", [3, 4, 5], ids=["auto", "bm64", "bm128"])
+@pytest.mark.parametrize("kernel", [3, 4, 5, 6, 7], ids=["auto", "64x8x32", "128x8x32", "128x4x64", "128x4x32"])
 @pytest.mark.parametrize("ln", [True, False], ids=["ln-fold", "plain"])
 def test_bvgemm_geglu_matches_torch(m, c, n2, kernel, ln):
     rs = np.random.RandomState(m + c + kernel)
@@ -155,3 +155,19 @@ def test_bvgemm_geglu_matches_torch(m, c, n2, kernel, ln):
     ln_b = (0.1 * rs.randn(c)).astype(np.float32) if ln else None
     out, _ = _lib.geglu_ln(x, w, bias, ln_w, ln_b, kernel=kernel)
     close(out, geglu_ln_ref(x, w, bias, ln_w, ln_b), f"bvgemm geglu M={m} C={c} N2={n2} kernel={kernel} ln={ln}")
+
+
+@pytest.mark.parametrize("case", [(2, 640, 32, 32, 640), (2, 2560, 32, 32, 640), (1, 1280, 24, 24, 1920)], ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("tile", [110, 114], ids=["auto", "128x4x32"])
+def test_bvgemm_128_column_tiles(case, tile):
+    """N a multiple of 128 but not of 256 (the 640-channel level's to_out / ff.net.2): only the 128-column variant applies."""
+    b, cin, hh, ww, cout = case
+    rs = np.random.RandomState(sum(case))
+    x = h16(rs.randn(b, cin, hh, ww))
+    w = h16(rs.randn(cout, cin, 1, 1) / np.sqrt(cin))
+    bias = (0.1 * rs.randn(cout)).astype(np.float32)
+    res = h16(rs.randn(b, cout, hh, ww))
+    out, _ = _lib.conv2d(x, w, bias, res, tile=tile)
+    close(out, conv1x1_ref(x, w, bias, res), f"bvgemm {case} tile {tile}")
+    with pytest.raises(ValueError):
+        _lib.conv2d(x, w, bias, res, tile=113)   # 256-column variants refuse it
