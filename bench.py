@@ -23,7 +23,7 @@ Timing: the K-step timed region (barrier + synchronize on both sides, max over r
 Extra objects on the JSON line:
   roofline     MFMA roofline of the step graph: algorithmic FLOP per step (SURVEY.md section 8d:
                1.6085e12 per CFG-batch-2 step) / HIP-event time per step on the handle's stream;
-               `traffic` = HBM bytes per step from rocprofv3 PMC passes (profiles/r05_final_hbm_traffic.json,
+               `traffic` = HBM bytes per step from rocprofv3 PMC passes (profiles/r06_final_hbm_traffic.json,
                `tools/gpu_session.sh <tag> pmc`; only when the file was measured on this very library and workload),
                `dominant_kernel` = the kernel family with the largest TIME share of the step (sd_unet_profile: HIP
                events around every op of the eager step), `kernel_families` = all of them, `flop_heaviest_kernel` =
@@ -52,7 +52,7 @@ FLOP_PER_SAMPLE_STEP = 1.6085e12 / 2     # 804.3 GFLOP p
 MFMA_PEAK_TFLOPS = 2500.0                # MI355X dense fp16/bf16 (MI355X_MICROARCH.md)
 PUBLISHED_BEST_ITS = 3.07                # best published SD2.1-base it/s (iPad Pro M2, Core ML)
 MODEL = "stabilityai/stable-diffusion-2-1-base"
-HBM_TRAFFIC_FILE = "r05_final_hbm_traffic.json"   # written by `tools/gpu_session.sh <tag> pmc` on the final library of the round
+HBM_TRAFFIC_FILE = "r06_final_hbm_traffic.json"   # written by `tools/gpu_session.sh <tag> pmc` on the final library of the round
 # --model: the UNets of BASELINE.json's configs (random-init weights of the real architectures).  The default
 # invocation stays BASELINE config 2 (sd21-base at 64x64 latents); the others are reported lines, never `vs_baseline`.
 MODELS = {
@@ -404,7 +404,7 @@ def build_id():
 
 def hbm_traffic(step_ms, args, lat_hw):
     """HBM bytes per step from committed rocprofv3 PMC passes (bench.py cannot run under the profiler itself):
-    profiles/r05_final_hbm_traffic.json is written by tools/pmc_reduce.py from separate --pmc FETCH_SIZE / WRITE_SIZE
+    profiles/r06_final_hbm_traffic.json is written by tools/pmc_reduce.py from separate --pmc FETCH_SIZE / WRITE_SIZE
     runs of the same step, corrected as MI355X_MICROARCH.md prescribes, and stamped with the hash of the library it
     profiled and the workload.  The number is only emitted when both match this run; otherwise `traffic` is null."""
     path = os.path.join(ROOT, "profiles", HBM_TRAFFIC_FILE)
