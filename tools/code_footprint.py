@@ -16,7 +16,8 @@ CSRC = os.path.join(ROOT, "ml-stable-diffusion_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
 READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
 EXTRA = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
-         "attention8.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans", "-fno-slp-vectorize"]}
+         "attention8.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans", "-fno-slp-vectorize"],
+         "wsgemm.hip": ["-fno-slp-vectorize"], "bvgemm.hip": ["-fno-slp-vectorize"]}
 timeline = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r05_final_step_timeline_original.txt")
 
 sizes = {}
@@ -32,7 +33,9 @@ with tempfile.TemporaryDirectory() as tmp:
             if len(f) >= 8 and f[3] == "FUNC" and f[2].isdigit() and int(f[2]) > 0:
                 rows.append((f[7], int(f[2])))
         dem = subprocess.run(["c++filt"], input="\n".join(r[0] for r in rows), capture_output=True, text=True).stdout.splitlines()
-        for (_, size), name in zip(rows, dem):
+        for (mangled, size), name in zip(rows, dem):
+            if "groupnorm_fused_kernel" in mangled and "Lb1EEEv" in mangled:
+                continue   # <.., RES = true>: round 5's register-resident form, launched only under SD_TUNE=1 SD_GN_RESIDENT=1
             m = re.match(r"_ZN2sd12_GLOBAL__N_1(\d+)", name)   # c++filt gives up on _Float16 parameters: the plain name from the mangling
             if m:
                 name = name[m.end():m.end() + int(m.group(1))]
@@ -56,7 +59,8 @@ missing, table = [], []
 for name, calls, busy, avg in step:
     size = sizes.get(name)
     if size is None:   # the timeline drops the template arguments of some kernels: the largest instantiation of that name
-        cands = [v for k, v in sizes.items() if k.split("<")[0] == name]
+        # (groupnorm_fused_kernel<.., true> is the register-resident A/B variant, launched only under SD_TUNE=1 SD_GN_RESIDENT=1)
+        cands = [v for k, v in sizes.items() if k.split("<")[0] == name and not (name == "groupnorm_fused_kernel" and k.endswith("true>"))]
         size = max(cands) if cands else None
     if size is None:
         missing.append(name)
