@@ -331,6 +331,12 @@ int sd_op_geglu(const void* x, const void* w, const float* bias, void* out, int 
  * 2 = the weight-stationary kernel (wsgemm.hip: C = 320, N2 % 256 == 0, M >= 2048; other shapes -> SD_ERR_INVALID_ARGUMENT). */
 int sd_op_geglu_ln(const void* x, const float* ln_weight, const float* ln_bias, const void* w, const float* bias, void* out, int M, int C,
                    int N2, float eps, int kernel, int iters, float* ms);
+/* Fused q|k|v projection of self-attention with norm1 folded in (unet.py:583-586 -> :74-84 as ONE GEMM): x (B * HW, C) f16,
+ * ln_weight / ln_bias (C) f32, w (3C, C) f16 = [Wq | Wk | Wv] -> out_qk (B * HW, 2C) f16 with the queries multiplied by q_scale
+ * before the rounding, out_vt (B, C, HW) f16 = V^T (vt_perm != 0: the two middle 4-token blocks of every 16 tokens swapped, the key
+ * order of the d = 64 attention kernel).  kernel: 0 = the library's plan, 1 = the tiled kernels, 3 = bvgemm.hip, 4 + v = its variant v + 1. */
+int sd_op_qkv_ln(const void* x, const float* ln_weight, const float* ln_bias, const void* w, void* out_qk, void* out_vt, int B, int HW, int C,
+                 float eps, float q_scale, int vt_perm, int kernel, int iters, float* ms);
 /* unet.py:703-728 */
 int sd_op_timestep_embedding(const float* t, float* out, int n, int dim, int flip_sin_to_cos, float freq_shift);
 /* numpy legacy stream: np.random.seed(seed); np.random.randn(n) (pipeline.py:331,:726;

@@ -36,6 +36,12 @@ struct BvArgs {
   int M, N, K, nk, ldo;
   int mtiles, ntiles;
   float ln_eps;
+  // fused q|k|v (unet.py:74-84 to_q / to_k / to_v as ONE GEMM): column tiles at or beyond n_trans leave token-transposed to
+  // out_t [B][N - n_trans][ldT] (attention's V^T, optionally in attention8's key order), the others to out with row length ldo =
+  // n_trans; columns below q_cols are multiplied by q_scale on the fp32 accumulator (ConvDesc::q_scale).  out_t == null: off.
+  half_t* out_t;
+  int n_trans, ldT, HoWo, vt_perm, q_cols;
+  float q_scale;
 };
 
 __device__ __forceinline__ float bv_gelu_erf(float x) {   // igemm.hip gelu_erf (Abramowitz-Stegun 7.1.26)
@@ -81,7 +87,10 @@ struct BvLds {
   static constexpr int OROW = OCOLS + 8;                      // staged row stride in halves
   static constexpr int SLOT = BM * BV_BK * 2;                 // one activation stage
   static constexpr int STAGE = BM * OROW * 2;                 // the epilogue's tile (re-uses the ring)
-  static constexpr int MAIN = (2 * SLOT > STAGE) ? 2 * SLOT : STAGE;
+  static constexpr int TROW = BM + 8;                         // transposed staging (V^T tiles of the fused q|k|v): [OCOLS][TROW]
+  static constexpr int TSTAGE = GEGLU ? 0 : OCOLS * TROW * 2;
+  static constexpr int STG = STAGE > TSTAGE ? STAGE : TSTAGE;
+  static constexpr int MAIN = (2 * SLOT > STG) ? 2 * SLOT : STG;
   static constexpr int STAT_OFF = MAIN;                       // [BM][2] floats
   static constexpr int BYTES = STAT_OFF + BM * 2 * 4;
 };
@@ -90,7 +99,7 @@ struct BvLds {
 // fragments, half the LDS traffic per MFMA, twice the accumulators); PB: weight stages in the register ring (requests run PB - 1
 // stages ahead).  Occupancy: 8 waves per CU in every configuration (one workgroup of 8, or two of 4).
 template <int BM, int NW, int TN, int PB, bool GEGLU, bool LNF>
-__global__ __launch_bounds__(NW * 64, (BM == 64 && TN == 1) ? 4 : 2) void bvgemm_kernel(BvArgs a) {
+__global__ __launch_bounds__(NW * 64, (BM == 64 && TN == 1) ? 4 : (BM == 32 ? 1 : 2)) void bvgemm_kernel(BvArgs a) {
   using L = BvLds<BM, NW, TN, GEGLU>;
   constexpr int NT = NW * 64;
   constexpr int TM = BM / 32;                                  // accumulator row blocks per wave
@@ -126,7 +135,7 @@ __global__ __launch_bounds__(NW * 64, (BM == 64 && TN == 1) ? 4 : 2) void bvgemm
   const half_t* wsrc = a.wt + ((size_t)strip0 * ks16 * 64 + lane) * 8;
   const size_t wstrip = (size_t)ks16 * 512;                    // halves between two strips
 
-  constexpr int AD = TN >= 2 ? 1 : 2;   // activation register sets: 2 = requested two stages ahead; 1 (the 256-VGPR wave tile): one
+  constexpr int AD = (TN >= 2 || CPT >= 8) ? 1 : 2;   // activation register sets: 2 = requested two stages ahead; 1 (the 256-VGPR wave tile, 8-chunk loaders): one
   half8 areg[AD][CPT], breg[PB][NBF];
   float ls1[CPT], ls2[CPT];
 #pragma unroll
@@ -256,6 +265,7 @@ __global__ __launch_bounds__(NW * 64, (BM == 64 && TN == 1) ? 4 : 2) void bvgemm
 
   // ---- epilogue: per column block the constants of the lane's 16 accumulator rows, tile -> LDS, whole rows -> global ----
   half_t* sg = reinterpret_cast<half_t*>(smem);
+  const bool tblock = !GEGLU && a.out_t != nullptr && nt * L::OCOLS >= a.n_trans;   // block-uniform: a V^T tile of the fused q|k|v
   if constexpr (LNF) __syncthreads();                          // statistics visible (the ring is free since the last stage's barrier)
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -291,16 +301,24 @@ __global__ __launch_bounds__(NW * 64, (BM == 64 && TN == 1) ? 4 : 2) void bvgemm
         }
         *reinterpret_cast<half8*>(sg + row * L::OROW + (wave * TN + j) * 16 + hi * 8) = o;
       } else {
+        const bool qcol = (strip0 + j) * 32 < a.q_cols;          // wave-uniform: a query strip of the fused q|k|v
         half8 o[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float v;
           if constexpr (LNF) v = fmaf(acc[i][j][r], la, fmaf(lb, cs[r], cb[r]));
           else v = acc[i][j][r] + cb[r];
+          if (qcol) v *= a.q_scale;
           o[r >> 3][r & 7] = (half_t)v;
         }
-        *reinterpret_cast<half8*>(sg + row * L::OROW + (wave * TN + j) * 32 + hi * 16) = o[0];
-        *reinterpret_cast<half8*>(sg + row * L::OROW + (wave * TN + j) * 32 + hi * 16 + 8) = o[1];
+        if (tblock) {   // V^T tile: staged [column][token] so that the write-out rows are token-contiguous
+          half_t* tg = sg + ((wave * TN + j) * 32 + hi * 16) * L::TROW + row;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tg[r * L::TROW] = o[r >> 3][r & 7];
+        } else {
+          *reinterpret_cast<half8*>(sg + row * L::OROW + (wave * TN + j) * 32 + hi * 16) = o[0];
+          *reinterpret_cast<half8*>(sg + row * L::OROW + (wave * TN + j) * 32 + hi * 16 + 8) = o[1];
+        }
       }
     }
   }
@@ -309,6 +327,27 @@ __global__ __launch_bounds__(NW * 64, (BM == 64 && TN == 1) ? 4 : 2) void bvgemm
   constexpr int ROUNDS = BM * CPR / NT;
   static_assert(BM * CPR % NT == 0, "whole store rounds");
   const size_t col0 = (size_t)nt * L::OCOLS;
+  if constexpr (!GEGLU) {
+    if (tblock) {   // out_t[b][n - n_trans][s]: 8 tokens of one image per 16-byte store (the row tile lies inside one image)
+      const int NV = a.N - a.n_trans, nv0 = (int)col0 - a.n_trans;
+      const int b = m0 / a.HoWo, sp0 = m0 - b * a.HoWo;
+      for (int id = tid; id < L::OCOLS * (BM / 8); id += NT) {
+        const int r = id / (BM / 8), c = id - r * (BM / 8);
+        if (m0 + c * 8 < a.M) {
+          half8 v;
+          if (a.vt_perm) {   // chunk c = tokens 16 j + 4 o + {0..3} and 16 j + 8 + 4 o + {0..3}  (j = c >> 1, o = c & 1): AttnDesc::vt_perm
+            const half_t* src = sg + r * L::TROW + (c >> 1) * 16 + (c & 1) * 4;
+            const half4 lo = *reinterpret_cast<const half4*>(src), up = *reinterpret_cast<const half4*>(src + 8);
+            v = half8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+          } else {
+            v = *reinterpret_cast<const half8*>(sg + r * L::TROW + c * 8);
+          }
+          *reinterpret_cast<half8*>(a.out_t + ((size_t)b * NV + nv0 + r) * a.ldT + sp0 + c * 8) = v;
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll 4
   for (int it = 0; it < ROUNDS; ++it) {
     const int id = tid + it * NT;
@@ -341,10 +380,15 @@ void launch_bv(const BvArgs& a, hipStream_t s) {
 // no timestep embedding, no fused q|k|v, no GroupNorm statistics of the output, no split-K.
 bool bvgemm_shape_ok(const ConvDesc& d) {
   if (d.ksize != 1 || d.stride != 1 || d.up != 1 || d.x1 || d.C0 % 64 != 0 || d.C0 < 256) return false;
-  if (d.temb || d.out_t || d.gn_partial || d.gnf_partial || d.n_twins || d.debug) return false;
+  if (d.temb || d.gn_partial || d.gnf_partial || d.n_twins || d.debug) return false;
   if (!(d.out_mode == kOutHalf || d.out_mode == kOutGeglu)) return false;
   if (d.out_mode == kOutGeglu && d.res) return false;
-  if (d.N % 128 != 0) return false;
+  if (d.out_t) {   // fused q|k|v: whole 128-column tiles on either side of the boundary, row tiles inside one image
+    if (d.out_mode != kOutHalf || d.res || d.n_trans <= 0 || d.n_trans % 128 != 0 || d.N % 128 != 0 || (d.Ho * d.Wo) % 128 != 0 ||
+        d.ldT % 8 != 0 || d.q_cols % 32 != 0)
+      return false;
+  }
+  if (d.N % 64 != 0) return false;
   return (long)d.B * d.Ho * d.Wo >= 128;
 }
 
@@ -358,11 +402,13 @@ void launch_bvgemm_retile(const half_t* w, half_t* wt, int N, int K, bool geglu,
 }
 
 // variant: 1: 64 rows x 8 waves x 32 columns; 2: 128 rows x 8 waves x 32 columns; 3: 128 rows x 4 waves x 64 columns (two
-// workgroups per CU); 4: 128 rows x 4 waves x 32 columns (128-column tiles: the only form for N % 256 != 0); 0 = chosen here from
-// the stand-alone table profiles/r06_bvgemm_bench.txt
+// workgroups per CU); 4: 128 rows x 4 waves x 32 columns (128-column tiles: N % 256 != 0); 5: 32 rows x 2 waves x 32 columns (many
+// small workgroups: the small-M experiment - ties the tiled kernels warm, loses cold); 6: 128 rows x 2 waves x 32 columns (64-column
+// tiles for N = 320 / 960 at large M); 0 = chosen here from the stand-alone table profiles/r06_bvgemm_bench.txt
 int bvgemm_auto_variant(const ConvDesc& d) {
   const long M = (long)d.B * d.Ho * d.Wo;
-  if (d.N % 256 != 0) return 4;
+  if (d.N % 128 != 0) return M >= 4096 ? 6 : 5;
+  if (d.N % 256 != 0 || (d.out_t && d.n_trans % 256 != 0)) return 4;
   if (d.out_mode == kOutGeglu) return (d.C0 >= 1280 || M < 16384) ? 2 : 3;
   if (M >= 16384) return 3;
   return 1;
@@ -370,8 +416,10 @@ int bvgemm_auto_variant(const ConvDesc& d) {
 
 void launch_bvgemm(const ConvDesc& d, int variant, hipStream_t s) {
   SD_REQUIRE(bvgemm_shape_ok(d) && d.w_bv, kInvalidArgument, "bvgemm: shape not eligible (C0=%d N=%d mode=%d)", d.C0, d.N, d.out_mode);
-  if (variant < 1 || variant > 4) variant = bvgemm_auto_variant(d);
-  SD_REQUIRE(variant == 4 || d.N % 256 == 0, kInvalidArgument, "bvgemm variant %d needs N %% 256 == 0 (N=%d)", variant, d.N);
+  if (variant < 1 || variant > 6) variant = bvgemm_auto_variant(d);
+  SD_REQUIRE(variant >= 5 || (variant == 4 && d.N % 128 == 0) || d.N % 256 == 0, kInvalidArgument, "bvgemm variant %d does not tile N=%d", variant, d.N);
+  SD_REQUIRE(!d.out_t || (variant <= 4 && d.n_trans % (variant == 4 ? 128 : 256) == 0), kInvalidArgument,
+             "bvgemm variant %d: the q|k / v boundary %d is not a tile boundary", variant, d.n_trans);
   BvArgs a{};
   a.x = d.x0;
   a.wt = d.w_bv;
@@ -384,10 +432,17 @@ void launch_bvgemm(const ConvDesc& d, int variant, hipStream_t s) {
   a.K = d.C0;
   a.nk = a.K / BV_BK;
   const bool geglu = d.out_mode == kOutGeglu;
-  a.ldo = geglu ? d.N / 2 : d.N;
-  a.ntiles = d.N / (variant == 4 ? 128 : 256);
+  a.ldo = geglu ? d.N / 2 : (d.out_t ? d.n_trans : d.N);
+  a.out_t = d.out_t;
+  a.n_trans = d.out_t ? d.n_trans : 0x7fffffff;
+  a.ldT = d.ldT;
+  a.HoWo = d.Ho * d.Wo;
+  a.vt_perm = d.out_t ? d.vt_perm : 0;
+  a.q_cols = d.out_t ? d.q_cols : 0;
+  a.q_scale = d.q_scale;
+  a.ntiles = d.N / (variant >= 5 ? 64 : (variant == 4 ? 128 : 256));
   a.ln_eps = d.ln_eps;
-  const int bm = variant == 1 ? 64 : 128;
+  const int bm = variant == 5 ? 32 : (variant == 1 ? 64 : 128);
   a.mtiles = cdiv(a.M, bm);
   const bool lnf = d.ln_colsum != nullptr;
 #define SD_BV(BM_, NW_, TN_, PB_)                                     \
@@ -403,7 +458,9 @@ void launch_bvgemm(const ConvDesc& d, int variant, hipStream_t s) {
   if (variant == 1) SD_BV(64, 8, 1, 4);
   else if (variant == 2) SD_BV(128, 8, 1, 4);
   else if (variant == 3) SD_BV(128, 4, 2, 2);
-  else SD_BV(128, 4, 1, 4);
+  else if (variant == 4) SD_BV(128, 4, 1, 4);
+  else if (variant == 5) SD_BV(32, 2, 1, 4);
+  else SD_BV(128, 2, 1, 2);
 #undef SD_BV
   SD_HIP(hipGetLastError());
 }
@@ -413,6 +470,10 @@ void launch_bvgemm(const ConvDesc& d, int variant, hipStream_t s) {
 bool bvgemm_wanted(const ConvDesc& d) {
   if (!bvgemm_shape_ok(d)) return false;
   const long M = (long)d.B * d.Ho * d.Wo;
+  static const bool narrow = tune_env_int("SD_BVGEMM_NARROW", 1) != 0;   // 64-column tiles (N = 320 / 960 ...): A/B
+  if (d.N % 128 != 0 && !narrow) return false;
+  static const bool qkv = tune_env_int("SD_BVGEMM_QKV", 1) != 0;         // the fused q|k|v epilogue: A/B
+  if (d.out_t && !qkv) return false;
   return M >= 4096 && d.C0 >= 640;
 }
 

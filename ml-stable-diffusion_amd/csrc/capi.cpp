@@ -467,7 +467,7 @@ int sd_op_conv2d(const void* x, const void* w, const float* bias, const void* re
     d.ksize = ksize; d.stride = stride; d.up = up; d.N = Cout;
     d.tile = tile % 10;          // tile / 10 selects the staging variant of the same tile (A/B testing)
     d.staging = tile / 10;
-    if (tile >= 110 && tile <= 114) {   // 110 / 111 / 112 / 113: plan tile 11 (bvgemm.hip) by grid size / variants 1-3 (launch_bvgemm)
+    if (tile >= 110 && tile <= 116) {   // 110 / 111 / 112 / 113: plan tile 11 (bvgemm.hip) by grid size / variants 1-3 (launch_bvgemm)
       d.tile = 11;
       d.staging = tile - 110;
     }
@@ -1091,7 +1091,7 @@ int sd_op_geglu_ln(const void* x, const float* ln_weight, const float* ln_bias, 
   return guarded([&] {
     const int abl = kernel / 10;   // kernel = 2 + 10 * n: ablation build n of the weight-stationary kernel (measurement tools only)
     kernel %= 10;
-    SD_REQUIRE(x && w && out && N2 % 64 == 0 && (ln_weight == nullptr) == (ln_bias == nullptr) && kernel >= 0 && kernel <= 7 &&
+    SD_REQUIRE(x && w && out && N2 % 64 == 0 && (ln_weight == nullptr) == (ln_bias == nullptr) && kernel >= 0 && kernel <= 9 &&
                    (abl == 0 || kernel == 2), kInvalidArgument, "bad GEGLU arguments");
     Scratch sc;
     const half_t* wh = reinterpret_cast<const half_t*>(w);
@@ -1153,6 +1153,69 @@ int sd_op_geglu_ln(const void* x, const float* ln_weight, const float* ln_bias, 
                 i + 1, t[i * 8 + 1] - t[i * 8], t[i * 8 + 2] - t[i * 8 + 1], t[i * 8 + 3] - t[i * 8 + 2], t[i * 8 + 4] - t[i * 8 + 3]);
     }
     SD_HIP(hipMemcpy(out, dout, (size_t)M * half_n * 2, hipMemcpyDeviceToHost));
+  });
+}
+
+// Fused q|k|v projection of self-attention with norm1 folded in (unet.py:583-586 norm1 -> :74-84 to_q / to_k / to_v as ONE GEMM, as the
+// UNet graph runs it): x (B * HW, C) f16 un-normalised tokens, ln_weight / ln_bias (C) f32, w (3C, C) f16 = [Wq | Wk | Wv] (no bias)
+// -> out_qk (B * HW, 2C) f16 (the queries multiplied by q_scale on the fp32 accumulator), out_vt (B, C, HW) f16 = V^T, with
+// vt_perm in attention8's key order (AttnDesc::vt_perm).  kernel: 0 = the library's plan, 1 = the tiled kernels, 3 = bvgemm.hip
+// (its own variant choice), 4 + v = bvgemm variant v + 1.
+int sd_op_qkv_ln(const void* x, const float* ln_weight, const float* ln_bias, const void* w, void* out_qk, void* out_vt, int B, int HW, int C,
+                 float eps, float q_scale, int vt_perm, int kernel, int iters, float* ms) {
+  return guarded([&] {
+    SD_REQUIRE(x && ln_weight && ln_bias && w && out_qk && out_vt && B >= 1 && HW >= 1 && C % 64 == 0 && kernel >= 0 && kernel <= 9 && kernel != 2,
+               kInvalidArgument, "bad q|k|v arguments");
+    Scratch sc;
+    const half_t* wh = reinterpret_cast<const half_t*>(w);
+    const int N = 3 * C, M = B * HW;
+    std::vector<half_t> wt((size_t)N * C);
+    std::vector<float> bt(N, 0.f), cst(N, 0.f);
+    for (int o = 0; o < N; ++o) {   // UNet::fold_layernorm
+      double cs = 0.0, bb = 0.0;
+      for (int c = 0; c < C; ++c) {
+        const float wv = (float)wh[(size_t)o * C + c];
+        const half_t h = (half_t)(wv * ln_weight[c]);
+        wt[(size_t)o * C + c] = h;
+        cs += (double)(float)h;
+        bb += (double)wv * (double)ln_bias[c];
+      }
+      bt[o] = (float)bb;
+      cst[o] = (float)cs;
+    }
+    ConvDesc d;
+    d.x0 = sc.dev<half_t>((size_t)M * C, reinterpret_cast<const half_t*>(x));
+    d.C0 = C;
+    d.w = sc.dev<half_t>(wt.size(), wt.data());
+    d.bias = sc.dev<float>(N, bt.data());
+    d.ln_colsum = sc.dev<float>(N, cst.data());
+    d.ln_eps = eps;
+    half_t* dqk = sc.dev<half_t>((size_t)M * 2 * C);
+    half_t* dvt = sc.dev<half_t>((size_t)B * C * HW);
+    d.out = dqk;
+    d.out_t = dvt;
+    d.n_trans = 2 * C;
+    d.ldT = HW;
+    d.vt_perm = vt_perm ? 1 : 0;
+    d.q_scale = q_scale;
+    d.q_cols = C;
+    d.B = B; d.Hi = 1; d.Wi = HW; d.Ho = 1; d.Wo = HW;
+    d.N = N;
+    SD_REQUIRE(conv_fast_path_ok(d), kUnsupported, "q|k|v shape off the MFMA path (C=%d)", C);
+    if (kernel >= 3 || (kernel == 0 && bvgemm_wanted(d))) {
+      SD_REQUIRE(bvgemm_shape_ok(d), kInvalidArgument, "q|k|v shape not eligible for plan tile 11 (bvgemm.hip)");
+      half_t* wtd = sc.dev<half_t>(bvgemm_tiled_halves(N, C));
+      launch_bvgemm_retile(d.w, wtd, N, C, false, sc.stream);
+      d.w_bv = wtd;
+      if (kernel >= 3) {
+        d.tile = 11;
+        d.staging = kernel - 3;
+      }
+    }
+    ConvWorkspace ws;
+    sc.timed(iters, ms, [&] { launch_conv(d, ws, sc.stream); });
+    SD_HIP(hipMemcpy(out_qk, dqk, (size_t)M * 2 * C * 2, hipMemcpyDeviceToHost));
+    SD_HIP(hipMemcpy(out_vt, dvt, (size_t)B * C * HW * 2, hipMemcpyDeviceToHost));
   });
 }
 

@@ -102,6 +102,7 @@ SYMBOLS = [
     ("sd_op_cross_attention_block", _I, [_P, _FP, _FP, _P, _P, _P, _P, _FP, _P, _P, _FP, _P, _I, _I, _I, _I, _F, _I, _I, _FP]),
     ("sd_op_geglu", _I, [_P, _P, _FP, _P, _I, _I, _I, _I, _FP]),
     ("sd_op_geglu_ln", _I, [_P, _FP, _FP, _P, _FP, _P, _I, _I, _I, C.c_float, _I, _I, _FP]),
+    ("sd_op_qkv_ln", _I, [_P, _FP, _FP, _P, _P, _P, _I, _I, _I, C.c_float, C.c_float, _I, _I, _I, _FP]),
     ("sd_op_timestep_embedding", _I, [_FP, _FP, _I, _I, _I, _F]),
     ("sd_numpy_randn", _I, [C.c_uint32, C.POINTER(C.c_double), C.c_size_t]),
     ("sd_torch_randn", _I, [C.c_uint32, C.POINTER(C.c_double), C.c_size_t]),
@@ -386,6 +387,20 @@ def geglu_ln(x, w, bias=None, ln_weight=None, ln_bias=None, eps=1e-5, kernel=0, 
     check(lib().sd_op_geglu_ln(ptr(x), fptr(ln_weight), fptr(ln_bias), ptr(w), fptr(bias), ptr(out), M, Cn, N2, eps, kernel, iters,
                                C.byref(ms)))
     return out, ms.value
+
+
+def qkv_ln(x, ln_weight, ln_bias, w, batch, q_scale=1.0, vt_perm=True, eps=1e-5, kernel=0, iters=1):
+    """Fused q|k|v projection with the LayerNorm in front of it folded in (unet.py:583-586 -> :74-84).  x (batch * HW, C), w (3C, C).
+    Returns (out_qk (batch * HW, 2C), out_vt (batch, C, HW), ms)."""
+    x, w = f16(x), f16(w)
+    M, Cn = x.shape
+    HW = M // batch
+    out_qk = np.empty((M, 2 * Cn), np.float16)
+    out_vt = np.empty((batch, Cn, HW), np.float16)
+    ms = C.c_float(0)
+    check(lib().sd_op_qkv_ln(ptr(x), fptr(f32(ln_weight)), fptr(f32(ln_bias)), ptr(w), ptr(out_qk), ptr(out_vt), batch, HW, Cn, eps, q_scale,
+                             int(vt_perm), kernel, iters, C.byref(ms)))
+    return out_qk, out_vt, ms.value
 
 
 def timestep_embedding(t, dim, flip_sin_to_cos=True, freq_shift=0.0):

@@ -128,7 +128,7 @@ BV_CASES = [  # (B, Cin, H, W, Cout)
 
 
 @pytest.mark.parametrize("case", BV_CASES, ids=lambda c: "x".join(map(str, c)))
-@pytest.mark.parametrize("tile", [110, 111, 112, 113, 114], ids=["auto", "64x8x32", "128x8x32", "128x4x64", "128x4x32"])
+@pytest.mark.parametrize("tile", [110, 111, 112, 113, 114, 115, 116], ids=["auto", "64x8x32", "128x8x32", "128x4x64", "128x4x32", "32x2x32", "128x2x32"])
 @pytest.mark.parametrize("with_res", [True, False], ids=["res", "nores"])
 def test_bvgemm_matches_torch(case, tile, with_res):
     b, cin, hh, ww, cout = case
@@ -144,7 +144,7 @@ def test_bvgemm_matches_torch(case, tile, with_res):
 
 
 @pytest.mark.parametrize("m,c,n2", [(512, 1280, 10240), (2048, 640, 5120), (8192, 320, 2560), (1000, 640, 512)], ids=lambda v: str(v))
-@pytest.mark.parametrize("kernel", [3, 4, 5, 6, 7], ids=["auto", "64x8x32", "128x8x32", "128x4x64", "128x4x32"])
+@pytest.mark.parametrize("kernel", [3, 4, 5, 6, 7, 8, 9], ids=["auto", "64x8x32", "128x8x32", "128x4x64", "128x4x32", "32x2x32", "128x2x32"])
 @pytest.mark.parametrize("ln", [True, False], ids=["ln-fold", "plain"])
 def test_bvgemm_geglu_matches_torch(m, c, n2, kernel, ln):
     rs = np.random.RandomState(m + c + kernel)
@@ -157,11 +157,13 @@ def test_bvgemm_geglu_matches_torch(m, c, n2, kernel, ln):
     close(out, geglu_ln_ref(x, w, bias, ln_w, ln_b), f"bvgemm geglu M={m} C={c} N2={n2} kernel={kernel} ln={ln}")
 
 
-@pytest.mark.parametrize("case", [(2, 640, 32, 32, 640), (2, 2560, 32, 32, 640), (1, 1280, 24, 24, 1920)], ids=lambda c: "x".join(map(str, c)))
-@pytest.mark.parametrize("tile", [110, 114], ids=["auto", "128x4x32"])
+@pytest.mark.parametrize("case", [(2, 640, 32, 32, 640), (2, 2560, 32, 32, 640), (1, 1280, 24, 24, 1920), (2, 1280, 64, 64, 320)], ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("tile", [110, 114, 116], ids=["auto", "128x4x32", "128x2x32"])
 def test_bvgemm_128_column_tiles(case, tile):
-    """N a multiple of 128 but not of 256 (the 640-channel level's to_out / ff.net.2): only the 128-column variant applies."""
+    """N a multiple of 128 (64) but not of 256 (the 640- / 320-channel levels' to_out / ff.net.2): only the narrow variants apply."""
     b, cin, hh, ww, cout = case
+    if tile == 114 and cout % 128 != 0:
+        pytest.skip("128-column tiles need N % 128 == 0")
     rs = np.random.RandomState(sum(case))
     x = h16(rs.randn(b, cin, hh, ww))
     w = h16(rs.randn(cout, cin, 1, 1) / np.sqrt(cin))
@@ -171,3 +173,39 @@ def test_bvgemm_128_column_tiles(case, tile):
     close(out, conv1x1_ref(x, w, bias, res), f"bvgemm {case} tile {tile}")
     with pytest.raises(ValueError):
         _lib.conv2d(x, w, bias, res, tile=113)   # 256-column variants refuse it
+
+
+# ---- fused q|k|v epilogue of bvgemm.hip (LayerNorm fold, pre-scaled queries, V^T in attention8's key order) --------------------
+def qkv_ref(x, ln_w, ln_b, w, batch, q_scale, vt_perm, eps=1e-5):
+    xt = F.layer_norm(torch.from_numpy(x.astype(np.float32)), (x.shape[1],), torch.from_numpy(ln_w), torch.from_numpy(ln_b), eps)
+    y = (xt @ torch.from_numpy(w.astype(np.float32)).T).numpy()
+    c = x.shape[1]
+    qk = np.concatenate([y[:, :c] * q_scale, y[:, c:2 * c]], axis=1)
+    hw = x.shape[0] // batch
+    vt = y[:, 2 * c:].reshape(batch, hw, c).transpose(0, 2, 1)                 # [B][C][HW]
+    if vt_perm:                                                                # position p of a row holds token t(p) (AttnDesc::vt_perm)
+        p = np.arange(hw)
+        c8, e = (p % 16) // 8, p % 8
+        t = (p // 16) * 16 + 4 * c8 + np.where(e < 4, e, 8 + (e - 4))
+        vt = vt[:, :, t]
+    return qk, vt
+
+
+@pytest.mark.parametrize("batch,hw,c", [(2, 1024, 640), (2, 256, 1280), (16, 256, 1280), (3, 128, 320), (4, 1024, 640)], ids=lambda v: str(v))
+@pytest.mark.parametrize("kernel", [1, 3, 5, 6, 7], ids=["tiled", "bv-auto", "bv-128x8x32", "bv-128x4x64", "bv-128x4x32"])
+@pytest.mark.parametrize("perm", [True, False], ids=["vt-perm", "vt-plain"])
+def test_qkv_ln_matches_torch(batch, hw, c, kernel, perm):
+    if c % 128 != 0 and kernel >= 3:   # N = 3C must be a multiple of 128 (C = 320: the tiled kernels keep that shape)
+        pytest.skip("bvgemm's q|k|v epilogue needs N % 128 == 0")
+    if (3 * c) % 256 != 0 and kernel in (5, 6):
+        pytest.skip("256-column tiles need N % 256 == 0")
+    rs = np.random.RandomState(batch + hw + c)
+    x = h16(rs.randn(batch * hw, c) * (1.0 + rs.rand(batch * hw, 1)))
+    w = h16(rs.randn(3 * c, c) / np.sqrt(c))
+    ln_w = (1.0 + 0.2 * rs.randn(c)).astype(np.float32)
+    ln_b = (0.1 * rs.randn(c)).astype(np.float32)
+    q_scale = 1.4426950408889634 / 8.0
+    qk, vt, _ = _lib.qkv_ln(x, ln_w, ln_b, w, batch, q_scale=q_scale, vt_perm=perm, kernel=kernel)
+    rqk, rvt = qkv_ref(x, ln_w, ln_b, w, batch, q_scale, perm)
+    close(qk, rqk, f"q|k kernel {kernel} B={batch} HW={hw} C={c}")
+    close(vt, rvt, f"V^T kernel {kernel} B={batch} HW={hw} C={c} perm={perm}")
