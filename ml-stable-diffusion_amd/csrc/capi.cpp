@@ -1128,7 +1128,7 @@ int sd_op_geglu_ln(const void* x, const float* ln_weight, const float* ln_bias, 
     SD_REQUIRE(conv_fast_path_ok(d), kUnsupported, "GEGLU shape off the MFMA path (C=%d N2=%d)", C, N2);
     if (kernel != 1 && kernel < 3 && wsgemm_shape_ok(d)) {
       half_t* wtd = sc.dev<half_t>(wsgemm_tiled_halves(N2));
-      launch_wsgemm_retile(d.w, wtd, N2, sc.stream);
+      launch_wsgemm_retile(d.w, wtd, N2, true, sc.stream);
       d.w_ws = wtd;
     }
     if (kernel == 2) d.tile = 10;
@@ -1164,7 +1164,7 @@ int sd_op_geglu_ln(const void* x, const float* ln_weight, const float* ln_bias, 
 int sd_op_qkv_ln(const void* x, const float* ln_weight, const float* ln_bias, const void* w, void* out_qk, void* out_vt, int B, int HW, int C,
                  float eps, float q_scale, int vt_perm, int kernel, int iters, float* ms) {
   return guarded([&] {
-    SD_REQUIRE(x && ln_weight && ln_bias && w && out_qk && out_vt && B >= 1 && HW >= 1 && C % 64 == 0 && kernel >= 0 && kernel <= 9 && kernel != 2,
+    SD_REQUIRE(x && ln_weight && ln_bias && w && out_qk && out_vt && B >= 1 && HW >= 1 && C % 64 == 0 && kernel >= 0 && kernel <= 9,
                kInvalidArgument, "bad q|k|v arguments");
     Scratch sc;
     const half_t* wh = reinterpret_cast<const half_t*>(w);
@@ -1202,7 +1202,13 @@ int sd_op_qkv_ln(const void* x, const float* ln_weight, const float* ln_bias, co
     d.B = B; d.Hi = 1; d.Wi = HW; d.Ho = 1; d.Wo = HW;
     d.N = N;
     SD_REQUIRE(conv_fast_path_ok(d), kUnsupported, "q|k|v shape off the MFMA path (C=%d)", C);
-    if (kernel >= 3 || (kernel == 0 && bvgemm_wanted(d))) {
+    if (kernel == 2 || (kernel == 0 && wsgemm_wanted(d))) {   // the weight-stationary kernel (wsgemm.hip, plan tile 10)
+      SD_REQUIRE(wsgemm_shape_ok(d), kInvalidArgument, "q|k|v shape not eligible for plan tile 10 (wsgemm.hip)");
+      half_t* wtd = sc.dev<half_t>(wsgemm_tiled_halves(N));
+      launch_wsgemm_retile(d.w, wtd, N, false, sc.stream);
+      d.w_ws = wtd;
+      if (kernel == 2) d.tile = 10;
+    } else if (kernel >= 3 || (kernel == 0 && bvgemm_wanted(d))) {
       SD_REQUIRE(bvgemm_shape_ok(d), kInvalidArgument, "q|k|v shape not eligible for plan tile 11 (bvgemm.hip)");
       half_t* wtd = sc.dev<half_t>(bvgemm_tiled_halves(N, C));
       launch_bvgemm_retile(d.w, wtd, N, C, false, sc.stream);

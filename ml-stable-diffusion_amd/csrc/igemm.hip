@@ -2812,7 +2812,7 @@ int launch_conv(const ConvDesc& d, const ConvWorkspace& ws, hipStream_t s) {
       // asked for (SD_WSGEMM=0 with SD_TUNE: the tiled kernels, A/B; a tuner candidate in force also keeps it off)
     static const bool wsg_on = tune_env_int("SD_WSGEMM", 1) != 0;
     const bool forced = d.tile == 10;
-    if (d.w_ws && wsgemm_shape_ok(d) && (forced || (wsg_on && d.tile == 0 && d.splitk == 0 && d.staging == 0 && g_tune.tile == 0))) {
+    if (d.w_ws && wsgemm_shape_ok(d) && (forced || (wsg_on && wsgemm_wanted(d) && d.tile == 0 && d.splitk == 0 && d.staging == 0 && g_tune.tile == 0))) {
       launch_wsgemm(d, s);
       return 0;
     }

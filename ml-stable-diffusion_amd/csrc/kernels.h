@@ -129,8 +129,9 @@ void launch_reduce_twin(const float* partial, int S, int M, int N, int HW, const
 
 // wsgemm.hip (round 6): weight-stationary GEGLU projection of the 320-channel level (plan tile 10)
 bool wsgemm_shape_ok(const ConvDesc& d);
+bool wsgemm_wanted(const ConvDesc& d);                               // the library's rule for taking plan tile 10 on its own
 size_t wsgemm_tiled_halves(int N);
-void launch_wsgemm_retile(const half_t* w, half_t* wt, int N, hipStream_t s);
+void launch_wsgemm_retile(const half_t* w, half_t* wt, int N, bool geglu, hipStream_t s);
 void launch_wsgemm(const ConvDesc& d, hipStream_t s);
 
 // bvgemm.hip (round 6): 1x1 GEMM with the weights global -> VGPR, activations alone in LDS (plan tile 11)

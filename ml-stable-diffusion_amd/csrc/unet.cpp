@@ -346,9 +346,9 @@ Tensor UNet::conv_w(std::vector<Op>& ops, const std::string& name, const half_t*
     }
     {   // widest-M GEGLU projection (K = 320): the weight-stationary kernel reads its own fragment-major copy (wsgemm.hip)
       static const bool wsg_on = tune_env_int("SD_WSGEMM", 1) != 0;
-      if (wsg_on && wsgemm_shape_ok(d)) {
+      if (wsg_on && wsgemm_wanted(d)) {
         half_t* wt = arena_.alloc_n<half_t>(wsgemm_tiled_halves(cout));
-        launch_wsgemm_retile(w, wt, cout, stream_);
+        launch_wsgemm_retile(w, wt, cout, geglu, stream_);
         d.w_ws = wt;
       }
     }

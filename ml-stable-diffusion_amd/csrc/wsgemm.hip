@@ -41,6 +41,12 @@ struct WsgArgs {
   int M, N, tiles;
   float ln_eps;
   long long* prof;        // ABL == 5: s_memtime stamps of workgroup (0, 0), wave 0: [iteration][phase]
+  // QKV mode (fused q|k|v, unet.py:74-84 as ONE GEMM): column groups at or beyond n_trans leave token-transposed to out_t
+  // [B][N - n_trans][ldT] (V^T, vt_perm: attention8's key order), the others to out with row length n_trans; columns below q_cols
+  // are multiplied by q_scale on the fp32 accumulator
+  half_t* out_t;
+  int n_trans, ldT, HoWo, vt_perm, q_cols;
+  float q_scale;
 };
 
 __device__ __forceinline__ float wsg_gelu_erf(float x) {   // igemm.hip gelu_erf (Abramowitz-Stegun 7.1.26)
@@ -73,35 +79,43 @@ __host__ __device__ inline int wsg_geglu_row(int strip, int n) {
   return (ch >> 5) * 64 + (grp & 1) * 32 + (ch & 31);        // device layout: 32 values | 32 gates per 64 rows (upload_conv_weight)
 }
 
-__global__ __launch_bounds__(256) void wsgemm_retile_kernel(const half_t* __restrict__ w, half_t* __restrict__ wt, int N) {
+// plain rows (QKV mode): a lane ends up with the 16 consecutive output channels 32 strip + 16 hi + r
+__host__ __device__ inline int wsg_row(int strip, int n, bool geglu) {
+  if (geglu) return wsg_geglu_row(strip, n);
+  return strip * 32 + 16 * ((n >> 2) & 1) + 4 * (n >> 3) + (n & 3);
+}
+
+__global__ __launch_bounds__(256) void wsgemm_retile_kernel(const half_t* __restrict__ w, half_t* __restrict__ wt, int N, int geglu) {
   const size_t total = (size_t)(N / 32) * WSG_KS * 64;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int lane = (int)(idx & 63);
     const size_t r = idx >> 6;
     const int ks = (int)(r % WSG_KS), strip = (int)(r / WSG_KS);
-    const int row = wsg_geglu_row(strip, lane & 31);
+    const int row = wsg_row(strip, lane & 31, geglu != 0);
     *reinterpret_cast<half8*>(wt + idx * 8) = *reinterpret_cast<const half8*>(w + (size_t)row * WSG_K + ks * 16 + (lane >> 5) * 8);
   }
 }
 
-template <int NW>
+template <int NW, bool QKV>
 struct WsgLds {
-  static constexpr int OCOLS = NW * 16;                        // output channels of the workgroup (GEGLU: half its weight rows)
+  static constexpr int OCOLS = NW * (QKV ? 32 : 16);           // output columns of the workgroup (GEGLU: half its weight rows)
   static constexpr int OROW = OCOLS + 8;                       // staged row stride in halves (+16 B: conflict-free 16-B writes)
-  static constexpr int STAGE_BYTES = WSG_BM * OROW * 2;
+  static constexpr int TROW = WSG_BM + 8;                      // transposed staging of a V^T tile: [OCOLS][TROW]
+  static constexpr int STAGE_BYTES = (QKV && OCOLS * TROW > WSG_BM * OROW ? OCOLS * TROW : WSG_BM * OROW) * 2;
   static constexpr int A_OFF = 0;                              // [2][tile]
-  static constexpr int ST_OFF = 2 * WSG_TILE_BYTES;            // [2][64][OROW] halves
+  static constexpr int ST_OFF = 2 * WSG_TILE_BYTES;            // [2] staged tiles
   static constexpr int STAT_OFF = ST_OFF + 2 * STAGE_BYTES;    // [2][64][2] floats: (rstd, -mean * rstd)
   static constexpr int CONST_OFF = STAT_OFF + 2 * WSG_BM * 2 * 4;   // [NW][bias | colsum][hi][16] floats: the epilogue constants of a wave
   static constexpr int BYTES = CONST_OFF + NW * 2 * 2 * 16 * 4;
 };
 
-// NW waves (NW * 32 weight rows = NW * 16 GEGLU outputs per workgroup); LNF: LayerNorm folded in (a.colsum).
+// NW waves (NW * 32 weight rows per workgroup: NW * 16 GEGLU outputs, or NW * 32 plain columns in QKV mode); LNF: LayerNorm folded
+// in (a.colsum).
 // ABL (ablation builds, tools/r6_wsgemm_bench.py; results are garbage when != 0): 1 no MFMAs, 2 no erf-GELU (value * gate),
 // 3 no LayerNorm statistics pass, 4 the activation tile is fetched once (no DMA in the loop), 5 timestamps, 6 no global stores
-template <int NW, bool LNF, int ABL = 0>
+template <int NW, bool LNF, int ABL = 0, bool QKV = false>
 __global__ __launch_bounds__(NW * 64) void wsgemm_geglu_kernel(WsgArgs a) {
-  using L = WsgLds<NW>;
+  using L = WsgLds<NW, QKV>;
   constexpr int NT = NW * 64;
   constexpr int PPW = (WSG_PIECES + NW - 1) / NW;              // DMA pieces per wave and tile (dead ones use a zero-sized resource)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -125,7 +139,7 @@ __global__ __launch_bounds__(NW * 64) void wsgemm_geglu_kernel(WsgArgs a) {
   float* const ctab = reinterpret_cast<float*>(smem + L::CONST_OFF) + wave * 64;
   if (lane < 32) {
     const int h = lane >> 4, r = lane & 15;
-    const int row = wsg_geglu_row(strip, (r & 3) + 8 * (r >> 2) + 4 * h);
+    const int row = wsg_row(strip, (r & 3) + 8 * (r >> 2) + 4 * h, !QKV);
     ctab[h * 16 + r] = a.bias ? a.bias[row] : 0.f;
     ctab[32 + h * 16 + r] = LNF ? a.colsum[row] : 0.f;
   }
@@ -217,8 +231,10 @@ __global__ __launch_bounds__(NW * 64) void wsgemm_geglu_kernel(WsgArgs a) {
     float la[2] = {1.f, 1.f}, lb[2] = {0.f, 0.f};
     half8 o[2];
     floatx4 kb_v, kb_g, ks_v, ks_g;
-    auto unit = [&](int u) {   // output element e = u & 7 of sub-tile i = u >> 3... ordered so that a constant quad serves 8 units
-      const int h4 = u >> 3, i = (u >> 2) & 1, q = u & 3;   // h4: channel quad (registers 0-3|4-7 or 8-11|12-15), i: sub-tile
+    const bool tblock = QKV && blockIdx.x * L::OCOLS >= a.n_trans;   // block-uniform: a V^T column group
+    const float qs = (QKV && strip * 32 < a.q_cols) ? a.q_scale : 1.f;   // wave-uniform: a query strip
+    auto unit = [&](int u) {   // GEGLU: one output (value register rv, gate register rg); QKV: the two plain values of those registers
+      const int h4 = u >> 3, i = (u >> 2) & 1, q = u & 3;   // h4: register octet (0-7 | 8-15), i: sub-tile
       const int rv = 8 * h4 + q, rg = rv + 4, e = 4 * h4 + q;
       float v, g;
       if constexpr (LNF) {
@@ -228,7 +244,25 @@ __global__ __launch_bounds__(NW * 64) void wsgemm_geglu_kernel(WsgArgs a) {
         v = accE[i][rv] + kb_v[q];
         g = accE[i][rg] + kb_g[q];
       }
-      o[i][e] = (half_t)(ABL == 2 ? v * g : v * wsg_gelu_erf(g));
+      if constexpr (QKV) {   // (the octet of registers 8 h4 .. 8 h4 + 7 = channels 8 h4 .. + 7 of the lane's 16; flushed per octet)
+        o[i][q] = (half_t)(v * qs);
+        o[i][4 + q] = (half_t)(g * qs);
+      } else {
+        o[i][e] = (half_t)(ABL == 2 ? v * g : v * wsg_gelu_erf(g));
+      }
+    };
+    auto flush_qkv = [&](int h4) {   // QKV mode: the finished octet of both sub-tiles -> staging (V^T groups: [column][token])
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = i * 32 + l31;
+        if (tblock) {
+          half_t* tg = sg + (wave * 32 + hi * 16 + 8 * h4) * L::TROW + row;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) tg[r * L::TROW] = o[i][r];
+        } else {
+          *reinterpret_cast<half8*>(sg + row * L::OROW + wave * 32 + hi * 16 + 8 * h4) = o[i];
+        }
+      }
     };
     auto consts = [&](int h4) {
       kb_v = *reinterpret_cast<const floatx4*>(ctab + hi * 16 + 8 * h4);
@@ -270,7 +304,10 @@ __global__ __launch_bounds__(NW * 64) void wsgemm_geglu_kernel(WsgArgs a) {
       }
       if constexpr (EP) {   // 16 units over K steps 2 .. 17 (the first reads and the last MFMAs keep their slots free)
         if (s >= 2 && s < 18) {
-          if (s == 10) consts(1);
+          if (s == 10) {
+            if constexpr (QKV) flush_qkv(0);
+            consts(1);
+          }
           unit(s - 2);
         }
       }
@@ -279,16 +316,41 @@ __global__ __launch_bounds__(NW * 64) void wsgemm_geglu_kernel(WsgArgs a) {
       __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (EP) {
+      if constexpr (QKV) {
+        flush_qkv(1);
+      } else {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) *reinterpret_cast<half8*>(sg + (i * 32 + l31) * L::OROW + wave * 16 + hi * 8) = o[i];
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<half8*>(sg + (i * 32 + l31) * L::OROW + wave * 16 + hi * 8) = o[i];
+      }
     }
   };
-  // staged tile t -> global, whole rows: OCOLS / 8 16-byte chunks per row
+  // staged tile t -> global, whole rows: OCOLS / 8 16-byte chunks per row (V^T groups: 8 tokens per chunk, OCOLS channel rows)
   auto store_tile = [&](int t) {
     const half_t* sg = reinterpret_cast<const half_t*>(smem + L::ST_OFF + (t & 1) * L::STAGE_BYTES);
     const int m0 = (worker + t * workers) * WSG_BM;
     constexpr int CPR = L::OCOLS / 8;
-    const int NO = a.N >> 1;
+    if constexpr (QKV) {
+      if (blockIdx.x * L::OCOLS >= a.n_trans) {   // out_t[b][n - n_trans][s]: the 64-token tile lies inside one image
+        const int NV = a.N - a.n_trans, nv0 = blockIdx.x * L::OCOLS - a.n_trans;
+        const int b = m0 / a.HoWo, sp0 = m0 - b * a.HoWo;
+#pragma unroll
+        for (int it = 0; it < (L::OCOLS * 8) / NT; ++it) {
+          const int id = tid + it * NT;
+          const int r = id >> 3, c = id & 7;
+          half8 v;
+          if (a.vt_perm) {   // chunk c = tokens 16 j + 4 o + {0..3} and 16 j + 8 + 4 o + {0..3}  (j = c >> 1, o = c & 1)
+            const half_t* src = sg + r * L::TROW + (c >> 1) * 16 + (c & 1) * 4;
+            const half4 lo = *reinterpret_cast<const half4*>(src), up = *reinterpret_cast<const half4*>(src + 8);
+            v = half8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+          } else {
+            v = *reinterpret_cast<const half8*>(sg + r * L::TROW + c * 8);
+          }
+          if (m0 + c * 8 < a.M) *reinterpret_cast<half8*>(a.out_t + ((size_t)b * NV + nv0 + r) * a.ldT + sp0 + c * 8) = v;
+        }
+        return;
+      }
+    }
+    const int NO = QKV ? a.n_trans : (a.N >> 1);
 #pragma unroll
     for (int it = 0; it < (WSG_BM * CPR) / NT; ++it) {
       const int id = tid + it * NT;
@@ -297,7 +359,7 @@ __global__ __launch_bounds__(NW * 64) void wsgemm_geglu_kernel(WsgArgs a) {
       if (m0 + r < a.M && ABL != 6) *reinterpret_cast<half8*>(a.out + (size_t)(m0 + r) * NO + (size_t)blockIdx.x * L::OCOLS + c * 8) = v;
     }
   };
-  static_assert((WSG_BM * (NW * 16 / 8)) % (NW * 64) == 0, "whole store rounds");
+  static_assert((WSG_BM * (L::OCOLS / 8)) % NT == 0 && (L::OCOLS * 8) % NT == 0, "whole store rounds");
   auto top = [&]() {   // my DMA pieces (and older stores) are done; then everybody's: the tile is readable, the other slot is free
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (lgkmcnt: the staging / statistics / table writes)
   };
@@ -359,10 +421,10 @@ __global__ __launch_bounds__(NW * 64) void wsgemm_geglu_kernel(WsgArgs a) {
   store_tile(T - 1);
 }
 
-template <int NW, bool LNF, int ABL = 0>
+template <int NW, bool LNF, int ABL = 0, bool QKV = false>
 void launch_wsg(const WsgArgs& a, int workers, hipStream_t s) {
-  auto k = wsgemm_geglu_kernel<NW, LNF, ABL>;
-  constexpr size_t lds = WsgLds<NW>::BYTES;
+  auto k = wsgemm_geglu_kernel<NW, LNF, ABL, QKV>;
+  constexpr size_t lds = WsgLds<NW, QKV>::BYTES;
   static DynLdsOnce once;
   once.set(k, lds);
   hipLaunchKernelGGL(k, dim3(a.N / (32 * NW), workers), dim3(NW * 64), lds, s, a);
@@ -370,21 +432,34 @@ void launch_wsg(const WsgArgs& a, int workers, hipStream_t s) {
 
 }  // namespace
 
-// GEGLU projection (kOutGeglu), single source, K = 320, N a multiple of 256 (eight waves per workgroup), no residual / timestep
-// embedding; the LayerNorm fold is optional.  Worth it once a workgroup walks several row tiles.
+// K = 320, single source, no residual / timestep embedding, a workgroup walking several row tiles: the GEGLU projection (kOutGeglu,
+// N a multiple of 256: eight waves per workgroup; LayerNorm fold optional) or the fused q|k|v projection (out_t set, LayerNorm fold,
+// N and the q|k / v boundary multiples of 160: five waves per workgroup, 64-token tiles inside one image).
 bool wsgemm_shape_ok(const ConvDesc& d) {
   if (d.ksize != 1 || d.stride != 1 || d.up != 1 || d.x1 || d.C0 != WSG_K) return false;
-  if (d.out_mode != kOutGeglu || d.res || d.temb || d.out_t || d.gn_partial || d.gnf_partial || d.n_twins) return false;
-  if (d.N % 256 != 0 || !d.bias) return false;
-  return (long)d.B * d.Ho * d.Wo >= 2048;
+  if (d.res || d.temb || d.gn_partial || d.gnf_partial || d.n_twins || !d.bias) return false;
+  if ((long)d.B * d.Ho * d.Wo < 2048) return false;
+  if (d.out_t)
+    return d.out_mode == kOutHalf && d.ln_colsum && !d.debug && d.N % 160 == 0 && d.n_trans > 0 && d.n_trans % 160 == 0 &&
+           (d.Ho * d.Wo) % WSG_BM == 0 && d.ldT % 8 == 0 && d.q_cols % 32 == 0;
+  return d.out_mode == kOutGeglu && d.N % 256 == 0;
+}
+
+// The library's own rule: the GEGLU projection always (stand-alone 31.5 -> 27.5 us at M = 8 192, 272 -> 157 at M = 65 536); the
+// fused q|k|v only on request (SD_WSGEMM_QKV=1 with SD_TUNE): five waves x 4 tiles per workgroup run 21.2 us where the tiled
+// kernel takes 17.0 at M = 8 192 and tie it at M = 65 536 (104 vs 107 us) - the per-tile issue latency of Finding 16 again.
+bool wsgemm_wanted(const ConvDesc& d) {
+  if (!wsgemm_shape_ok(d)) return false;
+  static const bool qkv = tune_env_int("SD_WSGEMM_QKV", 0) != 0;
+  return d.out_t == nullptr || qkv;
 }
 
 size_t wsgemm_tiled_halves(int N) { return (size_t)N * WSG_K; }
 
-void launch_wsgemm_retile(const half_t* w, half_t* wt, int N, hipStream_t s) {
+void launch_wsgemm_retile(const half_t* w, half_t* wt, int N, bool geglu, hipStream_t s) {
   SD_REQUIRE(N % 32 == 0, kInvalidArgument, "wsgemm retile: N=%d", N);
   const size_t total = (size_t)N * WSG_K / 8;
-  hipLaunchKernelGGL(wsgemm_retile_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 2048)), dim3(256), 0, s, w, wt, N);
+  hipLaunchKernelGGL(wsgemm_retile_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 2048)), dim3(256), 0, s, w, wt, N, geglu ? 1 : 0);
   SD_HIP(hipGetLastError());
 }
 
@@ -400,14 +475,24 @@ void launch_wsgemm(const ConvDesc& d, hipStream_t s) {
   a.N = d.N;
   a.tiles = cdiv(a.M, WSG_BM);
   a.ln_eps = d.ln_eps;
-  const int groups = a.N / 256;
-  // one workgroup per CU (105 KB of LDS): as many row workers per column group as the 256 CUs give, never more than the tiles
+  const bool qkv = d.out_t != nullptr;
+  a.out_t = d.out_t;
+  a.n_trans = qkv ? d.n_trans : 0x7fffffff;
+  a.ldT = d.ldT;
+  a.HoWo = d.Ho * d.Wo;
+  a.vt_perm = qkv ? d.vt_perm : 0;
+  a.q_cols = qkv ? d.q_cols : 0;
+  a.q_scale = d.q_scale;
+  const int groups = a.N / (qkv ? 160 : 256);
+  // one workgroup per CU (105-125 KB of LDS): as many row workers per column group as the 256 CUs give, never more than the tiles
   int workers = std::max(1, std::min(a.tiles, 256 / groups));
   // equal trip counts beat a ragged last round: the smallest worker count with the same number of rounds
   const int rounds = cdiv(a.tiles, workers);
   workers = cdiv(a.tiles, rounds);
   a.prof = d.prof;
-  if (d.debug) {   // ablation builds of the LayerNorm-folded form (measurement only)
+  if (qkv) {
+    launch_wsg<5, true, 0, true>(a, workers, s);
+  } else if (d.debug) {   // ablation builds of the LayerNorm-folded form (measurement only)
     SD_REQUIRE(d.ln_colsum && d.debug >= 1 && d.debug <= 6 && (d.debug != 5 || d.prof), kInvalidArgument, "wsgemm ablation %d", d.debug);
     switch (d.debug) {
       case 1: launch_wsg<8, true, 1>(a, workers, s); break;

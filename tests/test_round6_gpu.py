@@ -209,3 +209,28 @@ def test_qkv_ln_matches_torch(batch, hw, c, kernel, perm):
     rqk, rvt = qkv_ref(x, ln_w, ln_b, w, batch, q_scale, perm)
     close(qk, rqk, f"q|k kernel {kernel} B={batch} HW={hw} C={c}")
     close(vt, rvt, f"V^T kernel {kernel} B={batch} HW={hw} C={c} perm={perm}")
+
+
+@pytest.mark.parametrize("batch,hw", [(2, 4096), (1, 2112), (3, 1024), (16, 4096)], ids=lambda v: str(v))
+@pytest.mark.parametrize("perm", [True, False], ids=["vt-perm", "vt-plain"])
+def test_wsgemm_qkv_matches_torch_and_tiled(batch, hw, perm):
+    """The 320-channel level's fused q|k|v on the weight-stationary kernel (five waves per workgroup, six column groups: four q|k,
+    two V^T), against fp32 torch and against the tiled kernel.  Built, correct and NOT selected by the library: 21.2 vs 17.0 us at
+    M = 8 192 (tools/r6_qkv_bench.py), so the library's own plan for the shape stays the tiled kernel."""
+    c = 320
+    rs = np.random.RandomState(batch * 7 + hw)
+    x = h16(rs.randn(batch * hw, c) * (1.0 + rs.rand(batch * hw, 1)))
+    w = h16(rs.randn(3 * c, c) / np.sqrt(c))
+    ln_w = (1.0 + 0.2 * rs.randn(c)).astype(np.float32)
+    ln_b = (0.1 * rs.randn(c)).astype(np.float32)
+    q_scale = 1.4426950408889634 / 8.0
+    qk, vt, _ = _lib.qkv_ln(x, ln_w, ln_b, w, batch, q_scale=q_scale, vt_perm=perm, kernel=2)
+    rqk, rvt = qkv_ref(x, ln_w, ln_b, w, batch, q_scale, perm)
+    close(qk, rqk, f"wsgemm q|k B={batch} HW={hw}")
+    close(vt, rvt, f"wsgemm V^T B={batch} HW={hw} perm={perm}")
+    if batch <= 3:
+        tqk, tvt, _ = _lib.qkv_ln(x, ln_w, ln_b, w, batch, q_scale=q_scale, vt_perm=perm, kernel=1)
+        close(qk, tqk.astype(np.float32), "wsgemm vs tiled q|k", min_psnr=66.0)
+        close(vt, tvt.astype(np.float32), "wsgemm vs tiled V^T", min_psnr=66.0)
+        dqk, dvt, _ = _lib.qkv_ln(x, ln_w, ln_b, w, batch, q_scale=q_scale, vt_perm=perm, kernel=0)
+        assert np.array_equal(dqk, tqk) and np.array_equal(dvt, tvt), "the library's own plan for this shape stays the tiled kernel"
