@@ -99,7 +99,7 @@ struct BvLds {
 // fragments, half the LDS traffic per MFMA, twice the accumulators); PB: weight stages in the register ring (requests run PB - 1
 // stages ahead).  Occupancy: 8 waves per CU in every configuration (one workgroup of 8, or two of 4).
 template <int BM, int NW, int TN, int PB, bool GEGLU, bool LNF>
-__global__ __launch_bounds__(NW * 64, (BM == 64 && TN == 1) ? 4 : (BM == 32 ? 1 : 2)) void bvgemm_kernel(BvArgs a) {
+__global__ __launch_bounds__(NW * 64, (BM == 64 && TN == 1 && NW == 8) ? 4 : (BM == 32 ? 1 : 2)) void bvgemm_kernel(BvArgs a) {
   using L = BvLds<BM, NW, TN, GEGLU>;
   constexpr int NT = NW * 64;
   constexpr int TM = BM / 32;                                  // accumulator row blocks per wave
@@ -404,7 +404,8 @@ void launch_bvgemm_retile(const half_t* w, half_t* wt, int N, int K, bool geglu,
 // variant: 1: 64 rows x 8 waves x 32 columns; 2: 128 rows x 8 waves x 32 columns; 3: 128 rows x 4 waves x 64 columns (two
 // workgroups per CU); 4: 128 rows x 4 waves x 32 columns (128-column tiles: N % 256 != 0); 5: 32 rows x 2 waves x 32 columns (many
 // small workgroups: the small-M experiment - ties the tiled kernels warm, loses cold); 6: 128 rows x 2 waves x 32 columns (64-column
-// tiles for N = 320 / 960 at large M); 0 = chosen here from the stand-alone table profiles/r06_bvgemm_bench.txt
+// tiles for N = 320 / 960 at large M); 0 = chosen here (64 / 32 rows x 4 waves x 32 columns were also measured, on SDXL's 1 152-row
+// level with cold operands: 19.5 / 20.4 us against 19.1 tiled on 1280->1280, 51.1 / 53.6 against 45.8 on 5120->1280 - removed) from the stand-alone table profiles/r06_bvgemm_bench.txt
 int bvgemm_auto_variant(const ConvDesc& d) {
   const long M = (long)d.B * d.Ho * d.Wo;
   if (d.N % 128 != 0) return M >= 4096 ? 6 : 5;
@@ -417,8 +418,9 @@ int bvgemm_auto_variant(const ConvDesc& d) {
 void launch_bvgemm(const ConvDesc& d, int variant, hipStream_t s) {
   SD_REQUIRE(bvgemm_shape_ok(d) && d.w_bv, kInvalidArgument, "bvgemm: shape not eligible (C0=%d N=%d mode=%d)", d.C0, d.N, d.out_mode);
   if (variant < 1 || variant > 6) variant = bvgemm_auto_variant(d);
-  SD_REQUIRE(variant >= 5 || (variant == 4 && d.N % 128 == 0) || d.N % 256 == 0, kInvalidArgument, "bvgemm variant %d does not tile N=%d", variant, d.N);
-  SD_REQUIRE(!d.out_t || (variant <= 4 && d.n_trans % (variant == 4 ? 128 : 256) == 0), kInvalidArgument,
+  const int tcols = (variant == 5 || variant == 6) ? 64 : (variant == 4 ? 128 : 256);   // columns per workgroup
+  SD_REQUIRE(d.N % tcols == 0, kInvalidArgument, "bvgemm variant %d does not tile N=%d", variant, d.N);
+  SD_REQUIRE(!d.out_t || (tcols >= 128 && d.n_trans % tcols == 0), kInvalidArgument,
              "bvgemm variant %d: the q|k / v boundary %d is not a tile boundary", variant, d.n_trans);
   BvArgs a{};
   a.x = d.x0;
@@ -440,7 +442,7 @@ void launch_bvgemm(const ConvDesc& d, int variant, hipStream_t s) {
   a.vt_perm = d.out_t ? d.vt_perm : 0;
   a.q_cols = d.out_t ? d.q_cols : 0;
   a.q_scale = d.q_scale;
-  a.ntiles = d.N / (variant >= 5 ? 64 : (variant == 4 ? 128 : 256));
+  a.ntiles = d.N / tcols;
   a.ln_eps = d.ln_eps;
   const int bm = variant == 5 ? 32 : (variant == 1 ? 64 : 128);
   a.mtiles = cdiv(a.M, bm);
@@ -474,7 +476,8 @@ bool bvgemm_wanted(const ConvDesc& d) {
   if (d.N % 128 != 0 && !narrow) return false;
   static const bool qkv = tune_env_int("SD_BVGEMM_QKV", 1) != 0;         // the fused q|k|v epilogue: A/B
   if (d.out_t && !qkv) return false;
-  return M >= 4096 && d.C0 >= 640;
+  static const int min_m = tune_env_int("SD_BVGEMM_MIN_M", 4096), min_k = tune_env_int("SD_BVGEMM_MIN_K", 640);   // thresholds: A/B
+  return M >= min_m && d.C0 >= min_k;
 }
 
 }  // namespace sd
