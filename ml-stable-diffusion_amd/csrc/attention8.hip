@@ -374,7 +374,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn8_kernel(Attn8Args a) {
       if (q < a.Sq) {
         typedef unsigned uint4v __attribute__((ext_vector_type(4)));
         const uint4v o = {o4[0], o4[1], o4[2], o4[3]};
-        *reinterpret_cast<uint4v*>(orow + ct * 32 + 8 * g + 8 * hi) = o;
+        out_store(reinterpret_cast<uint4v*>(orow + ct * 32 + 8 * g + 8 * hi), o);
       }
     }
 }

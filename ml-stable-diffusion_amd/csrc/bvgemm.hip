@@ -342,7 +342,7 @@ __global__ __launch_bounds__(NW * 64, (BM == 64 && TN == 1 && NW == 8) ? 4 : (BM
           } else {
             v = *reinterpret_cast<const half8*>(sg + r * L::TROW + c * 8);
           }
-          *reinterpret_cast<half8*>(a.out_t + ((size_t)b * NV + nv0 + r) * a.ldT + sp0 + c * 8) = v;
+          out_store(reinterpret_cast<half8*>(a.out_t + ((size_t)b * NV + nv0 + r) * a.ldT + sp0 + c * 8), v);
         }
       }
       return;
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(NW * 64, (BM == 64 && TN == 1 && NW == 8) ? 4 : (BM
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
       }
-      *reinterpret_cast<half8*>(a.out + off) = v;
+      out_store(reinterpret_cast<half8*>(a.out + off), v);
     }
   }
 }

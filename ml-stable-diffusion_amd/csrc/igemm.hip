@@ -207,7 +207,7 @@ __device__ __forceinline__ void tile_epilogue(const IgemmArgs& a, floatx16 (&acc
           const int n = n_blk + (wn * TN + j) * 32 + 8 * q + 4 * hi;
           if (n < a.N) {
             floatx4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-            *reinterpret_cast<floatx4*>(prow + n) = v;
+            out_store(reinterpret_cast<floatx4*>(prow + n), v);
           }
         }
     }
@@ -313,7 +313,7 @@ __device__ __forceinline__ void tile_epilogue(const IgemmArgs& a, floatx16 (&acc
           } else {
             v = *reinterpret_cast<const half8*>(ot + r * TROW + c * 8);
           }
-          *reinterpret_cast<half8*>(a.out_t + ((size_t)b * NV + nv) * a.ldT + sp) = v;
+          out_store(reinterpret_cast<half8*>(a.out_t + ((size_t)b * NV + nv) * a.ldT + sp), v);
         }
       }
       return;
@@ -340,7 +340,7 @@ __device__ __forceinline__ void tile_epilogue(const IgemmArgs& a, floatx16 (&acc
               const half8 rr = resv[it];
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
-              *reinterpret_cast<half8*>(dst) = v;
+              out_store(reinterpret_cast<half8*>(dst), v);
               if (gn) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -370,7 +370,7 @@ __device__ __forceinline__ void tile_epilogue(const IgemmArgs& a, floatx16 (&acc
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
             }
-            *reinterpret_cast<half8*>(dst) = v;
+            out_store(reinterpret_cast<half8*>(dst), v);
             if (gn) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
@@ -1368,7 +1368,7 @@ __global__ __launch_bounds__(256, halo_lds_bytes(64, D) <= 80 * 1024 ? 2 : 1) vo
           const int n = n_blk + j * 32 + 8 * q + 4 * hi;
           if (n < a.N) {
             floatx4 v = {fin[j][4 * q], fin[j][4 * q + 1], fin[j][4 * q + 2], fin[j][4 * q + 3]};
-            *reinterpret_cast<floatx4*>(prow + n) = v;
+            out_store(reinterpret_cast<floatx4*>(prow + n), v);
           }
         }
     }
@@ -1404,7 +1404,7 @@ __global__ __launch_bounds__(256, halo_lds_bytes(64, D) <= 80 * 1024 ? 2 : 1) vo
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rr[e]);
         }
-        *reinterpret_cast<half8*>(dst) = v;
+        out_store(reinterpret_cast<half8*>(dst), v);
         if (gn) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -1844,7 +1844,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmArgs a) {
       s[3] += (float)rr[3];
     }
     half4 o = {(half_t)s[0], (half_t)s[1], (half_t)s[2], (half_t)s[3]};
-    *reinterpret_cast<half4*>(a.out + e0) = o;
+    out_store(reinterpret_cast<half4*>(a.out + e0), o);
   }
 }
 
@@ -1878,7 +1878,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(IgemmArgs a, i
         s[3] += (float)rr[3];
       }
       const half4 o = {(half_t)s[0], (half_t)s[1], (half_t)s[2], (half_t)s[3]};
-      *reinterpret_cast<half4*>(a.out + e0) = o;
+      out_store(reinterpret_cast<half4*>(a.out + e0), o);
       const float f0 = (float)o[0], f1 = (float)o[1], f2 = (float)o[2], f3 = (float)o[3];
       fs = (f0 + f1) + (f2 + f3);
       fq = fmaf(f0, f0, fmaf(f1, f1, fmaf(f2, f2, f3 * f3)));

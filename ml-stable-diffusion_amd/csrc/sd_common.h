@@ -21,6 +21,27 @@ typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+// Output stores of the step's kernels.  -DSD_SC1_STORES (experiment, round 6): write-through (sc1) instead of plain stores, so that
+// a kernel's results leave the XCD's L2 while it runs instead of at its end-of-kernel release (MI355X_MICROARCH.md "boundary":
+// + bytes / 6 TB/s when the predecessor leaves dirty lines).  16- and 8-byte forms; the s_nop keeps the data registers alive until
+// the store has read them (cdna guide 5.7).
+template <typename V>
+__device__ __forceinline__ void out_store(V* p, const V& v) {
+#if defined(SD_SC1_STORES) && defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (sizeof(V) == 16) {
+    typedef unsigned u4_ __attribute__((ext_vector_type(4)));
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(__builtin_bit_cast(u4_, v)) : "memory");
+  } else if constexpr (sizeof(V) == 8) {
+    typedef unsigned u2_ __attribute__((ext_vector_type(2)));
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(__builtin_bit_cast(u2_, v)) : "memory");
+  } else {
+    *p = v;
+  }
+#else
+  *p = v;
+#endif
+}
+
 // ---- errors: C++ exceptions inside, int status + thread-local string at the C ABI ------------
 enum Status : int {
   kOk = 0,

@@ -356,7 +356,7 @@ __global__ __launch_bounds__(NW * 64) void wsgemm_geglu_kernel(WsgArgs a) {
       const int id = tid + it * NT;
       const int r = id / CPR, c = id - r * CPR;
       const half8 v = *reinterpret_cast<const half8*>(sg + r * L::OROW + c * 8);
-      if (m0 + r < a.M && ABL != 6) *reinterpret_cast<half8*>(a.out + (size_t)(m0 + r) * NO + (size_t)blockIdx.x * L::OCOLS + c * 8) = v;
+      if (m0 + r < a.M && ABL != 6) out_store(reinterpret_cast<half8*>(a.out + (size_t)(m0 + r) * NO + (size_t)blockIdx.x * L::OCOLS + c * 8), v);
     }
   };
   static_assert((WSG_BM * (L::OCOLS / 8)) % NT == 0 && (L::OCOLS * 8) % NT == 0, "whole store rounds");

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(NW * 64) void wstream_kernel(WsArgs a) {
 #pragma unroll
     for (int w = 1; w < NW; ++w) s += reinterpret_cast<const floatx4*>(smem + w * WS_REGION)[id];
     const int m = zb * 128 + ml, n = strip * 32 + 4 * pc;
-    if (m < a.M) *reinterpret_cast<floatx4*>(a.partial + ((size_t)split * a.M + m) * a.N + n) = s;
+    if (m < a.M) out_store(reinterpret_cast<floatx4*>(a.partial + ((size_t)split * a.M + m) * a.N + n), s);
   }
 }
 

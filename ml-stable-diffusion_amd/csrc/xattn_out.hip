@@ -510,7 +510,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_proj_kernel(FPArgs a) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int idx = tid + NT * i, row = idx / (C / 8), c8 = idx - row * (C / 8);
-    *reinterpret_cast<half8*>(a.out + (size_t)(m_blk + row) * C + c8 * 8) = *reinterpret_cast<const half8*>(ot + row * ROW + c8 * 8);
+    out_store(reinterpret_cast<half8*>(a.out + (size_t)(m_blk + row) * C + c8 * 8), *reinterpret_cast<const half8*>(ot + row * ROW + c8 * 8));
   }
   if (a.gn_partial == nullptr) return;                     // (block-uniform)
   // GroupNorm statistics of the stored (fp16-rounded) values: thread = channel, fixed-order sums over the 32 tokens, then
