@@ -337,6 +337,16 @@ int sd_op_geglu_ln(const void* x, const float* ln_weight, const float* ln_bias, 
  * order of the d = 64 attention kernel).  kernel: 0 = the library's plan, 1 = the tiled kernels, 3 = bvgemm.hip, 4 + v = its variant v + 1. */
 int sd_op_qkv_ln(const void* x, const float* ln_weight, const float* ln_bias, const void* w, void* out_qk, void* out_vt, int B, int HW, int C,
                  float eps, float q_scale, int vt_perm, int kernel, int iters, float* ms);
+/* The head of a SpatialTransformer (unet.py:553-556 norm -> proj_in; :583-586 norm1 -> :74-84 fused to_q | to_k | to_v) behind a 1x1 conv
+ * x = conv_w . x_in that leaves the GroupNorm statistics of x in its epilogue, as the resnet conv in front of it does in the UNet.
+ * fused = 1: GroupNorm apply, proj_in, LayerNorm and the q|k|v projection in ONE launch; 0: the three launches it replaces.
+ * x_in (B, C, H, W) f16; conv_w / proj_w (C, C) f16; gn_*, proj_bias, ln_* (C) f32; wqkv (3C, C) f16 -> out_h (B * H * W, C) = proj_in's
+ * output, out_qk (B * H * W, 2C) with pre-scaled queries, out_vt (B, C, H * W) (vt_perm as sd_op_qkv_ln), all f16.  C = 320 only.
+ * *entries: the producer's statistics entries per (sample, group) folded by the fused launch (0: fall-back GroupNorm launch). */
+int sd_op_gn_proj_qkv(const void* x_in, const void* conv_w, const float* gn_weight, const float* gn_bias, const void* proj_w,
+                      const float* proj_bias, const float* ln_weight, const float* ln_bias, const void* wqkv, void* out_h, void* out_qk,
+                      void* out_vt, int B, int H, int W, int C, int groups, float gn_eps, float ln_eps, float q_scale, int vt_perm, int fused,
+                      int* entries, int iters, float* ms);
 /* unet.py:703-728 */
 int sd_op_timestep_embedding(const float* t, float* out, int n, int dim, int flip_sin_to_cos, float freq_shift);
 /* numpy legacy stream: np.random.seed(seed); np.random.randn(n) (pipeline.py:331,:726;

@@ -1225,6 +1225,112 @@ int sd_op_qkv_ln(const void* x, const float* ln_weight, const float* ln_bias, co
   });
 }
 
+// The head of a SpatialTransformer (unet.py:553-556 norm -> proj_in, :583-586 norm1 -> :74-84 fused to_q | to_k | to_v) behind a 1x1 conv
+// that produces its input x = conv(x_in) and - like the resnet conv in front of it in the UNet - leaves the GroupNorm statistics of x in
+// its epilogue.  fused = 1: ONE launch (xattn_out.hip gn_proj_qkv_kernel); 0: GroupNorm launch, proj_in GEMM, LayerNorm-folded q|k|v GEMM.
+// x_in (B, C, H, W) f16 NCHW; conv_w (C, C); gn_* (C) f32; proj_w (C, C), proj_bias (C); ln_* (C); wqkv (3C, C) -> out_h (B * HW, C),
+// out_qk (B * HW, 2C), out_vt (B, C, HW), all f16.  *entries = the producer's partial entries per (sample, group) the fused launch folded.
+int sd_op_gn_proj_qkv(const void* x_in, const void* conv_w, const float* gn_weight, const float* gn_bias, const void* proj_w,
+                      const float* proj_bias, const float* ln_weight, const float* ln_bias, const void* wqkv, void* out_h, void* out_qk,
+                      void* out_vt, int B, int H, int W, int C, int groups, float gn_eps, float ln_eps, float q_scale, int vt_perm, int fused,
+                      int* entries, int iters, float* ms) {
+  return guarded([&] {
+    SD_REQUIRE(x_in && conv_w && gn_weight && gn_bias && proj_w && proj_bias && ln_weight && ln_bias && wqkv && out_h && out_qk && out_vt,
+               kInvalidArgument, "NULL argument");
+    const int HW = H * W, M = B * HW, N = 3 * C;
+    SD_REQUIRE(gn_proj_qkv_ok(C, C / 64, HW, M, HW, groups), kInvalidArgument, "gn_proj_qkv: C=%d HW=%d groups=%d", C, HW, groups);
+    Scratch sc;
+    std::vector<half_t> xt = nchw_to_nhwc(reinterpret_cast<const half_t*>(x_in), B, C, H, W);
+    ConvDesc d;   // the producer
+    d.x0 = sc.dev<half_t>(xt.size(), xt.data());
+    d.C0 = C;
+    d.w = sc.dev<half_t>((size_t)C * C, reinterpret_cast<const half_t*>(conv_w));
+    half_t* dx = sc.dev<half_t>((size_t)M * C);
+    d.out = dx;
+    d.B = B; d.Hi = H; d.Wi = W; d.Ho = H; d.Wo = W;
+    d.N = C;
+    d.splitk = 1;
+    const size_t pf = groupnorm_scratch_floats(B, HW, groups);
+    float* partial = sc.dev<float>(pf);
+    {   // poison: the fold must only read what the producer wrote
+      std::vector<float> poison(pf, 1.0e30f);
+      SD_HIP(hipMemcpy(partial, poison.data(), pf * sizeof(float), hipMemcpyHostToDevice));
+    }
+    d.gn_partial = partial;
+    d.gn_groups = groups;
+    float* dgw = sc.dev<float>(C, gn_weight);
+    float* dgb = sc.dev<float>(C, gn_bias);
+    // LayerNorm fold of the fused q|k|v (UNet::fold_layernorm)
+    const half_t* wh = reinterpret_cast<const half_t*>(wqkv);
+    std::vector<half_t> wf((size_t)N * C);
+    std::vector<float> bt(N, 0.f), cst(N, 0.f);
+    for (int o = 0; o < N; ++o) {
+      double cs = 0.0, bb = 0.0;
+      for (int c = 0; c < C; ++c) {
+        const float wv = (float)wh[(size_t)o * C + c];
+        const half_t h = (half_t)(wv * ln_weight[c]);
+        wf[(size_t)o * C + c] = h;
+        cs += (double)(float)h;
+        bb += (double)wv * (double)ln_bias[c];
+      }
+      bt[o] = (float)bb;
+      cst[o] = (float)cs;
+    }
+    half_t* dwp = sc.dev<half_t>((size_t)C * C, reinterpret_cast<const half_t*>(proj_w));
+    float* dpb = sc.dev<float>(C, proj_bias);
+    half_t* dwq = sc.dev<half_t>(wf.size(), wf.data());
+    float* dqb = sc.dev<float>(N, bt.data());
+    float* dqc = sc.dev<float>(N, cst.data());
+    half_t* dnorm = sc.dev<half_t>((size_t)M * C);
+    half_t* dh = sc.dev<half_t>((size_t)M * C);
+    half_t* dqk = sc.dev<half_t>((size_t)M * 2 * C);
+    half_t* dvt = sc.dev<half_t>((size_t)B * C * HW);
+    half_t* dwp_t = sc.dev<half_t>((size_t)C * C);
+    half_t* dwq_t = sc.dev<half_t>((size_t)N * C);
+    launch_xattn_out_retile_nk(dwp, dwp_t, C, C, sc.stream);
+    launch_xattn_out_retile_nk(dwq, dwq_t, N, C, sc.stream);
+    ConvDesc pd;   // proj_in of the three-launch path
+    pd.x0 = dnorm; pd.C0 = C; pd.w = dwp; pd.bias = dpb; pd.out = dh;
+    pd.B = B; pd.Hi = H; pd.Wi = W; pd.Ho = H; pd.Wo = W; pd.N = C;
+    ConvDesc qd;   // fused q|k|v of the three-launch path
+    qd.x0 = dh; qd.C0 = C; qd.w = dwq; qd.bias = dqb; qd.ln_colsum = dqc; qd.ln_eps = ln_eps; qd.out = dqk; qd.out_t = dvt;
+    qd.n_trans = 2 * C; qd.ldT = HW; qd.vt_perm = vt_perm ? 1 : 0; qd.q_scale = q_scale; qd.q_cols = C;
+    qd.B = B; qd.Hi = H; qd.Wi = W; qd.Ho = H; qd.Wo = W; qd.N = N;
+    SD_REQUIRE(conv_fast_path_ok(d) && conv_fast_path_ok(pd) && conv_fast_path_ok(qd), kInvalidArgument, "gn_proj_qkv: off the MFMA path");
+    ConvWorkspace ws;
+    ws.partial_bytes = std::max(conv_workspace_bytes(d), std::max(conv_workspace_bytes(pd), conv_workspace_bytes(qd)));
+    if (ws.partial_bytes) ws.partial = reinterpret_cast<float*>(sc.dev<char>(ws.partial_bytes));
+    int n_entries = 0;
+    sc.timed(iters, ms, [&] {
+      n_entries = launch_conv(d, ws, sc.stream);
+      const bool have = n_entries >= 1 && n_entries <= 128;
+      if (fused) {
+        GnProjQkvDesc g;
+        g.x = dx;
+        if (have) {
+          g.gn_partial = partial; g.gn_gamma = dgw; g.gn_beta = dgb; g.gn_entries = n_entries;
+        } else {   // no producer statistics: the GroupNorm launch, then the fused launch on the normalised tensor
+          launch_groupnorm(dx, C, nullptr, 0, partial, dgw, dgb, dnorm, B, HW, groups, gn_eps, 0, sc.stream, n_entries);
+          g.x = dnorm;
+        }
+        g.gn_groups = groups; g.gn_eps = gn_eps;
+        g.wp_t = dwp_t; g.p_bias = dpb; g.h = dh;
+        g.wqkv_t = dwq_t; g.qkv_bias = dqb; g.qkv_colsum = dqc; g.ln_eps = ln_eps;
+        g.qk = dqk; g.vt = dvt; g.M = M; g.C = C; g.S = HW; g.ldT = HW; g.vt_perm = vt_perm != 0; g.q_scale = q_scale;
+        launch_gn_proj_qkv(g, sc.stream);
+      } else {
+        launch_groupnorm(dx, C, nullptr, 0, partial, dgw, dgb, dnorm, B, HW, groups, gn_eps, 0, sc.stream, n_entries);
+        launch_conv(pd, ws, sc.stream);
+        launch_conv(qd, ws, sc.stream);
+      }
+    });
+    if (entries) *entries = (fused && n_entries >= 1 && n_entries <= 128) ? n_entries : 0;
+    SD_HIP(hipMemcpy(out_h, dh, (size_t)M * C * 2, hipMemcpyDeviceToHost));
+    SD_HIP(hipMemcpy(out_qk, dqk, (size_t)M * 2 * C * 2, hipMemcpyDeviceToHost));
+    SD_HIP(hipMemcpy(out_vt, dvt, (size_t)B * C * HW * 2, hipMemcpyDeviceToHost));
+  });
+}
+
 int sd_op_timestep_embedding(const float* t, float* out, int n, int dim, int flip_sin_to_cos, float freq_shift) {
   return guarded([&] {
     SD_REQUIRE(t && out && n > 0 && dim > 0 && dim % 2 == 0, kInvalidArgument, "bad arguments");

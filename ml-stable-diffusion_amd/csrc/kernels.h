@@ -231,6 +231,33 @@ struct XAttnOutDesc {
   const half_t* wo1_t = nullptr;
   const float* o1_bias = nullptr;
 };
+// The head of a SpatialTransformer in one launch (xattn_out.hip gn_proj_qkv_kernel, round 6): GroupNorm apply (statistics from the
+// producer's partials: gn_partial [B][G][kGnMaxSlabs][2], gn_entries of them per (sample, group); 0 = x is normalised already) ->
+// proj_in + bias -> h (stored) -> LayerNorm-folded fused q|k|v (UNet::fold_layernorm: qkv_bias / qkv_colsum [3C]) -> qk [M][2C] with
+// the queries multiplied by q_scale, vt [B][C][ldT] (vt_perm: AttnDesc::vt_perm).  wp_t (C x C) / wqkv_t (3C x C) fragment-major
+// (launch_xattn_out_retile_nk).  C = 320 only.
+struct GnProjQkvDesc {
+  const half_t* x = nullptr;
+  const float* gn_partial = nullptr;
+  const float* gn_gamma = nullptr;
+  const float* gn_beta = nullptr;
+  int gn_entries = 0, gn_groups = 32;
+  float gn_eps = 1e-6f;
+  const half_t* wp_t = nullptr;
+  const float* p_bias = nullptr;
+  half_t* h = nullptr;
+  const half_t* wqkv_t = nullptr;
+  const float* qkv_bias = nullptr;
+  const float* qkv_colsum = nullptr;
+  float ln_eps = 1e-5f;
+  half_t* qk = nullptr;
+  half_t* vt = nullptr;
+  int M = 0, C = 0, S = 0, ldT = 0;
+  bool vt_perm = false;
+  float q_scale = 1.f;
+};
+bool gn_proj_qkv_ok(int C, int heads, int S, int M, int ldT, int G);
+void launch_gn_proj_qkv(const GnProjQkvDesc& d, hipStream_t s);
 bool xattn_out_ok(int C, int heads, int S, int L);
 void launch_xattn_out_retile(const half_t* w, half_t* wt, int C, hipStream_t s);   // [C][C] row-major -> fragment-major
 void launch_xattn_out(const XAttnOutDesc& d, hipStream_t s);

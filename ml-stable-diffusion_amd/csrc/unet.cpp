@@ -14,6 +14,10 @@
 //    time_emb_proj(SiLU(emb)) (unet.py:477) are one batched GEMV per step.
 #include "unet.h"
 
+#ifndef SD_GN_QKV_DEFAULT
+#define SD_GN_QKV_DEFAULT 1   // the one-launch head of a SpatialTransformer (UNet::transformer); 0 = the three launches it replaces
+#endif
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -686,7 +690,7 @@ Tensor UNet::attention(std::vector<Op>& ops, const Tensor& q, const half_t* k, c
 
 // unet.py:586-591 (+ CrossAttention :87-118, FeedForward/GEGLU :594-617)
 Tensor UNet::transformer_block(std::vector<Op>& ops, const std::string& b, const Tensor& h, int heads, const std::string* proj_out,
-                               const Tensor* tres, bool* tail_done) {
+                               const Tensor* tres, bool* tail_done, const PreQkv* pre) {
   const int C = h.C, S = h.H * h.W, L = cfg_.context_len;
   // --- self attention.  MFMA-tileable widths: norm1 is folded into ONE fused q|k|v GEMM whose V
   // columns leave token-transposed (attention's V^T operand); otherwise LN + stacked q|k + V^T GEMMs.
@@ -695,7 +699,12 @@ Tensor UNet::transformer_block(std::vector<Op>& ops, const std::string& b, const
   bool vt_perm = false;   // attention8.hip will run this self-attention: the fused q|k|v GEMM writes V^T in its key order
   bool q_pre = false;     // ... and the queries pre-scaled
   half_t* vtp;
-  if (can_fold_ln(h, 3 * C, false) && S % 8 == 0 && (2 * C) % 64 == 0) {
+  if (pre) {   // the SpatialTransformer's head launch (UNet::transformer) already wrote this block's q | k and V^T
+    qk = pre->qk;
+    vtp = pre->vt;
+    vt_perm = pre->vt_perm;
+    q_pre = pre->q_pre;
+  } else if (can_fold_ln(h, 3 * C, false) && S % 8 == 0 && (2 * C) % 64 == 0) {
     LnFold f = fold_layernorm(b + ".norm1", {b + ".attn1.to_q", b + ".attn1.to_k", b + ".attn1.to_v"}, C, C, false);
     ConvExtra ex;
     ex.ln_colsum = f.colsum;
@@ -896,8 +905,74 @@ Tensor UNet::transformer(std::vector<Op>& ops, const std::string& p, const Tenso
   d.N = C;
   const bool fold = fold_mode != 0 && !f32_ && x.gn && !x.gn->partial && x.gn->n_twins == 0 && x.gn->ops_list == &ops && C % G == 0 && G <= 32 &&
                     C <= 2048 && HW % 64 == 0 && conv_fast_path_ok(d) && (size_t)x.M() * C * 2 < ((size_t)1 << 31);
+  // norm -> proj_in -> norm1 -> to_q | to_k | to_v of block 0 as ONE launch at the 5-head level (xattn_out.hip gn_proj_qkv_kernel: rows are
+  // independent once the GroupNorm statistics exist, so a 32-token workgroup carries its rows through both GEMMs in LDS).
+  // Three launches of 10 + 9.5 + 15 us become one of 24.5; same box, back to back: 4.415 / 4.430 -> 4.344 / 4.368 ms, eight prompts
+  // 18.73 -> 18.45 ms (profiles/r06_gn_qkv_ab.txt).  SD_GN_QKV=0 (with SD_TUNE): the three launches.
+  static const int gq_mode = tune_env_int("SD_GN_QKV", SD_GN_QKV_DEFAULT);
+  const int ldv0 = round_up(HW, 8);
+  const bool gq = gq_mode != 0 && !fold && !f32_ && depth >= 1 && x.gn && !x.gn->partial && x.gn->n_twins == 0 && x.gn->ops_list == &ops &&
+                  C % G == 0 && gn_proj_qkv_ok(C, heads, HW, x.M(), ldv0, G) && (size_t)x.M() * C * 2 < ((size_t)1 << 31);
   Tensor h;
-  if (fold) {
+  PreQkv pre;
+  if (gq) {
+    const std::string b0 = p + ".transformer_blocks.0";
+    float* partial = arena_.alloc_n<float>(groupnorm_scratch_floats(x.B, HW, G));
+    std::shared_ptr<GnHook> hook = x.gn;
+    hook->partial = partial;
+    hook->groups = G;
+    Tensor t0 = new_tensor(x.B, x.H, x.W, C);   // the normalised tensor of the fall-back (producer left no statistics)
+    h = new_tensor(x.B, x.H, x.W, C);
+    const half_t* wp = upload_conv_weight(p + ".proj_in", C, C, 1, false);
+    half_t* wp_t = arena_.alloc_n<half_t>((size_t)C * C);
+    launch_xattn_out_retile_nk(wp, wp_t, C, C, stream_);
+    LnFold f = fold_layernorm(b0 + ".norm1", {b0 + ".attn1.to_q", b0 + ".attn1.to_k", b0 + ".attn1.to_v"}, C, C, false);
+    half_t* wq_t = arena_.alloc_n<half_t>((size_t)3 * C * C);
+    launch_xattn_out_retile_nk(f.w, wq_t, 3 * C, C, stream_);
+    pre.qk = new_tensor(x.B, x.H, x.W, 2 * C);
+    pre.vt = arena_.alloc_n<half_t>((size_t)x.B * C * ldv0);
+    pre.vt_perm = attention8_shape_ok(C / heads, HW, HW) && HW % 16 == 0;
+    pre.q_pre = pre.vt_perm;
+    GnProjQkvDesc g;
+    g.x = x.p;
+    g.gn_partial = partial;
+    g.gn_gamma = upload_vec(p + ".norm.weight", C);
+    g.gn_beta = upload_vec(p + ".norm.bias", C);
+    g.gn_groups = G;
+    g.gn_eps = 1e-6f;
+    g.wp_t = wp_t;
+    g.p_bias = upload_vec(p + ".proj_in.bias", C);
+    g.h = h.p;
+    g.wqkv_t = wq_t;
+    g.qkv_bias = f.bias;
+    g.qkv_colsum = f.colsum;
+    g.ln_eps = 1e-5f;
+    g.qk = pre.qk.p;
+    g.vt = pre.vt;
+    g.M = x.M();
+    g.C = C;
+    g.S = HW;
+    g.ldT = ldv0;
+    g.vt_perm = pre.vt_perm;
+    g.q_scale = pre.q_pre ? attention_q_prescale(C / heads) : 1.f;
+    const int B = x.B;
+    ops.push_back([g, hook, t0, B, HW, G, C](hipStream_t s) {
+      GnProjQkvDesc gg = g;
+      const int n = hook->consume();
+      if (n >= 1 && n <= 128) {
+        gg.gn_entries = n;
+      } else {
+        launch_groupnorm(g.x, C, nullptr, 0, const_cast<float*>(g.gn_partial), g.gn_gamma, g.gn_beta, t0.p, B, HW, G, g.gn_eps, 0, s, n);
+        gg.x = t0.p;
+        gg.gn_entries = 0;
+      }
+      launch_gn_proj_qkv(gg, s);
+    });
+    char buf[256];
+    snprintf(buf, sizeof(buf), "gemm1x1+gn %d->%d @%dx%d M=%d K=%d %s.proj_in + norm1 + to_qkv %d->%d", C, C, x.H, x.W, x.M(), C, p.c_str(), C, 3 * C);
+    ops.back().label = buf;
+    ops.back().flop = 8.0 * x.M() * (double)C * C;
+  } else if (fold) {
     float* partial = arena_.alloc_n<float>(groupnorm_scratch_floats(x.B, HW, G));
     const float* gamma = upload_vec(p + ".norm.weight", C);
     const float* beta = upload_vec(p + ".norm.bias", C);
@@ -943,7 +1018,7 @@ Tensor UNet::transformer(std::vector<Op>& ops, const std::string& p, const Tenso
   for (int d = 0; d < depth; ++d) {
     const bool last = d == depth - 1;
     h = transformer_block(ops, p + ".transformer_blocks." + std::to_string(d), h, heads, last ? &proj_name : nullptr, last ? &x : nullptr,
-                          last ? &tail_done : nullptr);
+                          last ? &tail_done : nullptr, (gq && d == 0) ? &pre : nullptr);
   }
   if (tail_done) return h;
   return conv(ops, p + ".proj_out", h, nullptr, x.C, 1, 1, 1, true, nullptr, x.p);

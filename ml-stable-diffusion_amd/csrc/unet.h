@@ -52,6 +52,14 @@ struct Tensor {
   size_t numel() const { return (size_t)B * H * W * C; }
 };
 
+// Self-attention operands of a transformer block written ahead of it (UNet::transformer's one-launch head, xattn_out.hip gn_proj_qkv_kernel)
+struct PreQkv {
+  Tensor qk;               // [M][2C]: q | k
+  half_t* vt = nullptr;    // [B][C][round_up(S, 8)]
+  bool vt_perm = false;    // V^T in attention8's key order
+  bool q_pre = false;      // queries carry d^-0.5 * log2(e)
+};
+
 // One entry of a handle's launch list: the launch closure plus what the per-op profile reports about it.
 struct Op {
   std::function<void(hipStream_t)> fn;
@@ -140,9 +148,9 @@ class UNet {
   Tensor transformer(std::vector<Op>& ops, const std::string& p, const Tensor& x, int heads, int depth);
   // proj_out / tres (last block of a SpatialTransformer only): the transformer's proj_out and its residual - where the tail
   // ff.net.2 + residual -> proj_out + residual runs as ONE launch (xattn_out.hip ffn_proj_kernel) *tail_done is set and the returned
-  // tensor is the transformer's output
+  // tensor is the transformer's output.  pre: the block's self-attention operands where the transformer's head launch already wrote them
   Tensor transformer_block(std::vector<Op>& ops, const std::string& b, const Tensor& h, int heads, const std::string* proj_out = nullptr,
-                           const Tensor* tres = nullptr, bool* tail_done = nullptr);
+                           const Tensor* tres = nullptr, bool* tail_done = nullptr, const PreQkv* pre = nullptr);
   Tensor vae_attention(std::vector<Op>& ops, const std::string& p, const Tensor& h);
   Tensor attention(std::vector<Op>& ops, const Tensor& q, const half_t* k, const half_t* vt, int heads, int Sq,
                    int Sk, int ldk, int ldv, int ldq, bool vt_perm = false, bool q_prescaled = false);

@@ -541,6 +541,223 @@ __global__ __launch_bounds__(NW * 64) void ffn_proj_kernel(FPArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The HEAD of a SpatialTransformer as ONE launch (round 6; unet.py:553-556 norm -> proj_in, then the first block's :583-586 norm1 ->
+// :74-84 to_q | to_k | to_v):
+//     xn      = GroupNorm(x)                         statistics from the producer's epilogue partials (GnHook), affine applied here
+//     h       = proj_in(xn) + b                      stored: it is the residual stream of the transformer block
+//     q|k|v   = [Wq | Wk | Wv] . LayerNorm(h)        LayerNorm folded (UNet::fold_layernorm), q pre-scaled, V^T in attention8's key order
+// Same workgroup shape as xattn_out_kernel (32 tokens x C / 64 waves, wave w = 64-channel output block w of all four GEMM passes,
+// weights global -> VGPR in fragment order); the GroupNorm'd tile and h live in LDS, every wave stages ITS 64-channel block of an
+// output in its own LDS region (no workgroup barrier: only that wave reads it) and writes whole 128-byte row pieces / 8-token V^T
+// chunks.  Three launches (GroupNorm apply, proj_in, fused q|k|v: 10 + 11.6 + 20.5 us in sequence) become one.  C = 320 only.
+// gn_entries == 0: x arrives normalised already (the fall-back when the producer left no statistics).
+// ---------------------------------------------------------------------------------------------
+struct GQArgs {
+  const half_t* x;
+  const float* gn_partial;
+  const float* gn_gamma;
+  const float* gn_beta;
+  const half8* wp_t;
+  const float* p_bias;
+  half_t* h;
+  const half8* wqkv_t;
+  const float* qkv_bias;
+  const float* qkv_colsum;
+  half_t* qk;
+  half_t* vt;
+  int M, S, ldT, vt_perm, gn_entries, gn_G;
+  float gn_eps, ln_eps, q_scale;
+};
+
+constexpr int GQ_WST = 5120;   // per-wave staging: [32 tokens][72] halves row-major (q / k) or [64 channels][40] halves transposed (V^T)
+template <int NW>
+constexpr size_t gq_lds_bytes() {
+  return (size_t)2 * XO_TOK * (NW * 64 + 8) * 2 + (size_t)NW * GQ_WST + (size_t)9 * NW * 64 * sizeof(float) + 128 * sizeof(float);
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void gn_proj_qkv_kernel(GQArgs a) {
+  constexpr int C = NW * 64, ROW = C + 8, K16 = C / 16, NT = NW * 64;
+  constexpr int BATCH = 4, NBUF = 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* xs = reinterpret_cast<half_t*>(smem);                      // [32][ROW] GroupNorm'd input rows
+  half_t* hs = xs + XO_TOK * ROW;                                    // [32][ROW] proj_in output rows (LayerNorm source)
+  char* wst_all = reinterpret_cast<char*>(hs + XO_TOK * ROW);        // [NW][GQ_WST]
+  float* sconst = reinterpret_cast<float*>(wst_all + NW * GQ_WST);   // gsc[C] | gsh[C] | pb[C] | qb[3C] | qc[3C]
+  float* gstat = sconst + 9 * C;                                     // mean[64] | rstd[64]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int m_blk = blockIdx.x * XO_TOK;
+  const int b = m_blk / a.S;                                         // S % 32 == 0: one sample per workgroup
+  half_t* wst = reinterpret_cast<half_t*>(wst_all + wave * GQ_WST);
+
+  // ---- everything that can be requested up front: the input tile, the first weight batches of proj_in, the per-column constants ----
+  half8 xv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + NT * i, row = idx / (C / 8), c8 = idx - row * (C / 8);
+    xv[i] = *reinterpret_cast<const half8*>(a.x + (size_t)(m_blk + row) * C + c8 * 8);
+  }
+  XoW<BATCH, NBUF> wr;
+  xo_prefetch<K16, BATCH, NBUF>(wr, a.wp_t, 2 * wave, lane);
+  const bool gn = a.gn_entries > 0;                                  // kernel-uniform
+  const float pb = a.p_bias[tid];
+  const float gam = gn ? a.gn_gamma[tid] : 1.f, bet = gn ? a.gn_beta[tid] : 0.f;
+  float qb[3], qc[3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    qb[p] = a.qkv_bias[p * C + tid];
+    qc[p] = a.qkv_colsum[p * C + tid];
+  }
+  const int cpg = C / a.gn_G;
+  if (gn) {
+    // fold the producer's (sum, sumsq) partials of this sample: 8 lanes per group, fixed order (waves 0-3 hold the 32 groups x 8 lanes)
+    if (tid < 256) {
+      const int g = tid >> 3, j = tid & 7;
+      float s = 0.f, q = 0.f;
+      if (g < a.gn_G) {
+        const float2* src = reinterpret_cast<const float2*>(a.gn_partial) + ((size_t)b * a.gn_G + g) * kGnMaxSlabs;
+        for (int e = j; e < a.gn_entries; e += 8) {
+          const float2 v = src[e];
+          s += v.x;
+          q += v.y;
+        }
+      }
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) {
+        s += __shfl_xor(s, o);
+        q += __shfl_xor(q, o);
+      }
+      if (j == 0 && g < a.gn_G) {
+        const float inv_n = 1.0f / ((float)cpg * (float)a.S);
+        const float mean = s * inv_n;
+        const float var = fmaxf(q * inv_n - mean * mean, 0.f);
+        gstat[g] = mean;
+        gstat[64 + g] = rsqrtf(var + a.gn_eps);
+      }
+    }
+    __syncthreads();
+    const int g = tid / cpg;
+    const float sc = gstat[64 + g] * gam;
+    sconst[tid] = sc;
+    sconst[C + tid] = bet - gstat[g] * sc;
+  }
+  sconst[2 * C + tid] = pb;
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    sconst[3 * C + p * C + tid] = qb[p];
+    sconst[6 * C + p * C + tid] = qc[p];
+  }
+  __syncthreads();                                                   // scale / shift and the constants are visible
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + NT * i, row = idx / (C / 8), c8 = idx - row * (C / 8);
+    half8 v = xv[i];
+    if (gn) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * sconst[c8 * 8 + e] + sconst[C + c8 * 8 + e]);
+    }
+    *reinterpret_cast<half8*>(xs + row * ROW + c8 * 8) = v;
+  }
+  __syncthreads();                                                   // the normalised tile is in LDS
+
+  // ---- proj_in: h^T[64 * wave ..][32] = Wp . xn^T + b -> LDS tile (fp16, as the tensor the separate launch stores) ----
+  floatx16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  float d1 = 0.f, d2 = 0.f;
+  xo_gemm<K16, BATCH, NBUF, false>(wr, a.wp_t, 2 * wave, xs, ROW, lane, acc, d1, d2);
+  xo_prefetch<K16, BATCH, NBUF>(wr, a.wqkv_t, 2 * wave, lane);       // q pass: first batches in flight under the epilogue and the barrier
+  {
+    half_t* hrow = hs + l31 * ROW + wave * XO_D + 4 * hi;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const floatx4 b1 = *reinterpret_cast<const floatx4*>(sconst + 2 * C + wave * XO_D + j * 32 + 8 * g + 4 * hi);
+        half4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (half_t)(acc[j][4 * g + e] + b1[e]);
+        *reinterpret_cast<half4*>(hrow + j * 32 + 8 * g) = o;
+      }
+  }
+  __syncthreads();                                                   // h of every channel block is in the tile
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {                                      // the residual stream leaves in whole rows
+    const int idx = tid + NT * i, row = idx / (C / 8), c8 = idx - row * (C / 8);
+    *reinterpret_cast<half8*>(a.h + (size_t)(m_blk + row) * C + c8 * 8) = *reinterpret_cast<const half8*>(hs + row * ROW + c8 * 8);
+  }
+
+  // ---- q | k | v: three passes over the h tile; LayerNorm statistics of the token rows from the fragments of the first ----
+  float la = 1.f, lb = 0.f;
+  const int sp0 = m_blk - b * a.S;
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    if (p == 0) xo_gemm<K16, BATCH, NBUF, true>(wr, a.wqkv_t, p * (C / 32) + 2 * wave, hs, ROW, lane, acc, s1, s2);
+    else xo_gemm<K16, BATCH, NBUF, false>(wr, a.wqkv_t, p * (C / 32) + 2 * wave, hs, ROW, lane, acc, s1, s2);
+    if (p < 2) xo_prefetch<K16, BATCH, NBUF>(wr, a.wqkv_t, (p + 1) * (C / 32) + 2 * wave, lane);
+    if (p == 0) {
+      const float inv_k = 1.0f / (float)C;
+      const float t1 = xo_xor32_sumf(s1), t2 = xo_xor32_sumf(s2);
+      const float mean = t1 * inv_k;
+      la = rsqrtf(fmaxf(t2 * inv_k - mean * mean, 0.f) + a.ln_eps);
+      lb = -la * mean;
+    }
+    const float qs = p == 0 ? a.q_scale : 1.f;
+    // acc[j][4 g + e]: channel j*32 + 8 g + 4 hi + e of the wave's block, token l31
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nl = j * 32 + 8 * g + 4 * hi;
+        const floatx4 b4 = *reinterpret_cast<const floatx4*>(sconst + 3 * C + p * C + wave * XO_D + nl);
+        const floatx4 c4 = *reinterpret_cast<const floatx4*>(sconst + 6 * C + p * C + wave * XO_D + nl);
+        half4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (half_t)(fmaf(acc[j][4 * g + e], la, fmaf(lb, c4[e], b4[e])) * qs);
+        if (p < 2) {
+          *reinterpret_cast<half4*>(wst + l31 * 72 + nl) = o;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) wst[(nl + e) * 40 + l31] = o[e];
+        }
+      }
+    // the wave's own staging region back out (DS operations of one wave execute in order: no barrier)
+    if (p < 2) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int id = lane + 64 * it, tok = id >> 3, c = id & 7;
+        const half8 v = *reinterpret_cast<const half8*>(wst + tok * 72 + c * 8);
+        *reinterpret_cast<half8*>(a.qk + (size_t)(m_blk + tok) * (2 * C) + p * C + wave * XO_D + c * 8) = v;
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int id = lane + 64 * it, ch = id >> 2, c = id & 3;
+        half8 v;
+        if (a.vt_perm) {   // chunk c = tokens 16 j + 4 o + {0..3} and 16 j + 8 + 4 o + {0..3}  (j = c >> 1, o = c & 1): AttnDesc::vt_perm
+          const half_t* src = wst + ch * 40 + (c >> 1) * 16 + (c & 1) * 4;
+          const half4 lo = *reinterpret_cast<const half4*>(src), up = *reinterpret_cast<const half4*>(src + 8);
+          v = half8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+        } else {
+          v = *reinterpret_cast<const half8*>(wst + ch * 40 + c * 8);
+        }
+        *reinterpret_cast<half8*>(a.vt + ((size_t)b * C + wave * XO_D + ch) * a.ldT + sp0 + c * 8) = v;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 bool xattn_out_ok(int C, int heads, int S, int L) {
@@ -589,6 +806,27 @@ int launch_ffn_proj(const FfnProjDesc& d, hipStream_t s) {
   hipLaunchKernelGGL(k, dim3(d.M / XO_TOK), dim3(5 * 64), lds, s, a);
   SD_HIP(hipGetLastError());
   return stats ? tiles : 0;
+}
+
+bool gn_proj_qkv_ok(int C, int heads, int S, int M, int ldT, int G) {
+  return C == 320 && heads == 5 && S >= XO_TOK && S % XO_TOK == 0 && M % S == 0 && ldT % 8 == 0 && ldT >= S && G >= 1 && G <= 32 && C % G == 0;
+}
+
+void launch_gn_proj_qkv(const GnProjQkvDesc& d, hipStream_t s) {
+  SD_REQUIRE(gn_proj_qkv_ok(d.C, d.C / XO_D, d.S, d.M, d.ldT, d.gn_groups) && d.x && d.wp_t && d.p_bias && d.h && d.wqkv_t && d.qkv_bias &&
+                 d.qkv_colsum && d.qk && d.vt && d.gn_entries >= 0 && d.gn_entries <= kGnMaxSlabs &&
+                 (d.gn_entries == 0 || (d.gn_partial && d.gn_gamma && d.gn_beta)),
+             kInvalidArgument, "gn_proj_qkv: C=%d S=%d M=%d ldT=%d entries=%d", d.C, d.S, d.M, d.ldT, d.gn_entries);
+  GQArgs a{d.x, d.gn_partial, d.gn_gamma, d.gn_beta, reinterpret_cast<const half8*>(d.wp_t), d.p_bias, d.h,
+           reinterpret_cast<const half8*>(d.wqkv_t), d.qkv_bias, d.qkv_colsum, d.qk, d.vt, d.M, d.S, d.ldT, d.vt_perm ? 1 : 0, d.gn_entries,
+           d.gn_groups, d.gn_eps, d.ln_eps, d.q_scale};
+  constexpr size_t lds = gq_lds_bytes<5>();
+  static_assert(lds <= 160 * 1024, "LDS");
+  auto k = gn_proj_qkv_kernel<5>;
+  static DynLdsOnce once;
+  once.set(k, lds);
+  hipLaunchKernelGGL(k, dim3(d.M / XO_TOK), dim3(5 * 64), lds, s, a);
+  SD_HIP(hipGetLastError());
 }
 
 void launch_xattn_out_retile_nk(const half_t* w, half_t* wt, int N, int K, hipStream_t s) {

@@ -103,6 +103,8 @@ SYMBOLS = [
     ("sd_op_geglu", _I, [_P, _P, _FP, _P, _I, _I, _I, _I, _FP]),
     ("sd_op_geglu_ln", _I, [_P, _FP, _FP, _P, _FP, _P, _I, _I, _I, C.c_float, _I, _I, _FP]),
     ("sd_op_qkv_ln", _I, [_P, _FP, _FP, _P, _P, _P, _I, _I, _I, C.c_float, C.c_float, _I, _I, _I, _FP]),
+    ("sd_op_gn_proj_qkv", _I, [_P, _P, _FP, _FP, _P, _FP, _FP, _FP, _P, _P, _P, _P, _I, _I, _I, _I, _I, C.c_float, C.c_float, C.c_float, _I, _I,
+                               C.POINTER(C.c_int), _I, _FP]),
     ("sd_op_timestep_embedding", _I, [_FP, _FP, _I, _I, _I, _F]),
     ("sd_numpy_randn", _I, [C.c_uint32, C.POINTER(C.c_double), C.c_size_t]),
     ("sd_torch_randn", _I, [C.c_uint32, C.POINTER(C.c_double), C.c_size_t]),
@@ -401,6 +403,23 @@ def qkv_ln(x, ln_weight, ln_bias, w, batch, q_scale=1.0, vt_perm=True, eps=1e-5,
     check(lib().sd_op_qkv_ln(ptr(x), fptr(f32(ln_weight)), fptr(f32(ln_bias)), ptr(w), ptr(out_qk), ptr(out_vt), batch, HW, Cn, eps, q_scale,
                              int(vt_perm), kernel, iters, C.byref(ms)))
     return out_qk, out_vt, ms.value
+
+
+def gn_proj_qkv(x_in, conv_w, gn_weight, gn_bias, proj_w, proj_bias, ln_weight, ln_bias, wqkv, groups=32, gn_eps=1e-6, ln_eps=1e-5,
+                q_scale=1.0, vt_perm=True, fused=True, iters=1):
+    """conv1x1 (producer, leaves GroupNorm statistics) -> GroupNorm -> proj_in -> LayerNorm -> fused q|k|v; fused: the last four in ONE
+    launch.  Returns (h (B * HW, C), qk (B * HW, 2C), vt (B, C, HW), entries, ms)."""
+    x_in, conv_w, proj_w, wqkv = f16(x_in), f16(conv_w), f16(proj_w), f16(wqkv)
+    B, Cn, H, W = x_in.shape
+    M = B * H * W
+    h = np.empty((M, Cn), np.float16)
+    qk = np.empty((M, 2 * Cn), np.float16)
+    vt = np.empty((B, Cn, H * W), np.float16)
+    ms, entries = C.c_float(0), C.c_int(0)
+    check(lib().sd_op_gn_proj_qkv(ptr(x_in), ptr(conv_w), fptr(f32(gn_weight)), fptr(f32(gn_bias)), ptr(proj_w), fptr(f32(proj_bias)),
+                                  fptr(f32(ln_weight)), fptr(f32(ln_bias)), ptr(wqkv), ptr(h), ptr(qk), ptr(vt), B, H, W, Cn, groups, gn_eps,
+                                  ln_eps, q_scale, int(vt_perm), int(fused), C.byref(entries), iters, C.byref(ms)))
+    return h, qk, vt, entries.value, ms.value
 
 
 def timestep_embedding(t, dim, flip_sin_to_cos=True, freq_shift=0.0):

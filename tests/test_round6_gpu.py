@@ -234,3 +234,61 @@ def test_wsgemm_qkv_matches_torch_and_tiled(batch, hw, perm):
         close(vt, tvt.astype(np.float32), "wsgemm vs tiled V^T", min_psnr=66.0)
         dqk, dvt, _ = _lib.qkv_ln(x, ln_w, ln_b, w, batch, q_scale=q_scale, vt_perm=perm, kernel=0)
         assert np.array_equal(dqk, tqk) and np.array_equal(dvt, tvt), "the library's own plan for this shape stays the tiled kernel"
+
+
+# ---- the head of a SpatialTransformer in one launch: GroupNorm apply -> proj_in -> LayerNorm -> q|k|v (xattn_out.hip) -----------
+def gn_proj_qkv_ref(x_in, conv_w, gn_w, gn_b, proj_w, proj_b, ln_w, ln_b, wqkv, q_scale, vt_perm):
+    x = F.conv2d(torch.from_numpy(x_in.astype(np.float32)), torch.from_numpy(conv_w.astype(np.float32))[:, :, None, None])
+    x = x.half().float()                                                            # the producer stores fp16
+    xn = F.group_norm(x, 32, torch.from_numpy(gn_w), torch.from_numpy(gn_b), 1e-6)  # unet.py:528-531
+    b, c, hh, ww = xn.shape
+    tok = xn.permute(0, 2, 3, 1).reshape(b * hh * ww, c)
+    h = tok @ torch.from_numpy(proj_w.astype(np.float32)).T + torch.from_numpy(proj_b)
+    qk, vt = qkv_ref(h.numpy(), ln_w, ln_b, wqkv, b, q_scale, vt_perm)
+    return h.numpy(), qk, vt
+
+
+@pytest.mark.parametrize("batch,hh,ww", [(2, 64, 64), (1, 32, 32), (3, 16, 32)], ids=lambda v: str(v))
+@pytest.mark.parametrize("fused", [True, False], ids=["one-launch", "three-launches"])
+@pytest.mark.parametrize("perm", [True, False], ids=["vt-perm", "vt-plain"])
+def test_gn_proj_qkv_matches_torch(batch, hh, ww, fused, perm):
+    c = 320
+    rs = np.random.RandomState(batch + hh + ww)
+    x_in = h16(rs.randn(batch, c, hh, ww))
+    conv_w = h16(rs.randn(c, c) / np.sqrt(c) * (1.0 + rs.rand(c, 1)))              # groups of different scale
+    gn_w = (1.0 + 0.2 * rs.randn(c)).astype(np.float32)
+    gn_b = (0.1 * rs.randn(c)).astype(np.float32)
+    proj_w = h16(rs.randn(c, c) / np.sqrt(c))
+    proj_b = (0.1 * rs.randn(c)).astype(np.float32)
+    ln_w = (1.0 + 0.2 * rs.randn(c)).astype(np.float32)
+    ln_b = (0.1 * rs.randn(c)).astype(np.float32)
+    wqkv = h16(rs.randn(3 * c, c) / np.sqrt(c))
+    q_scale = 1.4426950408889634 / 8.0
+    h, qk, vt, entries, _ = _lib.gn_proj_qkv(x_in, conv_w, gn_w, gn_b, proj_w, proj_b, ln_w, ln_b, wqkv, q_scale=q_scale, vt_perm=perm, fused=fused)
+    rh, rqk, rvt = gn_proj_qkv_ref(x_in, conv_w, gn_w, gn_b, proj_w, proj_b, ln_w, ln_b, wqkv, q_scale, perm)
+    if fused:
+        assert entries >= 1, "the producer's statistics were folded by the fused launch"
+    close(h, rh, f"proj_in output B={batch} {hh}x{ww} fused={fused}")
+    # q|k|v are a second GEMM over the fp16-rounded h: compare against the reference run on the kernel's own h
+    rqk2, rvt2 = qkv_ref(h.astype(np.float32), ln_w, ln_b, wqkv, batch, q_scale, perm)
+    close(qk, rqk2, f"q|k B={batch} {hh}x{ww} fused={fused}")
+    close(vt, rvt2, f"V^T B={batch} {hh}x{ww} fused={fused} perm={perm}")
+    close(qk, rqk, "q|k end to end", min_psnr=55.0, rel=1e-2)
+    close(vt, rvt, "V^T end to end", min_psnr=55.0, rel=1e-2)
+
+
+def test_gn_proj_qkv_one_launch_vs_three():
+    c = 320
+    rs = np.random.RandomState(5)
+    x_in = h16(rs.randn(2, c, 64, 64))
+    conv_w = h16(rs.randn(c, c) / np.sqrt(c))
+    args = (x_in, conv_w, (1 + 0.1 * rs.randn(c)).astype(np.float32), (0.1 * rs.randn(c)).astype(np.float32), h16(rs.randn(c, c) / np.sqrt(c)),
+            (0.1 * rs.randn(c)).astype(np.float32), (1 + 0.1 * rs.randn(c)).astype(np.float32), (0.1 * rs.randn(c)).astype(np.float32),
+            h16(rs.randn(3 * c, c) / np.sqrt(c)))
+    h1, qk1, vt1, e1, _ = _lib.gn_proj_qkv(*args, q_scale=0.18, fused=True)
+    h0, qk0, vt0, _, _ = _lib.gn_proj_qkv(*args, q_scale=0.18, fused=False)
+    close(h1, h0.astype(np.float32), "h one launch vs three", min_psnr=66.0)
+    close(qk1, qk0.astype(np.float32), "q|k one launch vs three", min_psnr=60.0)
+    close(vt1, vt0.astype(np.float32), "V^T one launch vs three", min_psnr=60.0)
+    h2, qk2, vt2, e2, _ = _lib.gn_proj_qkv(*args, q_scale=0.18, fused=True)
+    assert e1 == e2 and np.array_equal(h1, h2) and np.array_equal(qk1, qk2) and np.array_equal(vt1, vt2), "bit-reproducible"
