@@ -22,12 +22,18 @@
 // SPLIT_EINSUM_V2's 512-query chunks are two 256-query workgroups.  fp32 running max / sum / accumulators, fp16 operands.
 #include "kernels.h"
 
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 namespace sd {
 namespace {
 
+#ifndef SD_ATTN8_SK_DEFAULT
+#define SD_ATTN8_SK_DEFAULT 1                // the balanced form (SK below) where sk_plan() finds the classic grid unbalanced; 0 = never
+#endif
 constexpr int KT = 64;                       // keys per tile
 constexpr int TILE_BYTES = KT * 64 * 2;      // one K (or V^T) tile: 64 rows x 128 B
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;  // K | V^T
@@ -42,8 +48,18 @@ struct Attn8Args {
   float scale_log2;   // d^-0.5 * log2(e); 1 when q arrives pre-scaled (AttnDesc::q_prescaled)
   int q_tiles;        // query tiles (WAVES * 32 queries) per (sample, head)
   int prescaled;
+  // balanced form (SK): workgroup g runs the units [g * upw, (g + 1) * upw) of the linear order ((sample, head), query tile, key
+  // tile); a query tile whose key tiles were shared by several workgroups is finished by the last of them to arrive
+  int upw, total_units, max_seg;
+  int dbg;            // timing ablations (SD_ATTN8_SK_DBG): 1 = no partial stores, 2 = no arrivals / merge (results are wrong)
+  int xcd_local;      // every query tile's segments run on ONE XCD (launch geometry + verified dispatch order): partials through its L2
+  float* part;        // [workgroup * max_seg + segment][WAVES][8][64][4] O | [64][2] (m, l)
+  unsigned* cnt;      // [(sample, head) * q_tiles][WAVES] arrivals; left at zero
 };
+constexpr int SK_WAVE_FLOATS = 32 * 64 + 2 * 64;   // one wave's partial result: O (32 x 64 fp32), running max and sum per lane
 
+typedef unsigned uint4v_t __attribute__((ext_vector_type(4)));
+typedef unsigned uint2v_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t& rs, char* lds, unsigned voffset, int soffset) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, voffset, soffset, 0, 0);
@@ -81,7 +97,12 @@ __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(
 //     LDS read at the SAME per-lane offsets as a K fragment: no half-fragment moves, four address adds per tile;
 //   * the row max is a v_max3_f32 chain.
 // Left per tile and wave: 32 v_exp_f32, 16 v_cvt_pk_f16_f32, 16 v_dot2, 17 max, ~10 others.
-template <int WAVES, int D, bool EXACT>
+//
+// SK (round 6): the balanced form for launches whose query tiles do not fill the CUs evenly (S = 4096 at UNet batch 2: 160 query tiles
+// of eight waves on 256 CUs).  The (query tile, key tile) units are dealt out evenly - 40 key tiles of a query tile and, where the
+// range crosses into the next query tile, a second segment - each segment leaves (m, l, O) of its keys in HBM, and the LAST workgroup
+// to arrive at a query tile (one agent-scope counter per tile, no spinning) merges them in segment order: bit-reproducible.
+template <int WAVES, int D, bool EXACT, bool SK>
 __global__ __launch_bounds__(WAVES * 64) void attn8_kernel(Attn8Args a) {
   static_assert(WAVES == 4 || WAVES == 8, "4 or 8 waves");
   constexpr int PPT = 16 / WAVES;            // LDS-DMA pieces (1 KiB) per wave per tile: the K pieces first, then the V^T pieces
@@ -98,11 +119,72 @@ __global__ __launch_bounds__(WAVES * 64) void attn8_kernel(Attn8Args a) {
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = ((xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
   }
-  const int qtile = bid % a.q_tiles;
-  const int bh = bid / a.q_tiles;
+  const int nt_all = a.Sk / KT;
+  // ---- normalise + store the 32 queries this wave holds of query tile qg_: lane (query l31) has channels ct*32 + 8 g + 4 hi + 0..3 ----
+  auto store_out = [&](int qg_, const floatx16 (&o)[2], float inv) __attribute__((always_inline)) {
+    const int qtile_ = qg_ % a.q_tiles, bh_ = qg_ / a.q_tiles;
+    const int b_ = bh_ / a.heads, h_ = bh_ - b_ * a.heads;
+    const int q = (qtile_ * WAVES + wave) * 32 + l31;
+    half_t* orow = a.out + ((size_t)b_ * a.Sq + q) * a.ldo + (size_t)h_ * 64;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {
+        // widen the stores: the two half-waves trade 8-byte groups so that each lane ends up with 16 contiguous bytes
+        // (lower half: channels 8 g .. 8 g + 7, upper half: 8 g + 8 .. 8 g + 15 of this 32-channel tile)
+        unsigned w[2][2];
+#pragma unroll
+        for (int u2 = 0; u2 < 2; ++u2) {
+          const half2v lo = {(half_t)(o[ct][4 * (g + u2)] * inv), (half_t)(o[ct][4 * (g + u2) + 1] * inv)};
+          const half2v hh = {(half_t)(o[ct][4 * (g + u2) + 2] * inv), (half_t)(o[ct][4 * (g + u2) + 3] * inv)};
+          w[u2][0] = __builtin_bit_cast(unsigned, lo);
+          w[u2][1] = __builtin_bit_cast(unsigned, hh);
+        }
+        unsigned o4[4];
+#pragma unroll
+        for (int dw = 0; dw < 2; ++dw) {
+          const auto r = __builtin_amdgcn_permlane32_swap(w[0][dw], w[1][dw], false, false);
+          const unsigned r0 = r[0], r1 = r[1];
+          o4[dw] = r0;         // lower half: own group g              | upper half: the lower half's group g + 1
+          o4[2 + dw] = r1;     // lower half: the upper half's group g | upper half: own group g + 1
+        }
+        if (q < a.Sq) {
+          const uint4v_t ov = {o4[0], o4[1], o4[2], o4[3]};
+          out_store(reinterpret_cast<uint4v_t*>(orow + ct * 32 + 8 * g + 8 * hi), ov);
+        }
+      }
+  };
+  // The partial results of the balanced form travel with scoped stores and loads instead of a release / acquire fence pair - sc1 (agent
+  // scope: written through / read past this XCD's L2), or sc0 alone where the launch keeps a query tile's segments on one XCD: a fence writes back and invalidates the WHOLE L2 of the XCD, once per segment and
+  // workgroup, and takes the K / V tiles of every other workgroup with it (measured: 150 us against the classic grid's 70).
+  typedef float float4v __attribute__((ext_vector_type(4)));
+  typedef float float2v __attribute__((ext_vector_type(2)));
+  constexpr int kAgent = 16;                                 // aux bit 4 = sc1
+  constexpr int kLocal = 1;                                  // aux bit 0 = sc0: past the CU's vector cache, served by the XCD's L2
+  auto part_rsrc = [&](int g, int sg, bool live) {
+    float* base = a.part + ((size_t)(g * a.max_seg + sg) * WAVES + wave) * SK_WAVE_FLOATS;
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, live ? SK_WAVE_FLOATS * 4 : 0, 0x00020000);
+  };
+  int pq0 = -1, pn0 = 0, pq1 = -1, pn1 = 0;                  // query tiles this workgroup left partial results for (at most two)
+  int u = SK ? bid * a.upw : 0;                              // unit cursor of the balanced form
+  const int u_end = SK ? min(u + a.upw, a.total_units) : 1;
+  int seg = 0;
+  while (u < u_end) {   // (the classic form: one pass)
+  int qg, kt0, kt1;
+  if constexpr (SK) {
+    qg = u / nt_all;
+    kt0 = u - qg * nt_all;
+    kt1 = min(nt_all, kt0 + (u_end - u));
+  } else {
+    qg = bid;
+    kt0 = 0;
+    kt1 = nt_all;
+  }
+  const int qtile = qg % a.q_tiles;
+  const int bh = qg / a.q_tiles;
   const int b = bh / a.heads, h = bh - b * a.heads;
   const int q0 = (qtile * WAVES + wave) * 32;
-  const int nt = a.Sk / KT;
+  const int nt = kt1 - kt0;
 
   const half_t* qbase = a.q + (size_t)b * a.Sq * a.ldq + (size_t)h * 64;
   const half_t* kbase = a.k + (size_t)b * a.Sk * a.ldk + (size_t)h * 64;
@@ -137,9 +219,9 @@ __global__ __launch_bounds__(WAVES * 64) void attn8_kernel(Attn8Args a) {
     voff[i] = (unsigned)((r * (i < KP ? a.ldk : a.ldv) + c * 8) * 2);
   }
   const int k_step = KT * a.ldk * 2;                         // bytes between consecutive K tiles
-  int it_t = 0, it_stage = 0;                                // issue cursor
+  int it_t = kt0, it_stage = 0;                              // issue cursor
   auto issue_tile = [&]() {
-    const bool live = it_t < nt;                             // wave-uniform; past the end: zero-sized resources (the counted
+    const bool live = it_t < kt1;                            // wave-uniform; past the end: zero-sized resources (the counted
     const __amdgpu_buffer_rsrc_t rs_k =                      // waits below stay uniform, nothing is fetched)
         __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(kbase), 0, (int)(live ? k_bytes : 0u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_v =
@@ -345,38 +427,111 @@ __global__ __launch_bounds__(WAVES * 64) void attn8_kernel(Attn8Args a) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the zero-sized tail DMAs too, before the workgroup retires
 
-  // ---- normalise + store: lane (query l31) holds channels ct*32 + 8 g + 4 hi + 0..3 ----
-  const float inv = 1.0f / xor32_sum(ls0 + ls1);
-  const int q = q0 + l31;
-  half_t* orow = a.out + ((size_t)b * a.Sq + q) * a.ldo + (size_t)h * 64;
+  if constexpr (SK) {
+    __syncthreads();                                         // every wave is through the ring: the next segment's DMAs may land
+    const int g_first = (qg * nt_all) / a.upw, g_last = (qg * nt_all + nt_all - 1) / a.upw;
+    const int nseg = g_last - g_first + 1;                   // workgroups that share this query tile's keys
+    if (nseg > 1) {
+      // this segment's (m, l, O) leave for HBM; nobody waits for them here - the arrival is posted after the workgroup's last segment
+      const __amdgpu_buffer_rsrc_t rs = part_rsrc(bid, seg, true);
+      const float2v ml = {mrun, xor32_sum(ls0 + ls1)};
+      auto put = [&](auto aux_c) __attribute__((always_inline)) {
+        constexpr int AUX = decltype(aux_c)::value;
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
+        for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-    for (int g = 0; g < 4; g += 2) {
-      // widen the stores: the two half-waves trade 8-byte groups so that each lane ends up with 16 contiguous bytes
-      // (lower half: channels 8 g .. 8 g + 7, upper half: 8 g + 8 .. 8 g + 15 of this 32-channel tile)
-      unsigned w[2][2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const half2v lo = {(half_t)(oacc[ct][4 * (g + u)] * inv), (half_t)(oacc[ct][4 * (g + u) + 1] * inv)};
-        const half2v hh = {(half_t)(oacc[ct][4 * (g + u) + 2] * inv), (half_t)(oacc[ct][4 * (g + u) + 3] * inv)};
-        w[u][0] = __builtin_bit_cast(unsigned, lo);
-        w[u][1] = __builtin_bit_cast(unsigned, hh);
+          for (int g = 0; g < 4; ++g) {
+            const float4v v = {oacc[ct][4 * g], oacc[ct][4 * g + 1], oacc[ct][4 * g + 2], oacc[ct][4 * g + 3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v_t, v), rs, ((ct * 4 + g) * 64 + lane) * 16, 0, AUX);
+          }
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uint2v_t, ml), rs, 32 * 64 * 4 + lane * 8, 0, AUX);
+      };
+      if (a.dbg & 1) {
+      } else if (a.xcd_local) put(std::integral_constant<int, kLocal>{});
+      else put(std::integral_constant<int, kAgent>{});
+      if (pq0 < 0) {
+        pq0 = qg;
+        pn0 = nseg;
+      } else {
+        pq1 = qg;
+        pn1 = nseg;
       }
-      unsigned o4[4];
-#pragma unroll
-      for (int dw = 0; dw < 2; ++dw) {
-        const auto r = __builtin_amdgcn_permlane32_swap(w[0][dw], w[1][dw], false, false);
-        const unsigned r0 = r[0], r1 = r[1];
-        o4[dw] = r0;         // lower half: own group g              | upper half: the lower half's group g + 1
-        o4[2 + dw] = r1;     // lower half: the upper half's group g | upper half: own group g + 1
-      }
-      if (q < a.Sq) {
-        typedef unsigned uint4v __attribute__((ext_vector_type(4)));
-        const uint4v o = {o4[0], o4[1], o4[2], o4[3]};
-        out_store(reinterpret_cast<uint4v*>(orow + ct * 32 + 8 * g + 8 * hi), o);
-      }
+    } else {
+      store_out(qg, oacc, 1.0f / xor32_sum(ls0 + ls1));
     }
+    u += nt;
+    ++seg;
+  } else {
+    store_out(qg, oacc, 1.0f / xor32_sum(ls0 + ls1));
+    break;
+  }
+  }   // segments
+
+  if constexpr (SK) {
+    // ---- arrivals, one counter per (query tile, wave): a wave's 32 queries are merged by the wave of the LAST segment to arrive ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the write-through stores of both segments are acknowledged
+    unsigned o0 = 0, o1 = 0;
+    if (a.dbg & 2) return;
+    if (lane == 0) {
+      if (pq0 >= 0) o0 = atomicAdd(a.cnt + pq0 * WAVES + wave, 1u);
+      if (pq1 >= 0) o1 = atomicAdd(a.cnt + pq1 * WAVES + wave, 1u);
+    }
+    o0 = __builtin_amdgcn_readfirstlane(o0);
+    o1 = __builtin_amdgcn_readfirstlane(o1);
+    auto merge = [&](int qg_, int nseg) __attribute__((always_inline)) {
+      // segment order whoever merges (streaming-softmax update: the stabiliser follows the segments' own): bit-reproducible
+      const int g_first = (qg_ * nt_all) / a.upw;
+      floatx16 o[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        o[0][r] = 0.f;
+        o[1][r] = 0.f;
+      }
+      float mx = -3.0e38f, lsum = 0.f;
+      auto fold = [&](const float4v (&v)[8], const float2v& ml) {
+        const float mn = fmaxf(mx, ml[0]);
+        const float wo = __builtin_amdgcn_exp2f(mx - mn), wi = __builtin_amdgcn_exp2f(ml[0] - mn);
+        mx = mn;
+        lsum = fmaf(ml[1], wi, lsum * wo);
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[t >> 2][4 * (t & 3) + e] = fmaf(v[t][e], wi, o[t >> 2][4 * (t & 3) + e] * wo);
+      };
+      auto fetch_aux = [&](int i, float4v (&v)[8], float2v& ml, bool live, auto aux_c) __attribute__((always_inline)) {
+        constexpr int AUX = decltype(aux_c)::value;
+        const int g = g_first + (live ? i : 0);
+        const __amdgpu_buffer_rsrc_t rs = part_rsrc(g, qg_ - (g * a.upw) / nt_all, live);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(rs, (t * 64 + lane) * 16, 0, AUX));
+        ml = __builtin_bit_cast(float2v, __builtin_amdgcn_raw_buffer_load_b64(rs, 32 * 64 * 4 + lane * 8, 0, AUX));
+      };
+      auto fetch = [&](int i, float4v (&v)[8], float2v& ml, bool live) __attribute__((always_inline)) {
+        if (a.xcd_local) fetch_aux(i, v, ml, live, std::integral_constant<int, kLocal>{});
+        else fetch_aux(i, v, ml, live, std::integral_constant<int, kAgent>{});
+      };
+      if (nseg <= 3) {   // all of them in flight at once
+        float4v v[3][8];
+        float2v ml[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) fetch(i, v[i], ml[i], i < nseg);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          if (i < nseg) fold(v[i], ml[i]);
+      } else {
+        for (int i = 0; i < nseg; ++i) {
+          float4v v[8];
+          float2v ml;
+          fetch(i, v, ml, true);
+          fold(v, ml);
+        }
+      }
+      if (lane == 0) a.cnt[qg_ * WAVES + wave] = 0;          // ready for the next launch
+      store_out(qg_, o, 1.0f / lsum);
+    };
+    if (pq0 >= 0 && o0 == (unsigned)(pn0 - 1)) merge(pq0, pn0);
+    if (pq1 >= 0 && o1 == (unsigned)(pn1 - 1)) merge(pq1, pn1);
+  }
 }
 
 template <int WAVES, int D, bool EXACT>
@@ -384,10 +539,99 @@ void launch8(const Attn8Args& a0, int B, hipStream_t s) {
   Attn8Args a = a0;
   a.q_tiles = cdiv(a.Sq, WAVES * 32);
   constexpr size_t lds = (size_t)D * STAGE_BYTES;
-  auto k = attn8_kernel<WAVES, D, EXACT>;
+  auto k = attn8_kernel<WAVES, D, EXACT, false>;
   static DynLdsOnce once;
   once.set(k, lds);
   hipLaunchKernelGGL(k, dim3(a.q_tiles * a.heads * B), dim3(WAVES * 64), lds, s, a);
+}
+
+template <int WAVES, int D, bool EXACT>
+void launch8_sk(const Attn8Args& a, int grid, hipStream_t s) {
+  constexpr size_t lds = (size_t)D * STAGE_BYTES;
+  auto k = attn8_kernel<WAVES, D, EXACT, true>;
+  static DynLdsOnce once;
+  once.set(k, lds);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(WAVES * 64), lds, s, a);
+}
+
+int device_cus() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    return v;
+  }();
+  return n;
+}
+
+// Do consecutive workgroup ids go round-robin over eight XCDs (id % 8), as the locality walks of this library assume?  Probed once with a
+// grid that over-subscribes the chip; the balanced form sends its partial results through the XCD's L2 only when this held for every
+// workgroup, and through HBM otherwise.
+__global__ void xcc_probe_kernel(unsigned* out) {
+  if (threadIdx.x == 0) out[blockIdx.x] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 0xf;   // HW_REG_XCC_ID[3:0]
+}
+bool xcd_round_robin() {
+  static const bool ok = [] {
+    if (tune_env_int("SD_ATTN8_SK_LOCAL", 1) == 0) return false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(nullptr, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
+    const int n = 8192;
+    unsigned* d = nullptr;
+    if (hipMalloc(&d, n * sizeof(unsigned)) != hipSuccess) return false;
+    std::vector<unsigned> h(n, 0xffu);
+    bool good = hipMemset(d, 0xff, n * sizeof(unsigned)) == hipSuccess;
+    if (good) {
+      hipLaunchKernelGGL(xcc_probe_kernel, dim3(n), dim3(256), 0, nullptr, d);
+      good = hipDeviceSynchronize() == hipSuccess && hipMemcpy(h.data(), d, n * sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    (void)hipFree(d);
+    for (int i = 0; i < n && good; ++i) good = h[i] == (unsigned)(i & 7);
+    return good;
+  }();
+  return ok;
+}
+
+// The balanced form's launch geometry for a problem (nothing when the classic grid is the better one).
+struct SkPlan {
+  bool on = false;
+  bool xcd_local = false;   // each XCD's share of the workgroups (the kernel's XCD-contiguous walk) is whole query tiles
+  int waves = 8, q_tiles = 0, upw = 0, total = 0, max_seg = 0, grid = 0;
+  size_t part_bytes = 0;
+  int n_cnt = 0;
+};
+SkPlan sk_plan(const AttnDesc& d) {
+  // SD_ATTN8_SK (with SD_TUNE): 0 = never, 1 = where the classic grid leaves CUs idle (default), 2 = wherever it can run
+  static const int env_mode = tune_env_int("SD_ATTN8_SK", SD_ATTN8_SK_DEFAULT);
+  static const int force_waves = tune_env_int("SD_ATTN8_WAVES", 0);
+  static const int min_upw = tune_env_int("SD_ATTN8_SK_MIN_UPW", 32);
+  SkPlan p;
+  const int mode = d.sk_force ? 2 : env_mode;
+  if (mode == 0 || d.Sq % 32 != 0) return p;
+  const int ncu = device_cus();
+  const long wg8 = (long)d.B * d.heads * cdiv(d.Sq, 256);
+  p.waves = force_waves ? (force_waves == 8 ? 8 : 4) : (wg8 >= 128 ? 8 : 4);
+  if (d.Sq % (p.waves * 32) != 0) return p;                  // whole query tiles only: every wave of a segment has 32 live queries
+  p.q_tiles = d.Sq / (p.waves * 32);
+  const long classic = (long)d.B * d.heads * p.q_tiles;
+  const int nt = d.Sk / KT;
+  const long total = classic * nt;
+  if (total >= ((long)1 << 30)) return p;
+  // the library's rule: where the classic grid's last round leaves more than a fifth of the CUs idle (160 or 320 eight-wave workgroups on
+  // 256 CUs - UNet batch 2 and 4 at 64x64 - run 69 -> 62 and 138 -> 109 us; 480 workgroups, 0.94 full, 158 -> 170: the merge costs ~ 12 us)
+  if (mode == 1 && (double)classic / (double)(((classic + ncu - 1) / ncu) * ncu) >= 0.8) return p;
+  p.total = (int)total;
+  static const int wgs_per_cu = std::max(1, tune_env_int("SD_ATTN8_SK_WGS", 1));
+  const long want = (long)ncu * wgs_per_cu;
+  p.upw = (int)((total + want - 1) / want);
+  if (d.sk_upw > 0) p.upw = d.sk_upw;                        // (operator tests: any split)
+  else if (!d.sk_force && p.upw < min_upw) return p;
+  p.grid = cdiv(p.total, p.upw);
+  p.max_seg = (p.upw + nt - 2) / nt + 1;
+  p.part_bytes = (size_t)p.grid * p.max_seg * p.waves * SK_WAVE_FLOATS * sizeof(float);
+  // the kernel's walk hands XCD x the logical workgroups [x * grid / 8, (x + 1) * grid / 8): whole query tiles when that many units are
+  p.xcd_local = p.grid % 8 == 0 && p.total == p.grid * p.upw && ((long)(p.grid / 8) * p.upw) % nt == 0 && xcd_round_robin();
+  p.n_cnt = (int)classic * p.waves;                          // one arrival counter per (query tile, wave)
+  p.on = true;
+  return p;
 }
 
 }  // namespace
@@ -405,9 +649,41 @@ bool attention8_ok(const AttnDesc& d) {
          d.ldo % 8 == 0 && (size_t)d.Sk * d.ldk * 2 < lim && (size_t)64 * d.ldv * 2 < lim;
 }
 
+bool attention8_sk_scratch(const AttnDesc& d, size_t* part_bytes, int* n_counters) {
+  const SkPlan p = sk_plan(d);
+  if (part_bytes) *part_bytes = p.on ? p.part_bytes : 0;
+  if (n_counters) *n_counters = p.on ? p.n_cnt : 0;
+  return p.on;
+}
+
 void launch_attention8(const AttnDesc& d, hipStream_t s) {
   Attn8Args a{d.q, d.k, d.vt, d.out, d.heads, d.Sq, d.Sk, d.ldq, d.ldk, d.ldv, d.ldo, 1.4426950408889634f / 8.0f, 0, d.q_prescaled};
   static const bool exact = tune_env_int("SD_ATTN8_EXACT", 0) != 0;
+  if (d.sk_part && d.sk_cnt) {   // the caller offers scratch: the balanced form where it pays
+    const SkPlan p = sk_plan(d);
+    if (p.on && p.part_bytes <= d.sk_part_bytes && p.n_cnt <= d.sk_cnt_n) {
+      a.q_tiles = p.q_tiles;
+      a.upw = p.upw;
+      a.total_units = p.total;
+      a.max_seg = p.max_seg;
+      a.xcd_local = p.xcd_local ? 1 : 0;
+      static const int dbg = tune_env_int("SD_ATTN8_SK_DBG", 0);
+      a.dbg = dbg;
+      static const bool verbose = tune_env_int("SD_ATTN8_SK_VERBOSE", 0) != 0;
+      if (verbose) fprintf(stderr, "attention8 balanced: grid %d x %d waves, %d units each, max_seg %d, xcd_local %d, dbg %d\n", p.grid, p.waves, p.upw, p.max_seg, a.xcd_local, dbg);
+      a.part = d.sk_part;
+      a.cnt = d.sk_cnt;
+      if (p.waves == 8) {
+        if (exact) launch8_sk<8, 4, true>(a, p.grid, s);
+        else launch8_sk<8, 4, false>(a, p.grid, s);
+      } else {
+        if (exact) launch8_sk<4, 4, true>(a, p.grid, s);
+        else launch8_sk<4, 4, false>(a, p.grid, s);
+      }
+      SD_HIP(hipGetLastError());
+      return;
+    }
+  }
   // 256-query workgroups when they give at least half the CUs one, else 128-query ones: more, smaller workgroups
   const long wg8 = (long)d.B * d.heads * cdiv(d.Sq, 256);
   static const int force = tune_env_int("SD_ATTN8_WAVES", 0);

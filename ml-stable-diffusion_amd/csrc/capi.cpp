@@ -334,6 +334,25 @@ int sd_op_attention(int impl, const void* q, const void* k, const void* v, void*
       SD_REQUIRE(perm, kInvalidArgument, "attention variant 2 (pre-scaled q) needs attention8's shape (d %d Sq %d Sk %d)", d, Sq, Sk);
       a.q_prescaled = 1;
     }
+    if (variant >= 100) {   // attention8's balanced form, variant - 100 units per workgroup (0: the launch's own split)
+      SD_REQUIRE(perm, kInvalidArgument, "attention variant %d (balanced form) needs attention8's shape (d %d Sq %d Sk %d)", variant, d, Sq, Sk);
+      a.variant = 0;
+      a.sk_force = 1;
+      a.sk_upw = variant - 100;
+    }
+    {
+      size_t pb = 0;
+      int nc = 0;
+      if (perm && attention8_sk_scratch(a, &pb, &nc)) {
+        a.sk_part = reinterpret_cast<float*>(sc.dev<char>(pb));
+        a.sk_part_bytes = pb;
+        a.sk_cnt = sc.dev<unsigned>(nc);
+        a.sk_cnt_n = nc;
+        SD_HIP(hipMemset(a.sk_cnt, 0, (size_t)nc * sizeof(unsigned)));
+      } else {
+        SD_REQUIRE(variant < 100, kInvalidArgument, "attention variant %d: the balanced form cannot run this shape", variant);
+      }
+    }
     sc.timed(iters, ms, [&] { launch_attention(a, sc.stream); });
     std::vector<half_t> ot((size_t)B * Sq * C);
     SD_HIP(hipMemcpy(ot.data(), o, ot.size() * 2, hipMemcpyDeviceToHost));

@@ -175,6 +175,14 @@ struct AttnDesc {
   // 1: q already carries d^-0.5 * log2(e) (multiplied into the fp32 accumulator of the producing GEMM, ConvDesc::q_scale): attention8
   // does not re-scale (and re-round) it.  Only with vt_perm.
   int q_prescaled = 0;
+  // scratch for attention8's balanced form (attention8_sk_scratch says how much this problem wants): partial (m, l, O) results and
+  // one arrival counter per query tile, ZEROED once by the owner (the kernel leaves them at zero).  Without it: the classic grid.
+  float* sk_part = nullptr;
+  size_t sk_part_bytes = 0;
+  unsigned* sk_cnt = nullptr;
+  int sk_cnt_n = 0;
+  int sk_force = 0;   // 1: the balanced form wherever it can run (operator tests; the library's rule otherwise)
+  int sk_upw = 0;     // > 0: (query tile, key tile) units per workgroup of the balanced form (operator tests)
 };
 // the factor a producer of pre-scaled queries multiplies in (head dim d)
 inline float attention_q_prescale(int d) { return 1.4426950408889634f / sqrtf((float)d); }
@@ -186,6 +194,9 @@ bool attention8_ok(const AttnDesc& d);
 // build-time decision (UNet builder, sd_op_attention): will attention8 run this shape?  Then V^T must be produced permuted.
 bool attention8_shape_ok(int d, int Sq, int Sk);
 void launch_attention8(const AttnDesc& d, hipStream_t s);
+// true where attention8 would run the problem in its balanced form (query tiles dealt out evenly over the CUs, partial results
+// merged by the last workgroup to arrive), with the scratch that takes: bytes for AttnDesc::sk_part, counters for sk_cnt
+bool attention8_sk_scratch(const AttnDesc& d, size_t* part_bytes, int* n_counters);
 
 // Cross-attention front half in one launch (xattn.hip): out = softmax(to_q(LayerNorm(x)) k^T / sqrt(d)) v per head,
 // head dim 64, <= 96 keys (unet.py:87-118 with the prompt's K / V hoisted).  x [M][C] is the UN-normalised input; wq /

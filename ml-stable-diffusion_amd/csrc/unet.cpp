@@ -677,6 +677,25 @@ Tensor UNet::attention(std::vector<Op>& ops, const Tensor& q, const half_t* k, c
   d.vt_perm = vt_perm ? 1 : 0;
   d.q_prescaled = (vt_perm && q_prescaled) ? 1 : 0;
   SD_REQUIRE(attention_supported(d.d), kUnsupported, "head dim %d (C=%d, heads=%d) unsupported", d.d, q.C, heads);
+  if (d.vt_perm) {   // attention8's balanced form wants scratch (one buffer for all of this handle's launches: they run in sequence)
+    size_t pb = 0;
+    int nc = 0;
+    if (attention8_sk_scratch(d, &pb, &nc)) {
+      if (pb > sk_part_bytes_) {
+        sk_part_ = reinterpret_cast<float*>(arena_.alloc(pb));
+        sk_part_bytes_ = pb;
+      }
+      if (nc > sk_cnt_n_) {
+        sk_cnt_ = arena_.alloc_n<unsigned>(nc);
+        sk_cnt_n_ = nc;
+        SD_HIP(hipMemsetAsync(sk_cnt_, 0, (size_t)nc * sizeof(unsigned), stream_));
+      }
+      d.sk_part = sk_part_;
+      d.sk_part_bytes = sk_part_bytes_;
+      d.sk_cnt = sk_cnt_;
+      d.sk_cnt_n = sk_cnt_n_;
+    }
+  }
   ops.push_back([this, d](hipStream_t s) {
     AttnDesc dd = d;
     dd.impl = cfg_.attention_impl;   // run-time switch (the reference's global, unet.py:39)

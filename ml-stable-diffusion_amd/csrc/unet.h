@@ -154,6 +154,11 @@ class UNet {
   Tensor vae_attention(std::vector<Op>& ops, const std::string& p, const Tensor& h);
   Tensor attention(std::vector<Op>& ops, const Tensor& q, const half_t* k, const half_t* vt, int heads, int Sq,
                    int Sk, int ldk, int ldv, int ldq, bool vt_perm = false, bool q_prescaled = false);
+  // scratch of attention8's balanced form (AttnDesc::sk_part / sk_cnt), shared by this handle's self-attention launches
+  float* sk_part_ = nullptr;
+  size_t sk_part_bytes_ = 0;
+  unsigned* sk_cnt_ = nullptr;
+  int sk_cnt_n_ = 0;
   void down_and_mid(std::vector<Op>& ops, Tensor& h, std::vector<Tensor>& skips);
   const float* register_temb(const std::string& name, int cout);
   void finalize_temb();

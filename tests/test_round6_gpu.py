@@ -292,3 +292,39 @@ def test_gn_proj_qkv_one_launch_vs_three():
     close(vt1, vt0.astype(np.float32), "V^T one launch vs three", min_psnr=60.0)
     h2, qk2, vt2, e2, _ = _lib.gn_proj_qkv(*args, q_scale=0.18, fused=True)
     assert e1 == e2 and np.array_equal(h1, h2) and np.array_equal(qk1, qk2) and np.array_equal(vt1, vt2), "bit-reproducible"
+
+
+# ---- attention8's balanced form: (query tile, key tile) units dealt out evenly, partial (m, l, O) merged by the last arriver --------
+def attn_ref(q, k, v, heads):
+    b, c, _, sq = q.shape
+    d = c // heads
+    qt = torch.from_numpy(q.astype(np.float32)).reshape(b, heads, d, sq)
+    kt = torch.from_numpy(k.astype(np.float32)).reshape(b, heads, d, -1)
+    vt = torch.from_numpy(v.astype(np.float32)).reshape(b, heads, d, -1)
+    w = torch.softmax(torch.einsum("bhdq,bhdk->bhqk", qt, kt) * d ** -0.5, dim=-1)          # attention.py:24-40
+    return torch.einsum("bhqk,bhdk->bhdq", w, vt).reshape(b, c, 1, sq).numpy()
+
+
+@pytest.mark.parametrize("batch,heads,sq,sk,upw", [
+    (2, 5, 4096, 4096, 0),      # the UNet's 64x64 level at batch 2: 40 key tiles per workgroup, every query tile merged from 2-3 partials
+    (2, 10, 1024, 1024, 0),     # the 32x32 level: four-wave workgroups
+    (1, 2, 256, 256, 3),        # three of four key tiles: segments of 3 | 1+2 | 2+1 | 3
+    (1, 2, 256, 256, 1),        # one key tile per workgroup: four partials per query tile
+    (1, 3, 512, 320, 7),        # a split that crosses into the next query tile mid-way, ragged end
+    (1, 1, 128, 640, 4),        # one query tile, ten key tiles in three segments
+    (2, 2, 256, 128, 5),        # more units per workgroup than a query tile has: whole tiles stored directly, three segments per workgroup
+], ids=lambda v: str(v))
+def test_attention8_balanced_form(batch, heads, sq, sk, upw):
+    rs = np.random.RandomState(sq + sk + upw)
+    c = heads * 64
+    q = h16(rs.randn(batch, c, 1, sq) * 1.5)
+    k = h16(rs.randn(batch, c, 1, sk) * 1.5)
+    k[:, :, :, sk // 2:] *= 1.8                                  # the later keys carry the larger scores: the running max moves between segments
+    v = h16(rs.randn(batch, c, 1, sk))
+    got, _ = _lib.attention("ORIGINAL", q, k, v, heads, 64, variant=100 + upw)
+    classic, _ = _lib.attention("ORIGINAL", q, k, v, heads, 64, variant=0)
+    ref = attn_ref(q, k, v, heads)
+    close(got, ref, f"balanced attention B={batch} h={heads} {sq}x{sk} upw={upw}", min_psnr=60.0, rel=6e-3)
+    close(got, classic.astype(np.float32), "balanced vs classic grid", min_psnr=66.0, rel=4e-3)
+    again, _ = _lib.attention("ORIGINAL", q, k, v, heads, 64, variant=100 + upw, iters=3)    # the counters come back to zero; arrival order does not matter
+    assert np.array_equal(got, again), "bit-reproducible"
