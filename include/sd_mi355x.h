@@ -245,7 +245,8 @@ int sd_text_encoder_encode(sd_text_encoder* t, const int32_t* input_ids, int eos
  * ------------------------------------------------------------------------------------------ */
 /* attention.py:24-168.  q (B, h*d, 1, Sq), k/v (B, h*d, 1, Sk) f16 BC1S -> out (B, h*d, 1, Sq) f16.
  * variant (A/B testing): 0 = default dispatch, 1 = never the software-pipelined d = 64 kernel, 2 = q arrives multiplied by
- * d^-0.5 * log2(e) (how the UNet's fused q|k|v GEMM hands its queries to that kernel: scaled in fp32, rounded once). */
+ * d^-0.5 * log2(e) (how the UNet's fused q|k|v GEMM hands its queries to that kernel: scaled in fp32, rounded once),
+ * 100 + u = that kernel's balanced grid with u (query tile, key tile) units per workgroup (0: the launch's own split). */
 int sd_op_attention(int impl, const void* q, const void* k, const void* v, void* out, int B, int heads, int d,
                     int Sq, int Sk, int variant, int iters, float* ms);
 /* layer_norm.py:51-80.  x (B, C, 1, S) f16, weight/bias (C) f32 -> out (B, C, 1, S) f16 */

@@ -931,7 +931,8 @@ Tensor UNet::transformer(std::vector<Op>& ops, const std::string& p, const Tenso
   static const int gq_mode = tune_env_int("SD_GN_QKV", SD_GN_QKV_DEFAULT);
   const int ldv0 = round_up(HW, 8);
   const bool gq = gq_mode != 0 && !fold && !f32_ && depth >= 1 && x.gn && !x.gn->partial && x.gn->n_twins == 0 && x.gn->ops_list == &ops &&
-                  C % G == 0 && gn_proj_qkv_ok(C, heads, HW, x.M(), ldv0, G) && (size_t)x.M() * C * 2 < ((size_t)1 << 31);
+                  C % G == 0 && can_fold_ln(x, 3 * C, false) && gn_proj_qkv_ok(C, heads, HW, x.M(), ldv0, G) &&
+                  (size_t)x.M() * C * 2 < ((size_t)1 << 31);
   Tensor h;
   PreQkv pre;
   if (gq) {

@@ -809,7 +809,8 @@ int launch_ffn_proj(const FfnProjDesc& d, hipStream_t s) {
 }
 
 bool gn_proj_qkv_ok(int C, int heads, int S, int M, int ldT, int G) {
-  return C == 320 && heads == 5 && S >= XO_TOK && S % XO_TOK == 0 && M % S == 0 && ldT % 8 == 0 && ldT >= S && G >= 1 && G <= 32 && C % G == 0;
+  // (any head count: the kernel's column blocks are not heads - SD1.5's eight heads of 40 take the same launch)
+  return C == 320 && heads >= 1 && C % heads == 0 && S >= XO_TOK && S % XO_TOK == 0 && M % S == 0 && ldT % 8 == 0 && ldT >= S && G >= 1 && G <= 32 && C % G == 0;
 }
 
 void launch_gn_proj_qkv(const GnProjQkvDesc& d, hipStream_t s) {
