@@ -340,7 +340,8 @@ int sd_op_qkv_ln(const void* x, const float* ln_weight, const float* ln_bias, co
                  float eps, float q_scale, int vt_perm, int kernel, int iters, float* ms);
 /* The head of a SpatialTransformer (unet.py:553-556 norm -> proj_in; :583-586 norm1 -> :74-84 fused to_q | to_k | to_v) behind a 1x1 conv
  * x = conv_w . x_in that leaves the GroupNorm statistics of x in its epilogue, as the resnet conv in front of it does in the UNet.
- * fused = 1: GroupNorm apply, proj_in, LayerNorm and the q|k|v projection in ONE launch; 0: the three launches it replaces.
+ * fused = 1: GroupNorm apply, proj_in, LayerNorm and the q|k|v projection in ONE launch (2 / 3: forced to 64 / 32 tokens per workgroup;
+ * 64 needs H * W % 64 == 0); 0: the three launches it replaces.
  * x_in (B, C, H, W) f16; conv_w / proj_w (C, C) f16; gn_*, proj_bias, ln_* (C) f32; wqkv (3C, C) f16 -> out_h (B * H * W, C) = proj_in's
  * output, out_qk (B * H * W, 2C) with pre-scaled queries, out_vt (B, C, H * W) (vt_perm as sd_op_qkv_ln), all f16.  C = 320 only.
  * *entries: the producer's statistics entries per (sample, group) folded by the fused launch (0: fall-back GroupNorm launch). */

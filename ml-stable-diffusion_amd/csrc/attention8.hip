@@ -166,9 +166,50 @@ __global__ __launch_bounds__(WAVES * 64) void attn8_kernel(Attn8Args a) {
     return __builtin_amdgcn_make_buffer_rsrc(base, 0, live ? SK_WAVE_FLOATS * 4 : 0, 0x00020000);
   };
   int pq0 = -1, pn0 = 0, pq1 = -1, pn1 = 0;                  // query tiles this workgroup left partial results for (at most two)
+  unsigned o0 = 0, o1 = 0;                                   // ... and what their arrival counters held
+  bool posted0 = false;
   int u = SK ? bid * a.upw : 0;                              // unit cursor of the balanced form
   const int u_end = SK ? min(u + a.upw, a.total_units) : 1;
   int seg = 0;
+
+  // ---- LDS-DMA of the K / V^T tiles: loop-invariant per-lane byte offsets, scalar running offsets ----
+  const unsigned k_bytes = (unsigned)(((size_t)(a.Sk - 1) * a.ldk + 64) * 2);
+  const unsigned v_bytes = (unsigned)(((size_t)63 * a.ldv + a.Sk) * 2);
+  unsigned voff[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int p = (wave + i * WAVES) & 7;                    // piece = rows 8p .. 8p+7 of the K (i < KP) or V^T tile
+    const int r = 8 * p + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);               // logical 16-B chunk this lane fetches (bank swizzle)
+    voff[i] = (unsigned)((r * (i < KP ? a.ldk : a.ldv) + c * 8) * 2);
+  }
+  const int k_step = KT * a.ldk * 2;                         // bytes between consecutive K tiles
+  // ---- fragment addressing: row l31 (+ 32 per sub-tile / channel tile), logical 16-B chunk 2 s + hi of MFMA step s;
+  //      the same offsets serve the K tile (step = 16 channels) and the permuted V^T tile (step = 16 keys) ----
+  const int fsw = (l31 >> 1) & 7;
+  int foff[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) foff[s] = l31 * 128 + (((s * 2 + hi) ^ fsw) * 16);
+  int aoff[4], noff[4];                                      // ... plus the ring stage of tile j / tile j+1
+#pragma unroll
+  for (int s = 0; s < 4; ++s) aoff[s] = foff[s];
+  // The ring outlives a segment of the balanced form: its issue cursor walks the workgroup's units across query-tile boundaries, so
+  // the first tiles of the next segment are in flight while the last ones of this segment are consumed.
+  int it_stage = 0, st_cur = 0;
+  int i_u = u, i_kt = 0, i_qg = 0;
+  const half_t* i_kbase = a.k;
+  const half_t* i_vbase = a.vt;
+  auto issue_bases = [&]() {
+    const int bh_ = i_qg / a.q_tiles;
+    const int b_ = bh_ / a.heads, h_ = bh_ - b_ * a.heads;
+    i_kbase = a.k + (size_t)b_ * a.Sk * a.ldk + (size_t)h_ * 64;
+    i_vbase = a.vt + ((size_t)b_ * a.heads + h_) * 64 * (size_t)a.ldv;
+  };
+  if constexpr (SK) {
+    i_qg = u / nt_all;
+    i_kt = u - i_qg * nt_all;
+    if (u < u_end) issue_bases();
+  }
   while (u < u_end) {   // (the classic form: one pass)
   int qg, kt0, kt1;
   if constexpr (SK) {
@@ -207,45 +248,44 @@ __global__ __launch_bounds__(WAVES * 64) void attn8_kernel(Attn8Args a) {
     }
   }
 
-  // ---- LDS-DMA of the K / V^T tiles: loop-invariant per-lane byte offsets, scalar running offsets ----
-  const unsigned k_bytes = (unsigned)(((size_t)(a.Sk - 1) * a.ldk + 64) * 2);
-  const unsigned v_bytes = (unsigned)(((size_t)63 * a.ldv + a.Sk) * 2);
-  unsigned voff[PPT];
-#pragma unroll
-  for (int i = 0; i < PPT; ++i) {
-    const int p = (wave + i * WAVES) & 7;                    // piece = rows 8p .. 8p+7 of the K (i < KP) or V^T tile
-    const int r = 8 * p + (lane >> 3);
-    const int c = (lane & 7) ^ ((r >> 1) & 7);               // logical 16-B chunk this lane fetches (bank swizzle)
-    voff[i] = (unsigned)((r * (i < KP ? a.ldk : a.ldv) + c * 8) * 2);
-  }
-  const int k_step = KT * a.ldk * 2;                         // bytes between consecutive K tiles
-  int it_t = kt0, it_stage = 0;                              // issue cursor
+  int it_t = kt0;                                            // issue cursor of the classic form
   auto issue_tile = [&]() {
-    const bool live = it_t < kt1;                            // wave-uniform; past the end: zero-sized resources (the counted
-    const __amdgpu_buffer_rsrc_t rs_k =                      // waits below stay uniform, nothing is fetched)
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(kbase), 0, (int)(live ? k_bytes : 0u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_v =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(vbase), 0, (int)(live ? v_bytes : 0u), 0x00020000);
+    bool live;                                               // wave-uniform; past the end: zero-sized resources (the counted
+    const half_t* kb;                                        // waits below stay uniform, nothing is fetched)
+    const half_t* vb;
+    int t;
+    if constexpr (SK) {
+      live = i_u < u_end;
+      kb = i_kbase;
+      vb = i_vbase;
+      t = i_kt;
+    } else {
+      live = it_t < kt1;
+      kb = kbase;
+      vb = vbase;
+      t = it_t;
+    }
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(kb), 0, (int)(live ? k_bytes : 0u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(vb), 0, (int)(live ? v_bytes : 0u), 0x00020000);
     char* st = smem + it_stage * STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
       const int p = (wave + i * WAVES) & 7;
-      if (i < KP) dma16(rs_k, st + p * 1024, voff[i], it_t * k_step);
-      else dma16(rs_v, st + TILE_BYTES + p * 1024, voff[i], it_t * (KT * 2));
+      if (i < KP) dma16(rs_k, st + p * 1024, voff[i], t * k_step);
+      else dma16(rs_v, st + TILE_BYTES + p * 1024, voff[i], t * (KT * 2));
     }
-    ++it_t;
+    if constexpr (SK) {
+      ++i_u;
+      if (++i_kt == nt_all) {                                // on into the next query tile (another (sample, head) every q_tiles of them)
+        i_kt = 0;
+        ++i_qg;
+        if (i_u < u_end) issue_bases();
+      }
+    } else {
+      ++it_t;
+    }
     it_stage = (it_stage + 1 == D) ? 0 : it_stage + 1;
   };
-
-  // ---- fragment addressing: row l31 (+ 32 per sub-tile / channel tile), logical 16-B chunk 2 s + hi of MFMA step s;
-  //      the same offsets serve the K tile (step = 16 channels) and the permuted V^T tile (step = 16 keys) ----
-  const int fsw = (l31 >> 1) & 7;
-  int foff[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) foff[s] = l31 * 128 + (((s * 2 + hi) ^ fsw) * 16);
-  int aoff[4], noff[4];                                      // ... plus the ring stage of tile j / tile j+1
-#pragma unroll
-  for (int s = 0; s < 4; ++s) aoff[s] = foff[s];
 
   floatx16 oacc[2], sA[2], sB[2], negm;
 #pragma unroll
@@ -326,12 +366,15 @@ __global__ __launch_bounds__(WAVES * 64) void attn8_kernel(Attn8Args a) {
   };
 
   // ---- prologue: D - 1 tiles in flight, scores of tile 0, exact first running max ----
+  if (!SK || seg == 0) {   // (later segments of the balanced form: their first tiles were issued by the previous segment's steps, and K
+                           //  tile 0 landed for every wave behind the barrier of its last step)
 #pragma unroll
-  for (int p = 0; p < D - 1; ++p) {
-    asm volatile("" ::: "memory");                           // keep the DMA issue order: the counted waits rely on it
-    issue_tile();
+    for (int p = 0; p < D - 1; ++p) {
+      asm volatile("" ::: "memory");                         // keep the DMA issue order: the counted waits rely on it
+      issue_tile();
+    }
+    wait_vmcnt_barrier<(PPT - KP) + PPT * (D - 2)>();        // K tile 0 has landed for every wave
   }
-  wait_vmcnt_barrier<(PPT - KP) + PPT * (D - 2)>();          // K tile 0 has landed for every wave
   {
     half8 kf[2][4];
     read_k(kf, aoff);
@@ -348,7 +391,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn8_kernel(Attn8Args a) {
     }
   }
 
-  int st_cur = 0;                                            // ring stage of tile j
+  // (st_cur: ring stage of tile j)
   // One key tile.  cur: stabilised scores of tile j; nxt: receives those of tile j+1 (NEXT).
   auto step = [&](floatx16 (&cur)[2], floatx16 (&nxt)[2], auto next_c) {
     constexpr bool NEXT = decltype(next_c)::value;
@@ -417,6 +460,15 @@ __global__ __launch_bounds__(WAVES * 64) void attn8_kernel(Attn8Args a) {
     for (; j + 2 < nt; j += 2) {
       step(sA, sB, Tt{});
       step(sB, sA, Tt{});
+      if constexpr (SK) {
+        // the arrival of this workgroup's FIRST partial segment is posted here, four steps into a later segment: its stores are
+        // acknowledged (a wave's vector memory operations complete in order and the counted waits of steps 2 and 3 left only younger
+        // ones outstanding), nothing waits, and the other workgroups of that query tile find it long before they finish
+        if (j == 2 && pq0 >= 0 && !posted0) {
+          if (lane == 0) o0 = atomicAdd(a.cnt + pq0 * WAVES + wave, 1u);
+          posted0 = true;
+        }
+      }
     }
     if (nt - j == 2) {
       step(sA, sB, Tt{});
@@ -425,10 +477,9 @@ __global__ __launch_bounds__(WAVES * 64) void attn8_kernel(Attn8Args a) {
       step(sA, sB, Ff{});
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the zero-sized tail DMAs too, before the workgroup retires
+  if constexpr (!SK) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-sized tail DMAs too, before the workgroup retires
 
   if constexpr (SK) {
-    __syncthreads();                                         // every wave is through the ring: the next segment's DMAs may land
     const int g_first = (qg * nt_all) / a.upw, g_last = (qg * nt_all + nt_all - 1) / a.upw;
     const int nseg = g_last - g_first + 1;                   // workgroups that share this query tile's keys
     if (nseg > 1) {
@@ -469,11 +520,10 @@ __global__ __launch_bounds__(WAVES * 64) void attn8_kernel(Attn8Args a) {
 
   if constexpr (SK) {
     // ---- arrivals, one counter per (query tile, wave): a wave's 32 queries are merged by the wave of the LAST segment to arrive ----
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the write-through stores of both segments are acknowledged
-    unsigned o0 = 0, o1 = 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the partial stores are acknowledged (and the zero-sized tail DMAs done)
     if (a.dbg & 2) return;
     if (lane == 0) {
-      if (pq0 >= 0) o0 = atomicAdd(a.cnt + pq0 * WAVES + wave, 1u);
+      if (pq0 >= 0 && !posted0) o0 = atomicAdd(a.cnt + pq0 * WAVES + wave, 1u);
       if (pq1 >= 0) o1 = atomicAdd(a.cnt + pq1 * WAVES + wave, 1u);
     }
     o0 = __builtin_amdgcn_readfirstlane(o0);
@@ -564,14 +614,16 @@ int device_cus() {
 }
 
 // Do consecutive workgroup ids go round-robin over eight XCDs (id % 8), as the locality walks of this library assume?  Probed once with a
-// grid that over-subscribes the chip; the balanced form sends its partial results through the XCD's L2 only when this held for every
-// workgroup, and through HBM otherwise.
+// grid that over-subscribes the chip; the balanced form may send its partial results through the XCD's L2 (sc0) instead of past it (sc1)
+// only when this held for every workgroup - an experiment (see below), not the product path.
 __global__ void xcc_probe_kernel(unsigned* out) {
   if (threadIdx.x == 0) out[blockIdx.x] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 0xf;   // HW_REG_XCC_ID[3:0]
 }
 bool xcd_round_robin() {
   static const bool ok = [] {
-    if (tune_env_int("SD_ATTN8_SK_LOCAL", 1) == 0) return false;
+    // OFF unless SD_ATTN8_SK_LOCAL=1 (with SD_TUNE): measured equal to the agent-scope path (62.7 vs 62.4 us), and the agent-scope path
+    // does not depend on where the hardware places a workgroup (the probe below runs alone, not beside other streams' kernels)
+    if (tune_env_int("SD_ATTN8_SK_LOCAL", 0) == 0) return false;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(nullptr, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
     const int n = 8192;

@@ -1246,7 +1246,8 @@ int sd_op_qkv_ln(const void* x, const float* ln_weight, const float* ln_bias, co
 
 // The head of a SpatialTransformer (unet.py:553-556 norm -> proj_in, :583-586 norm1 -> :74-84 fused to_q | to_k | to_v) behind a 1x1 conv
 // that produces its input x = conv(x_in) and - like the resnet conv in front of it in the UNet - leaves the GroupNorm statistics of x in
-// its epilogue.  fused = 1: ONE launch (xattn_out.hip gn_proj_qkv_kernel); 0: GroupNorm launch, proj_in GEMM, LayerNorm-folded q|k|v GEMM.
+// its epilogue.  fused = 1: ONE launch (xattn_out.hip gn_proj_qkv_kernel; 2 / 3: its 64- / 32-token form); 0: GroupNorm launch, proj_in GEMM,
+// LayerNorm-folded q|k|v GEMM.
 // x_in (B, C, H, W) f16 NCHW; conv_w (C, C); gn_* (C) f32; proj_w (C, C), proj_bias (C); ln_* (C); wqkv (3C, C) -> out_h (B * HW, C),
 // out_qk (B * HW, 2C), out_vt (B, C, HW), all f16.  *entries = the producer's partial entries per (sample, group) the fused launch folded.
 int sd_op_gn_proj_qkv(const void* x_in, const void* conv_w, const float* gn_weight, const float* gn_bias, const void* proj_w,
@@ -1320,11 +1321,16 @@ int sd_op_gn_proj_qkv(const void* x_in, const void* conv_w, const float* gn_weig
     ws.partial_bytes = std::max(conv_workspace_bytes(d), std::max(conv_workspace_bytes(pd), conv_workspace_bytes(qd)));
     if (ws.partial_bytes) ws.partial = reinterpret_cast<float*>(sc.dev<char>(ws.partial_bytes));
     int n_entries = 0;
+    static const bool want_clk = tune_env_set("SD_GQ_CLOCK");   // phase clock of the one-launch kernel, printed to stderr
+    const size_t n_clk = (size_t)(M / 32) * 5 * 16;
+    long long* dclk = want_clk && fused ? sc.dev<long long>(n_clk) : nullptr;
     sc.timed(iters, ms, [&] {
       n_entries = launch_conv(d, ws, sc.stream);
       const bool have = n_entries >= 1 && n_entries <= 128;
       if (fused) {
         GnProjQkvDesc g;
+        g.clk = dclk;
+        g.tok = fused == 2 ? 64 : (fused == 3 ? 32 : 0);   // operator tests: the 64- / 32-token form whatever the launch's rule says
         g.x = dx;
         if (have) {
           g.gn_partial = partial; g.gn_gamma = dgw; g.gn_beta = dgb; g.gn_entries = n_entries;
@@ -1344,6 +1350,25 @@ int sd_op_gn_proj_qkv(const void* x_in, const void* conv_w, const float* gn_weig
       }
     });
     if (entries) *entries = (fused && n_entries >= 1 && n_entries <= 128) ? n_entries : 0;
+    if (dclk) {
+      std::vector<long long> hc(n_clk);
+      SD_HIP(hipMemcpy(hc.data(), dclk, n_clk * sizeof(long long), hipMemcpyDeviceToHost));
+      static const char* names[13] = {"start -> group statistics folded", "-> constants in LDS", "-> normalised tile in LDS", "-> proj_in MFMAs issued",
+                                      "-> h tile in LDS", "-> q MFMAs", "-> q stored", "-> k MFMAs", "-> k stored", "-> v MFMAs", "-> V^T stored", "", ""};
+      const size_t nw = n_clk / 16;
+      double total = 0;
+      for (int ph = 1; ph <= 11; ++ph) {
+        double sum = 0, mx = 0;
+        for (size_t w = 0; w < nw; ++w) {
+          const double dlt = (double)(hc[w * 16 + ph] - hc[w * 16 + ph - 1]);
+          sum += dlt;
+          mx = std::max(mx, dlt);
+        }
+        total += sum / nw;
+        fprintf(stderr, "gn_proj_qkv phase %2d  mean %8.0f  max %8.0f cycles   %s\n", ph, sum / nw, mx, names[ph - 1]);
+      }
+      fprintf(stderr, "gn_proj_qkv mean wave %8.0f cycles (%zu waves; the XCDs' counters are not synchronised: no launch-wide span)\n", total, nw);
+    }
     SD_HIP(hipMemcpy(out_h, dh, (size_t)M * C * 2, hipMemcpyDeviceToHost));
     SD_HIP(hipMemcpy(out_qk, dqk, (size_t)M * 2 * C * 2, hipMemcpyDeviceToHost));
     SD_HIP(hipMemcpy(out_vt, dvt, (size_t)B * C * HW * 2, hipMemcpyDeviceToHost));

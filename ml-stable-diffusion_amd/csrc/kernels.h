@@ -266,6 +266,8 @@ struct GnProjQkvDesc {
   int M = 0, C = 0, S = 0, ldT = 0;
   bool vt_perm = false;
   float q_scale = 1.f;
+  int tok = 0;                // tokens per workgroup: 0 = the launch's rule, 32 / 64 (operator tests)
+  long long* clk = nullptr;   // measurement builds of the operator test: [workgroup][wave][16] cycle stamps of the kernel's phases
 };
 bool gn_proj_qkv_ok(int C, int heads, int S, int M, int ldT, int G);
 void launch_gn_proj_qkv(const GnProjQkvDesc& d, hipStream_t s);

@@ -128,6 +128,38 @@ __device__ __forceinline__ void xo_gemm(XoW<BATCH, NBUF>& r, const half8* __rest
   }
 }
 
+// the same over TB blocks of 32 tokens of the LDS tile (rows tb * 32 + l31): a weight fragment fetched once feeds TB MFMAs per row block
+template <int K16, int BATCH, int NBUF, int TB>
+__device__ __forceinline__ void xo_gemm_tb(XoW<BATCH, NBUF>& r, const half8* __restrict__ wt, int nb0, const half_t* src, int ROW, int lane,
+                                           floatx16 (&acc)[TB][2]) {
+  static_assert(K16 % BATCH == 0 && K16 / BATCH >= NBUF - 1, "whole batches");
+  constexpr int NB = K16 / BATCH;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const half8* w0 = wt + (size_t)nb0 * K16 * 64 + lane;
+  const half8* w1 = w0 + (size_t)K16 * 64;
+  const half_t* srow = src + l31 * ROW + hi * 8;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int cur = b % NBUF, nxt = (b + NBUF - 1) % NBUF;
+    if (b + NBUF - 1 < NB) {
+#pragma unroll
+      for (int i = 0; i < BATCH; ++i) {
+        r.w[nxt][0][i] = w0[((b + NBUF - 1) * BATCH + i) * 64];
+        r.w[nxt][1][i] = w1[((b + NBUF - 1) * BATCH + i) * 64];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BATCH; ++i)
+#pragma unroll
+      for (int tb = 0; tb < TB; ++tb) {
+        const half8 xf = *reinterpret_cast<const half8*>(srow + tb * 32 * ROW + (b * BATCH + i) * 16);
+        acc[tb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r.w[cur][0][i], xf, acc[tb][0], 0, 0, 0);
+        acc[tb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(r.w[cur][1][i], xf, acc[tb][1], 0, 0, 0);
+      }
+    __builtin_amdgcn_sched_barrier(0);   // the later batches' loads stay NBUF - 1 batches ahead, no further
+  }
+}
+
 constexpr size_t xo_lds_bytes(int C) { return (size_t)2 * XO_TOK * (C + 8) * 2 + (size_t)4 * C * sizeof(float); }
 
 template <int NW, bool PRE>
@@ -568,42 +600,73 @@ struct GQArgs {
   half_t* vt;
   int M, S, ldT, vt_perm, gn_entries, gn_G;
   float gn_eps, ln_eps, q_scale;
+  long long* clk;   // phase clock (GnProjQkvDesc::clk): [workgroup][wave][16] cycle stamps, or nullptr
 };
 
 constexpr int GQ_WST = 5120;   // per-wave staging: [32 tokens][72] halves row-major (q / k) or [64 channels][40] halves transposed (V^T)
-template <int NW>
+template <int NW, int TB>
+constexpr size_t gq_xs_bytes() {   // the input tile [32 TB][C + 8] fp16, later the waves' staging regions
+  return std::max((size_t)32 * TB * (NW * 64 + 8) * 2, (size_t)NW * GQ_WST);
+}
+template <int NW, int TB>
 constexpr size_t gq_lds_bytes() {
-  return (size_t)2 * XO_TOK * (NW * 64 + 8) * 2 + (size_t)NW * GQ_WST + (size_t)9 * NW * 64 * sizeof(float) + 128 * sizeof(float);
+  return gq_xs_bytes<NW, TB>() + (size_t)32 * TB * (NW * 64 + 8) * 2 + (size_t)9 * NW * 64 * sizeof(float) + 128 * sizeof(float) +
+         (size_t)2 * NW * 32 * TB * sizeof(float2);
 }
 
-template <int NW>
+// TB: blocks of 32 tokens per workgroup.  2 where the grid still fills the chip (from two prompts per GPU): every weight fragment a wave
+// fetches from L2 then feeds two MFMAs per row block - at eight prompts per GPU the 32-token form re-reads 800 KB of weights per 32
+// tokens (1.6 GB per launch) and two resident workgroups per CU did not speed it up; the 64-token form runs 107 us against 125.
+template <int NW, int TB>
 __global__ __launch_bounds__(NW * 64) void gn_proj_qkv_kernel(GQArgs a) {
-  constexpr int C = NW * 64, ROW = C + 8, K16 = C / 16, NT = NW * 64;
+  constexpr int C = NW * 64, ROW = C + 8, K16 = C / 16, NT = NW * 64, TOK = 32 * TB;
   constexpr int BATCH = 4, NBUF = 3;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half_t* xs = reinterpret_cast<half_t*>(smem);                      // [32][ROW] GroupNorm'd input rows
-  half_t* hs = xs + XO_TOK * ROW;                                    // [32][ROW] proj_in output rows (LayerNorm source)
-  char* wst_all = reinterpret_cast<char*>(hs + XO_TOK * ROW);        // [NW][GQ_WST]
-  float* sconst = reinterpret_cast<float*>(wst_all + NW * GQ_WST);   // gsc[C] | gsh[C] | pb[C] | qb[3C] | qc[3C]
+  // the waves' staging regions [NW][GQ_WST] lie over the xs tile, which is dead once proj_in has consumed it (behind the barrier
+  // that publishes the h tile): 61 KB per workgroup instead of 82, TWO workgroups per CU where the grid has them (eight prompts per GPU)
+  char* wst_all = smem;
+  constexpr size_t XS_BYTES = gq_xs_bytes<NW, TB>();
+  half_t* hs = reinterpret_cast<half_t*>(smem + XS_BYTES);           // [TOK][ROW] proj_in output rows (LayerNorm source)
+  float* sconst = reinterpret_cast<float*>(hs + TOK * ROW);       // gsc[C] | gsh[C] | pb[C] | qb[3C] | qc[3C]
   float* gstat = sconst + 9 * C;                                     // mean[64] | rstd[64]
+  float2* lnp = reinterpret_cast<float2*>(gstat + 128);              // [2 NW][TOK] LayerNorm partial (sum, sumsq) of h per token
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
-  const int m_blk = blockIdx.x * XO_TOK;
-  const int b = m_blk / a.S;                                         // S % 32 == 0: one sample per workgroup
+  const int m_blk = blockIdx.x * TOK;
+  const int b = m_blk / a.S;                                         // S % TOK == 0: one sample per workgroup
   half_t* wst = reinterpret_cast<half_t*>(wst_all + wave * GQ_WST);
+  auto tick = [&](int i) {
+    if (a.clk && lane == 0) a.clk[((size_t)blockIdx.x * NW + wave) * 16 + i] = (long long)__builtin_readcyclecounter();
+  };
+  tick(0);
 
-  // ---- everything that can be requested up front: the input tile, the first weight batches of proj_in, the per-column constants ----
-  half8 xv[4];
+  // ---- everything that can be requested up front, in the order it is needed (a wave's loads return in order): the producer's
+  //      GroupNorm partials (8 lanes per group, each a contiguous run of 16 entries as 8 independent float4 loads, then a fixed
+  //      shuffle tree - a first version walked the entries in a dependent loop: 10 200 of the wave's 32 600 cycles,
+  //      tools/r6_gq_clock.py), the input tile, the first weight batches of proj_in, the per-column constants ----
+  const bool gn = a.gn_entries > 0;                                  // kernel-uniform
+  constexpr int per = 16;                                            // 8 lanes x 16 entries: launch_gn_proj_qkv takes <= 128 entries
+  floatx4 pv[per / 2];
+  const int fg = tid >> 3, fj = tid & 7;
+  if (gn && tid < 256 && fg < a.gn_G) {
+    const floatx4* src = reinterpret_cast<const floatx4*>(a.gn_partial + (((size_t)b * a.gn_G + fg) * kGnMaxSlabs + fj * per) * 2);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+    for (int k = 0; k < per / 2; ++k) {
+      const int e0 = fj * per + 2 * k;                               // first of the two entries of this float4
+      pv[k] = (e0 < a.gn_entries) ? src[k] : floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  half8 xv[4 * TB];
+#pragma unroll
+  for (int i = 0; i < 4 * TB; ++i) {
     const int idx = tid + NT * i, row = idx / (C / 8), c8 = idx - row * (C / 8);
     xv[i] = *reinterpret_cast<const half8*>(a.x + (size_t)(m_blk + row) * C + c8 * 8);
   }
   XoW<BATCH, NBUF> wr;
   xo_prefetch<K16, BATCH, NBUF>(wr, a.wp_t, 2 * wave, lane);
-  const bool gn = a.gn_entries > 0;                                  // kernel-uniform
   const float pb = a.p_bias[tid];
   const float gam = gn ? a.gn_gamma[tid] : 1.f, bet = gn ? a.gn_beta[tid] : 0.f;
   float qb[3], qc[3];
@@ -614,16 +677,20 @@ __global__ __launch_bounds__(NW * 64) void gn_proj_qkv_kernel(GQArgs a) {
   }
   const int cpg = C / a.gn_G;
   if (gn) {
-    // fold the producer's (sum, sumsq) partials of this sample: 8 lanes per group, fixed order (waves 0-3 hold the 32 groups x 8 lanes)
     if (tid < 256) {
-      const int g = tid >> 3, j = tid & 7;
+      const int g = fg, j = fj;
       float s = 0.f, q = 0.f;
       if (g < a.gn_G) {
-        const float2* src = reinterpret_cast<const float2*>(a.gn_partial) + ((size_t)b * a.gn_G + g) * kGnMaxSlabs;
-        for (int e = j; e < a.gn_entries; e += 8) {
-          const float2 v = src[e];
-          s += v.x;
-          q += v.y;
+#pragma unroll
+        for (int k = 0; k < per / 2; ++k) {
+          const int e0 = j * per + 2 * k;
+          floatx4 v = (e0 < a.gn_entries) ? pv[k] : floatx4{0.f, 0.f, 0.f, 0.f};
+          if (e0 + 1 >= a.gn_entries) {
+            v[2] = 0.f;
+            v[3] = 0.f;
+          }
+          s += v[0] + v[2];
+          q += v[1] + v[3];
         }
       }
 #pragma unroll
@@ -640,6 +707,7 @@ __global__ __launch_bounds__(NW * 64) void gn_proj_qkv_kernel(GQArgs a) {
       }
     }
     __syncthreads();
+    tick(1);
     const int g = tid / cpg;
     const float sc = gstat[64 + g] * gam;
     sconst[tid] = sc;
@@ -652,8 +720,9 @@ __global__ __launch_bounds__(NW * 64) void gn_proj_qkv_kernel(GQArgs a) {
     sconst[6 * C + p * C + tid] = qc[p];
   }
   __syncthreads();                                                   // scale / shift and the constants are visible
+  tick(2);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 4 * TB; ++i) {
     const int idx = tid + NT * i, row = idx / (C / 8), c8 = idx - row * (C / 8);
     half8 v = xv[i];
     if (gn) {
@@ -663,18 +732,26 @@ __global__ __launch_bounds__(NW * 64) void gn_proj_qkv_kernel(GQArgs a) {
     *reinterpret_cast<half8*>(xs + row * ROW + c8 * 8) = v;
   }
   __syncthreads();                                                   // the normalised tile is in LDS
+  tick(3);
 
   // ---- proj_in: h^T[64 * wave ..][32] = Wp . xn^T + b -> LDS tile (fp16, as the tensor the separate launch stores) ----
-  floatx16 acc[2];
+  floatx16 acc[TB][2];
+  auto zero_acc = [&]() {
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+    for (int tb = 0; tb < TB; ++tb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  float d1 = 0.f, d2 = 0.f;
-  xo_gemm<K16, BATCH, NBUF, false>(wr, a.wp_t, 2 * wave, xs, ROW, lane, acc, d1, d2);
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tb][j][r] = 0.f;
+  };
+  zero_acc();
+  xo_gemm_tb<K16, BATCH, NBUF, TB>(wr, a.wp_t, 2 * wave, xs, ROW, lane, acc);
+  tick(4);
   xo_prefetch<K16, BATCH, NBUF>(wr, a.wqkv_t, 2 * wave, lane);       // q pass: first batches in flight under the epilogue and the barrier
-  {
-    half_t* hrow = hs + l31 * ROW + wave * XO_D + 4 * hi;
+#pragma unroll
+  for (int tb = 0; tb < TB; ++tb) {
+    half_t* hrow = hs + (tb * 32 + l31) * ROW + wave * XO_D + 4 * hi;
+    float p1 = 0.f, p2 = 0.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -682,79 +759,93 @@ __global__ __launch_bounds__(NW * 64) void gn_proj_qkv_kernel(GQArgs a) {
         const floatx4 b1 = *reinterpret_cast<const floatx4*>(sconst + 2 * C + wave * XO_D + j * 32 + 8 * g + 4 * hi);
         half4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (half_t)(acc[j][4 * g + e] + b1[e]);
+        for (int e = 0; e < 4; ++e) {
+          o[e] = (half_t)(acc[tb][j][4 * g + e] + b1[e]);
+          const float r = (float)o[e];                               // norm1 sees the fp16 tensor, as behind the separate launch
+          p1 += r;
+          p2 = fmaf(r, r, p2);
+        }
         *reinterpret_cast<half4*>(hrow + j * 32 + 8 * g) = o;
       }
+    lnp[(wave * 2 + hi) * TOK + tb * 32 + l31] = float2{p1, p2};     // this lane's 32 of the token's 320 channels
   }
   __syncthreads();                                                   // h of every channel block is in the tile
+  tick(5);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {                                      // the residual stream leaves in whole rows
+  for (int i = 0; i < 4 * TB; ++i) {                                 // the residual stream leaves in whole rows
     const int idx = tid + NT * i, row = idx / (C / 8), c8 = idx - row * (C / 8);
     *reinterpret_cast<half8*>(a.h + (size_t)(m_blk + row) * C + c8 * 8) = *reinterpret_cast<const half8*>(hs + row * ROW + c8 * 8);
   }
 
   // ---- q | k | v: three passes over the h tile; LayerNorm statistics of the token rows from the fragments of the first ----
-  float la = 1.f, lb = 0.f;
+  float la[TB], lb[TB];                                              // LayerNorm of token tb * 32 + l31: out = acc * la + lb * colsum + bias
+#pragma unroll
+  for (int tb = 0; tb < TB; ++tb) {
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2 * NW; ++i) {                               // fixed order, every lane of the token the same sum
+      const float2 v = lnp[i * TOK + tb * 32 + l31];
+      t1 += v.x;
+      t2 += v.y;
+    }
+    const float inv_k = 1.0f / (float)C;
+    const float mean = t1 * inv_k;
+    la[tb] = rsqrtf(fmaxf(t2 * inv_k - mean * mean, 0.f) + a.ln_eps);
+    lb[tb] = -la[tb] * mean;
+  }
   const int sp0 = m_blk - b * a.S;
 #pragma unroll
   for (int p = 0; p < 3; ++p) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    float s1 = 0.f, s2 = 0.f;
-    if (p == 0) xo_gemm<K16, BATCH, NBUF, true>(wr, a.wqkv_t, p * (C / 32) + 2 * wave, hs, ROW, lane, acc, s1, s2);
-    else xo_gemm<K16, BATCH, NBUF, false>(wr, a.wqkv_t, p * (C / 32) + 2 * wave, hs, ROW, lane, acc, s1, s2);
+    zero_acc();
+    xo_gemm_tb<K16, BATCH, NBUF, TB>(wr, a.wqkv_t, p * (C / 32) + 2 * wave, hs, ROW, lane, acc);
     if (p < 2) xo_prefetch<K16, BATCH, NBUF>(wr, a.wqkv_t, (p + 1) * (C / 32) + 2 * wave, lane);
-    if (p == 0) {
-      const float inv_k = 1.0f / (float)C;
-      const float t1 = xo_xor32_sumf(s1), t2 = xo_xor32_sumf(s2);
-      const float mean = t1 * inv_k;
-      la = rsqrtf(fmaxf(t2 * inv_k - mean * mean, 0.f) + a.ln_eps);
-      lb = -la * mean;
-    }
+    tick(6 + 2 * p);
     const float qs = p == 0 ? a.q_scale : 1.f;
-    // acc[j][4 g + e]: channel j*32 + 8 g + 4 hi + e of the wave's block, token l31
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int tb = 0; tb < TB; ++tb) {
+      // acc[tb][j][4 g + e]: channel j*32 + 8 g + 4 hi + e of the wave's block, token tb * 32 + l31
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int nl = j * 32 + 8 * g + 4 * hi;
-        const floatx4 b4 = *reinterpret_cast<const floatx4*>(sconst + 3 * C + p * C + wave * XO_D + nl);
-        const floatx4 c4 = *reinterpret_cast<const floatx4*>(sconst + 6 * C + p * C + wave * XO_D + nl);
-        half4 o;
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (half_t)(fmaf(acc[j][4 * g + e], la, fmaf(lb, c4[e], b4[e])) * qs);
-        if (p < 2) {
-          *reinterpret_cast<half4*>(wst + l31 * 72 + nl) = o;
-        } else {
+        for (int g = 0; g < 4; ++g) {
+          const int nl = j * 32 + 8 * g + 4 * hi;
+          const floatx4 b4 = *reinterpret_cast<const floatx4*>(sconst + 3 * C + p * C + wave * XO_D + nl);
+          const floatx4 c4 = *reinterpret_cast<const floatx4*>(sconst + 6 * C + p * C + wave * XO_D + nl);
+          half4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) wst[(nl + e) * 40 + l31] = o[e];
+          for (int e = 0; e < 4; ++e) o[e] = (half_t)(fmaf(acc[tb][j][4 * g + e], la[tb], fmaf(lb[tb], c4[e], b4[e])) * qs);
+          if (p < 2) {
+            *reinterpret_cast<half4*>(wst + l31 * 72 + nl) = o;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wst[(nl + e) * 40 + l31] = o[e];
+          }
         }
-      }
-    // the wave's own staging region back out (DS operations of one wave execute in order: no barrier)
-    if (p < 2) {
+      // the wave's own staging region back out (DS operations of one wave execute in order: no barrier)
+      if (p < 2) {
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int id = lane + 64 * it, tok = id >> 3, c = id & 7;
-        const half8 v = *reinterpret_cast<const half8*>(wst + tok * 72 + c * 8);
-        *reinterpret_cast<half8*>(a.qk + (size_t)(m_blk + tok) * (2 * C) + p * C + wave * XO_D + c * 8) = v;
-      }
-    } else {
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int id = lane + 64 * it, ch = id >> 2, c = id & 3;
-        half8 v;
-        if (a.vt_perm) {   // chunk c = tokens 16 j + 4 o + {0..3} and 16 j + 8 + 4 o + {0..3}  (j = c >> 1, o = c & 1): AttnDesc::vt_perm
-          const half_t* src = wst + ch * 40 + (c >> 1) * 16 + (c & 1) * 4;
-          const half4 lo = *reinterpret_cast<const half4*>(src), up = *reinterpret_cast<const half4*>(src + 8);
-          v = half8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
-        } else {
-          v = *reinterpret_cast<const half8*>(wst + ch * 40 + c * 8);
+        for (int it = 0; it < 4; ++it) {
+          const int id = lane + 64 * it, tok = id >> 3, c = id & 7;
+          const half8 v = *reinterpret_cast<const half8*>(wst + tok * 72 + c * 8);
+          *reinterpret_cast<half8*>(a.qk + (size_t)(m_blk + tb * 32 + tok) * (2 * C) + p * C + wave * XO_D + c * 8) = v;
         }
-        *reinterpret_cast<half8*>(a.vt + ((size_t)b * C + wave * XO_D + ch) * a.ldT + sp0 + c * 8) = v;
+      } else {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int id = lane + 64 * it, ch = id >> 2, c = id & 3;
+          half8 v;
+          if (a.vt_perm) {   // chunk c = tokens 16 j + 4 o + {0..3} and 16 j + 8 + 4 o + {0..3}  (j = c >> 1, o = c & 1): AttnDesc::vt_perm
+            const half_t* src = wst + ch * 40 + (c >> 1) * 16 + (c & 1) * 4;
+            const half4 lo = *reinterpret_cast<const half4*>(src), up = *reinterpret_cast<const half4*>(src + 8);
+            v = half8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+          } else {
+            v = *reinterpret_cast<const half8*>(wst + ch * 40 + c * 8);
+          }
+          *reinterpret_cast<half8*>(a.vt + ((size_t)b * C + wave * XO_D + ch) * a.ldT + sp0 + tb * 32 + c * 8) = v;
+        }
       }
     }
+    tick(7 + 2 * p);
   }
 }
 
@@ -820,13 +911,26 @@ void launch_gn_proj_qkv(const GnProjQkvDesc& d, hipStream_t s) {
              kInvalidArgument, "gn_proj_qkv: C=%d S=%d M=%d ldT=%d entries=%d", d.C, d.S, d.M, d.ldT, d.gn_entries);
   GQArgs a{d.x, d.gn_partial, d.gn_gamma, d.gn_beta, reinterpret_cast<const half8*>(d.wp_t), d.p_bias, d.h,
            reinterpret_cast<const half8*>(d.wqkv_t), d.qkv_bias, d.qkv_colsum, d.qk, d.vt, d.M, d.S, d.ldT, d.vt_perm ? 1 : 0, d.gn_entries,
-           d.gn_groups, d.gn_eps, d.ln_eps, d.q_scale};
-  constexpr size_t lds = gq_lds_bytes<5>();
-  static_assert(lds <= 160 * 1024, "LDS");
-  auto k = gn_proj_qkv_kernel<5>;
-  static DynLdsOnce once;
-  once.set(k, lds);
-  hipLaunchKernelGGL(k, dim3(d.M / XO_TOK), dim3(5 * 64), lds, s, a);
+           d.gn_groups, d.gn_eps, d.ln_eps, d.q_scale, d.clk};
+  // 64-token workgroups where they still give every CU one (from two prompts per GPU, M = 16 384): same box, 32 vs 64 tokens: one prompt
+  // 4.303 vs 4.326 ms (worse: 128 workgroups), two 6.71 vs 6.69, four 10.74 vs 10.70, eight 18.40 vs 18.31.  SD_GQ_TOK = 32 / 64 (with
+  // SD_TUNE): A/B
+  static const int tok_env = tune_env_int("SD_GQ_TOK", 0);
+  const int want = d.tok ? d.tok : tok_env;
+  const bool two = want ? want == 64 : (d.M / 64 >= 256);
+  if (two && d.S % 64 == 0) {
+    constexpr size_t lds = gq_lds_bytes<5, 2>();
+    auto k = gn_proj_qkv_kernel<5, 2>;
+    static DynLdsOnce once;
+    once.set(k, lds);
+    hipLaunchKernelGGL(k, dim3(d.M / 64), dim3(5 * 64), lds, s, a);
+  } else {
+    constexpr size_t lds = gq_lds_bytes<5, 1>();
+    auto k = gn_proj_qkv_kernel<5, 1>;
+    static DynLdsOnce once;
+    once.set(k, lds);
+    hipLaunchKernelGGL(k, dim3(d.M / XO_TOK), dim3(5 * 64), lds, s, a);
+  }
   SD_HIP(hipGetLastError());
 }
 

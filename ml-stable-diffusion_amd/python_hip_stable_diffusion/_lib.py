@@ -408,7 +408,7 @@ def qkv_ln(x, ln_weight, ln_bias, w, batch, q_scale=1.0, vt_perm=True, eps=1e-5,
 def gn_proj_qkv(x_in, conv_w, gn_weight, gn_bias, proj_w, proj_bias, ln_weight, ln_bias, wqkv, groups=32, gn_eps=1e-6, ln_eps=1e-5,
                 q_scale=1.0, vt_perm=True, fused=True, iters=1):
     """conv1x1 (producer, leaves GroupNorm statistics) -> GroupNorm -> proj_in -> LayerNorm -> fused q|k|v; fused: the last four in ONE
-    launch.  Returns (h (B * HW, C), qk (B * HW, 2C), vt (B, C, HW), entries, ms)."""
+    launch (2 / 3: its 64- / 32-token form).  Returns (h (B * HW, C), qk (B * HW, 2C), vt (B, C, HW), entries, ms)."""
     x_in, conv_w, proj_w, wqkv = f16(x_in), f16(conv_w), f16(proj_w), f16(wqkv)
     B, Cn, H, W = x_in.shape
     M = B * H * W

@@ -249,7 +249,7 @@ def gn_proj_qkv_ref(x_in, conv_w, gn_w, gn_b, proj_w, proj_b, ln_w, ln_b, wqkv, 
 
 
 @pytest.mark.parametrize("batch,hh,ww", [(2, 64, 64), (1, 32, 32), (3, 16, 32)], ids=lambda v: str(v))
-@pytest.mark.parametrize("fused", [True, False], ids=["one-launch", "three-launches"])
+@pytest.mark.parametrize("fused", [1, 2, 0], ids=["one-launch", "one-launch-64-tokens", "three-launches"])
 @pytest.mark.parametrize("perm", [True, False], ids=["vt-perm", "vt-plain"])
 def test_gn_proj_qkv_matches_torch(batch, hh, ww, fused, perm):
     c = 320
@@ -287,6 +287,8 @@ def test_gn_proj_qkv_one_launch_vs_three():
             h16(rs.randn(3 * c, c) / np.sqrt(c)))
     h1, qk1, vt1, e1, _ = _lib.gn_proj_qkv(*args, q_scale=0.18, fused=True)
     h0, qk0, vt0, _, _ = _lib.gn_proj_qkv(*args, q_scale=0.18, fused=False)
+    h64, qk64, vt64, e64, _ = _lib.gn_proj_qkv(*args, q_scale=0.18, fused=2)
+    assert e64 == e1 and np.array_equal(h1, h64) and np.array_equal(qk1, qk64) and np.array_equal(vt1, vt64), "64-token workgroups: the same bits"
     close(h1, h0.astype(np.float32), "h one launch vs three", min_psnr=66.0)
     close(qk1, qk0.astype(np.float32), "q|k one launch vs three", min_psnr=60.0)
     close(vt1, vt0.astype(np.float32), "V^T one launch vs three", min_psnr=60.0)

@@ -4,6 +4,8 @@
 //             segments per step),
 //   layout 1: the same bytes pre-tiled so that a step's 8 KiB are contiguous?
 // hipcc --offload-arch=gfx950 -O3 tools/ubench/wstream.hip -o tools/ubench/wstream && tools/ubench/wstream
+// SD_PRE=1 (round 6): between the flush and the timed stream another kernel READS the matrix once (what a prefetch issued by the
+// previous launch of the step would leave behind: the bytes in the Infinity Cache and in whichever XCD's L2 touched them)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -59,6 +61,8 @@ __global__ void k_flush(unsigned* p, size_t n, int dirty, unsigned* sink) {
   if (acc == 0x12345678u) sink[0] = acc;
 }
 
+static size_t pre_bytes = 0;
+static int pre_grid = 2048;
 template <int DEPTH>
 float run(const char* w, int K, int n_tiles, int splits, int steps, int nsteps, unsigned* flush, size_t flush_bytes, unsigned* sink,
           hipEvent_t e0, hipEvent_t e1) {
@@ -66,6 +70,8 @@ float run(const char* w, int K, int n_tiles, int splits, int steps, int nsteps, 
   for (int r = 0; r < 4; ++r) {
     static const int dirty = getenv("SD_FLUSH_DIRTY") != nullptr;
     hipLaunchKernelGGL(k_flush, dim3(2048), dim3(256), 0, 0, flush, flush_bytes / 4, dirty, sink);
+    static const int pre = getenv("SD_PRE") != nullptr;
+    if (pre) hipLaunchKernelGGL(k_flush, dim3(pre_grid), dim3(256), 0, 0, (unsigned*)w, pre_bytes / 4, 0, sink);
     hipEventRecord(e0, 0);
     hipLaunchKernelGGL(k_stream<DEPTH>, dim3(n_tiles, splits), dim3(256), 0, 0, w, K * 2, steps, nsteps, 0, sink);
     hipEventRecord(e1, 0);
@@ -95,6 +101,8 @@ int main() {
     CK(hipMalloc(&w, bytes));
     CK(hipMemset(w, 1, bytes));
     const int n_tiles = c.N / 64, nsteps = c.K / 64;
+    pre_bytes = bytes;
+    pre_grid = getenv("SD_PRE_GRID") ? atoi(getenv("SD_PRE_GRID")) : 2048;
     for (int splits : {1, 2, 5, 10, 20, 30, 45, 60, 90, 180}) {
       if (nsteps % splits) continue;
       const int steps = nsteps / splits, wgs = n_tiles * splits;
