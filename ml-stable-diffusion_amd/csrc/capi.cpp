@@ -69,6 +69,15 @@ struct Scratch {
   template <typename F>
   void timed(int iters, float* ms, F&& launch) {
     if (iters < 1) iters = 1;
+    static const bool poison = tune_env_set("SD_POISON_LDS");   // debug: NaN patterns into every CU's LDS in front of the launches
+    if (poison) {   // (the result the caller reads is the last launch's)
+      launch();     // sets kernel attributes
+      launch_lds_poison(stream);
+      launch();
+      SD_HIP(hipStreamSynchronize(stream));
+      if (ms) *ms = 0.f;
+      return;
+    }
     launch();   // warm (also sets kernel attributes)
     SD_HIP(hipStreamSynchronize(stream));
     // SD_BENCH_COLD=1: every timed launch starts with cold caches like a kernel inside the UNet step does (its

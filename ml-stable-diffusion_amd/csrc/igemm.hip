@@ -1954,11 +1954,14 @@ __global__ __launch_bounds__(256) void conv_small_cin_kernel(IgemmArgs a, int si
   __shared__ float patch[SC_PIX][SC_KMAX];
   const int m0 = blockIdx.x * SC_PIX;
   const int Hup = a.Hi * a.up, Wup = a.Wi * a.up, upshift = a.up >> 1;
-  for (int idx = threadIdx.x; idx < SC_PIX * a.K; idx += blockDim.x) {
-    const int p = idx / a.K, k = idx - p * a.K;
+  // every column of a patch row is written - K .. SC_KMAX - 1 with zeros: the dot product below runs over all SC_KMAX columns against
+  // zero weights there, and 0 * (whatever the LDS held: NaN bit patterns on a fresh box) is NaN (round 6: the tiny test UNet's
+  // K = 48 to_k projection failed as the first launch of a process, tools/ubench/poison.hip + SD_NAN_TRACE)
+  for (int idx = threadIdx.x; idx < SC_PIX * SC_KMAX; idx += blockDim.x) {
+    const int p = idx / SC_KMAX, k = idx - p * SC_KMAX;
     const int m = m0 + p;
     float v = 0.f;
-    if (m < a.M) {
+    if (m < a.M && k < a.K) {
       const int b = m / a.HoWo;
       const int rem = m - b * a.HoWo;
       const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
@@ -1983,7 +1986,7 @@ __global__ __launch_bounds__(256) void conv_small_cin_kernel(IgemmArgs a, int si
       if (m >= a.M) break;
       float acc = bv;
 #pragma unroll
-      for (int k = 0; k < SC_KMAX; ++k) acc += w[k] * patch[p][k];   // patch rows beyond K are never read as non-zero w
+      for (int k = 0; k < SC_KMAX; ++k) acc += w[k] * patch[p][k];   // (columns beyond K: zero weights x zero patch)
       if (a.temb) acc += a.temb[(size_t)(m / a.HoWo) * a.temb_stride + n];
       if (a.res) acc += (float)a.res[(size_t)m * a.N + n];
       if (silu_out) acc = acc / (1.f + __expf(-acc));

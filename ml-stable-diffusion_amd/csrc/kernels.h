@@ -391,4 +391,7 @@ void launch_loop_prep(const float* latents, half_t* sample, float* tbuf, LoopTab
 void launch_cfg_sched_step(const float* noise_pred, float* latents, float* eps_hist, LoopTables t, float guidance,
                            int Bimg, int CHW, int cfg, int hist, hipStream_t s);
 
+void launch_lds_poison(hipStream_t s);   // debug (SD_POISON_LDS): NaN patterns into every CU's LDS
+void launch_count_nonfinite_half(const void* p, size_t bytes, unsigned long long* out, hipStream_t s);   // debug scan (SD_NAN_TRACE)
+
 }  // namespace sd

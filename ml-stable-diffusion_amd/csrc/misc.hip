@@ -371,4 +371,40 @@ void launch_cfg_sched_step(const float* noise_pred, float* latents, float* eps_h
   SD_HIP(hipGetLastError());
 }
 
+// Debug (SD_POISON_LDS=1 with SD_TUNE): fill the LDS of every CU with NaN bit patterns before a launch.  A kernel that reads LDS it
+// never wrote behind a zero weight is right on benign leftovers and wrong on a fresh box (0 * NaN); with this in front of every
+// launch the GPU suite finds such reads (round 6: conv_small_cin_kernel's patch columns beyond K).
+__global__ __launch_bounds__(1024) void lds_poison_kernel(unsigned* sink) {
+  extern __shared__ unsigned lds_words[];
+  const int n = 160 * 1024 / 4;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) lds_words[i] = (i & 1) ? 0x7e007e00u : (0x7fc00000u ^ (unsigned)(threadIdx.x << 3));
+  __syncthreads();
+  unsigned acc = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) acc ^= lds_words[i];
+  if (acc == 0x12345u) sink[0] = acc;   // (never true: keeps the stores)
+}
+void launch_lds_poison(hipStream_t s) {
+  static unsigned* sink = [] {
+    unsigned* p = nullptr;
+    (void)hipMalloc(&p, 256);
+    return p;
+  }();
+  static DynLdsOnce once;
+  once.set(lds_poison_kernel, 160 * 1024);
+  hipLaunchKernelGGL(lds_poison_kernel, dim3(512), dim3(1024), 160 * 1024, s, sink);
+  SD_HIP(hipGetLastError());
+}
+
+// Debug scan (SD_NAN_TRACE): how many fp16 values of a buffer are Inf / NaN (exponent all ones).
+__global__ void count_nonfinite_half_kernel(const unsigned short* __restrict__ p, size_t n, unsigned long long* __restrict__ out) {
+  unsigned long long c = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    c += (p[i] & 0x7c00u) == 0x7c00u;
+  if (c) atomicAdd(out, c);
+}
+void launch_count_nonfinite_half(const void* p, size_t bytes, unsigned long long* out, hipStream_t s) {
+  hipLaunchKernelGGL(count_nonfinite_half_kernel, dim3(1024), dim3(256), 0, s, reinterpret_cast<const unsigned short*>(p), bytes / 2, out);
+  SD_HIP(hipGetLastError());
+}
+
 }  // namespace sd

@@ -86,9 +86,12 @@ class Arena {
   template <typename T>
   T* alloc_n(size_t n) { return reinterpret_cast<T*>(alloc(n * sizeof(T))); }
   size_t bytes() const { return total_; }
+  const std::vector<void*>& chunks() const { return chunks_; }       // (debug scans: SD_NAN_TRACE)
+  const std::vector<size_t>& chunk_bytes() const { return sizes_; }
 
  private:
   std::vector<void*> chunks_;
+  std::vector<size_t> sizes_;
   size_t cap_ = 0, cur_ = 0, total_ = 0;
 };
 

@@ -1586,7 +1586,39 @@ void UNet::set_attention(int impl) {
 
 void UNet::run_ops(const std::vector<Op>& ops) { run_ops_on(ops, stream_); }
 void UNet::run_ops_on(const std::vector<Op>& ops, hipStream_t s) {
-  for (auto& op : ops) op(s);
+  // SD_NAN_TRACE=1 (with SD_TUNE; eager launches only): after every op the whole arena is scanned for fp16 Inf / NaN patterns and the op
+  // after which their number changes is named on stderr (fp32 regions give false positives - read the list with the op in mind).
+  static const bool trace = tune_env_set("SD_NAN_TRACE");
+  if (trace) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
+      unsigned long long* d = nullptr;
+      SD_HIP(hipMalloc(&d, sizeof(unsigned long long)));
+      auto scan = [&]() {
+        SD_HIP(hipMemsetAsync(d, 0, sizeof(unsigned long long), s));
+        for (size_t i = 0; i < arena_.chunks().size(); ++i) launch_count_nonfinite_half(arena_.chunks()[i], arena_.chunk_bytes()[i], d, s);
+        unsigned long long h = 0;
+        SD_HIP(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, s));
+        SD_HIP(hipStreamSynchronize(s));
+        return h;
+      };
+      unsigned long long last = scan();
+      fprintf(stderr, "nan-trace: %llu non-finite fp16 patterns in the arena before the list\n", last);
+      for (auto& op : ops) {
+        op(s);
+        const unsigned long long now = scan();
+        if (now != last) fprintf(stderr, "nan-trace: %llu -> %llu after  %s\n", last, now, op.label.c_str());
+        last = now;
+      }
+      (void)hipFree(d);
+      return;
+    }
+  }
+  static const bool poison = tune_env_set("SD_POISON_LDS");   // debug: NaN patterns into every CU's LDS in front of every op
+  for (auto& op : ops) {
+    if (poison) launch_lds_poison(s);
+    op(s);
+  }
 }
 
 // Stream capture that cannot leave the stream in capture mode: an op that throws between Begin and
@@ -1649,6 +1681,8 @@ void UNet::run_main(bool with_time) {
       SD_HIP(hipStreamWaitEvent(stream_, ev_cn_join_, 0));
       cn_join_pending_ = false;
     }
+    static const bool poison = tune_env_set("SD_POISON_LDS");
+    if (poison) launch_lds_poison(stream_);
     main_ops_[i](stream_);
   }
   SD_REQUIRE(!cn_join_pending_, kInternal, "forked ControlNets were never joined");

@@ -31,6 +31,7 @@ void* Arena::alloc(size_t bytes) {
     SD_HIP(hipMemset(p, 0, chunk));
     SD_HIP(hipDeviceSynchronize());   // the memset runs on the null stream; handles use their own
     chunks_.push_back(p);
+    sizes_.push_back(chunk);
     cap_ = chunk;
     cur_ = 0;
     total_ += chunk;

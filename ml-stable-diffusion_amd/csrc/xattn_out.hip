@@ -160,7 +160,9 @@ __device__ __forceinline__ void xo_gemm_tb(XoW<BATCH, NBUF>& r, const half8* __r
   }
 }
 
-constexpr size_t xo_lds_bytes(int C) { return (size_t)2 * XO_TOK * (C + 8) * 2 + (size_t)4 * C * sizeof(float); }
+constexpr size_t xo_lds_bytes(int C) {   // two activation tiles, the per-column constants, PRE: LayerNorm partials [2 C / 64][32] (sum, sumsq)
+  return (size_t)2 * XO_TOK * (C + 8) * 2 + (size_t)4 * C * sizeof(float) + (size_t)2 * (C / 64) * 32 * 2 * sizeof(float);
+}
 
 template <int NW, bool PRE>
 __global__ __launch_bounds__(NW * 64) void xattn_out_kernel(XOArgs a) {
@@ -171,6 +173,7 @@ __global__ __launch_bounds__(NW * 64) void xattn_out_kernel(XOArgs a) {
   half_t* xs = reinterpret_cast<half_t*>(smem);            // [32][ROW]  h1 rows: LayerNorm source, residual
   half_t* os = xs + XO_TOK * ROW;                          // [32][ROW]  a2 (all heads); PRE: a1 until phase 0 is over
   float* sconst = reinterpret_cast<float*>(os + XO_TOK * ROW);   // [C] q bias | [C] q colsum | [C] out bias | [C] first out bias (PRE)
+  float2* lnp = reinterpret_cast<float2*>(sconst + 4 * C);       // PRE: [2 NW][32] norm2 partials of h1 per token
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = head = 64-channel output block
@@ -242,17 +245,30 @@ __global__ __launch_bounds__(NW * 64) void xattn_out_kernel(XOArgs a) {
     xo_gemm<K16, BATCH, NBUF, false>(wr, a.wo1_t, 2 * wave, os, ROW, lane, acc, d1, d2);
     xo_prefetch<K16, BATCH, NBUF>(wr, a.wq_t, 2 * wave, lane);   // phase 1's first batches: in flight under the epilogue and the barrier
     half_t* hrow = xs + l31 * ROW + wave * XO_D + 4 * hi;
-#pragma unroll
+    float p1 = 0.f, p2 = 0.f;                              // norm2's statistics from here (the fp16 h1 the tile holds), not from the
+#pragma unroll                                             // q pass's K loop: 1 300 cycles per wave less (r6_gq_clock.py on the head kernel)
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const floatx4 b1 = *reinterpret_cast<const floatx4*>(sconst + 3 * C + wave * XO_D + j * 32 + 8 * g + 4 * hi);
         half4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (half_t)((float)(half_t)(acc[j][4 * g + e] + b1[e]) + (float)h0r[j][g][e]);
+        for (int e = 0; e < 4; ++e) {
+          o[e] = (half_t)((float)(half_t)(acc[j][4 * g + e] + b1[e]) + (float)h0r[j][g][e]);
+          const float r = (float)o[e];
+          p1 += r;
+          p2 = fmaf(r, r, p2);
+        }
         *reinterpret_cast<half4*>(hrow + j * 32 + 8 * g) = o;
       }
+    lnp[(wave * 2 + hi) * 32 + l31] = float2{p1, p2};
     __syncthreads();                                       // h1 of every channel block is in the tile; nobody reads a1 any more
+#pragma unroll
+    for (int i = 0; i < 2 * NW; ++i) {                     // fixed order; both half-waves of a token hold the full sums
+      const float2 v = lnp[i * 32 + l31];
+      ln_s1 += v.x;
+      ln_s2 += v.y;
+    }
   }
 
   // ---- phase 1: q^T of head `wave`, LayerNorm statistics of the token rows on the side ----
@@ -260,7 +276,12 @@ __global__ __launch_bounds__(NW * 64) void xattn_out_kernel(XOArgs a) {
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  xo_gemm<K16, BATCH, NBUF, true>(wr, a.wq_t, 2 * wave, xs, ROW, lane, acc, ln_s1, ln_s2);
+  if constexpr (PRE) {
+    float d1 = 0.f, d2 = 0.f;
+    xo_gemm<K16, BATCH, NBUF, false>(wr, a.wq_t, 2 * wave, xs, ROW, lane, acc, d1, d2);
+  } else {
+    xo_gemm<K16, BATCH, NBUF, true>(wr, a.wq_t, 2 * wave, xs, ROW, lane, acc, ln_s1, ln_s2);
+  }
 
   // ---- V^T fragments of this head (O^T[d][q] = V^T . P^T): lane (l31 = channel of the tile, hi), step (kt, s2): keys
   // kt*32 + s2*16 + 4*hi + {0..3, 8..11}; columns [L, ldv) are zero by contract, columns >= ldv do not exist.  Five heads: requested
@@ -288,7 +309,7 @@ __global__ __launch_bounds__(NW * 64) void xattn_out_kernel(XOArgs a) {
   half8 qf[2][2];
   {
     const float inv_k = 1.0f / (float)C;
-    const float s1 = xo_xor32_sumf(ln_s1), s2 = xo_xor32_sumf(ln_s2);
+    const float s1 = PRE ? ln_s1 : xo_xor32_sumf(ln_s1), s2 = PRE ? ln_s2 : xo_xor32_sumf(ln_s2);
     const float mean = s1 * inv_k;
     const float var = fmaxf(s2 * inv_k - mean * mean, 0.f);
     const float ln_a = rsqrtf(var + a.ln_eps);
