@@ -330,3 +330,17 @@ def test_attention8_balanced_form(batch, heads, sq, sk, upw):
     close(got, classic.astype(np.float32), "balanced vs classic grid", min_psnr=66.0, rel=4e-3)
     again, _ = _lib.attention("ORIGINAL", q, k, v, heads, 64, variant=100 + upw, iters=3)    # the counters come back to zero; arrival order does not matter
     assert np.array_equal(got, again), "bit-reproducible"
+
+
+# ---- results must not depend on what the LDS held before a launch (LAB_NOTES Finding 20) ------------------------------------------
+def test_tiny_unet_behind_poisoned_lds():
+    """SD_POISON_LDS=1 (with SD_TUNE) fills every CU's LDS with NaN bit patterns in front of every op: a kernel that reads LDS it
+    never wrote behind a zero weight (conv_small_cin_kernel did, for the tiny UNet's 48-wide prompt) turns the output into NaN."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    env = dict(os.environ, SD_TUNE="1", SD_POISON_LDS="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_unet_gpu.py"), "-m", "gpu", "-q", "-x", "-k", "tiny or mini"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
