@@ -167,7 +167,8 @@ def f32(a):
 # operator-level wrappers (tests / micro-benchmarks); all take & return the reference layouts
 # ------------------------------------------------------------------------------------------------
 def attention(impl, q, k, v, heads, dim_head, variant=0, iters=1):
-    """attention.py:24-168.  q (B,h*d,1,Sq), k/v (B,h*d,1,Sk) -> (B,h*d,1,Sq) fp16, ms."""
+    """attention.py:24-168.  q (B,h*d,1,Sq), k/v (B,h*d,1,Sk) -> (B,h*d,1,Sq) fp16, ms.  variant: sd_mi355x.h (0 default dispatch, 1 never the
+    d = 64 pipelined kernel, 2 pre-scaled q, 100 + u that kernel's balanced grid with u units per workgroup)."""
     if impl not in ATTENTION_IMPLEMENTATIONS:
         raise ValueError(f"unknown attention implementation {impl!r}")
     q, k, v = f16(q), f16(k), f16(v)
